@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- the mapping optimise iteration of the volumetric-rendering hot path on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full Mapper iteration (reference slams/mapping.py:881-910) on synthetic 640x480 RGB-D+label frames:
+draw pixels -> ray generation + depth-guided sampling -> OneBlob + hash grid -> coarse / per-class fine / colour /
+logit MLPs -> compositing -> the seven loss terms (incl. the 63^3-point smoothness lattice) -> backward to grid,
+MLPs and poses -> (N>1: one flat gradient all-reduce) -> Adam step.  Nothing is skipped inside the timed region.
+Workload = BASELINE.json configs[1]: 4096 rays x 64 samples per GPU, T=2^16 hash grid, 2x64 MLPs, mapping only.
+Weak scaling: every rank renders its own 4096 rays (global batch 4096*N).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant HIP entry point, algorithmic bytes or flops / its summed
+event time, measured on the launch stream inside the timed region) and `cpu_baseline` (the oracle, PyTorch CPU, on
+this host's cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+
+WORKLOADS = {
+    # name: rays/frame (uniform, by-class), n_uniform, n_surface, hash_size, voxel, neurons, layers, smooth_pts
+    "cfg2": dict(rays=(683, 341), nu=48, ns=16, hash_size=16, voxel=0.02, nn=64, nl=2, smooth_pts=64,
+                 desc="BASELINE configs[1]: room_0 bound, 640x480, 4 target frames, 4096 rays x 64 samples, "
+                      "T=2^16 hash grid, 2x64 MLPs, 8 classes + per-class fine decoders, 63^3 smoothness lattice, Adam"),
+    "ref": dict(rays=(332, 166), nu=32, ns=15, hash_size=16, voxel=0.02, nn=32, nl=1, smooth_pts=64,
+                desc="reference Replica defaults: 1992 rays x 47 samples, 1x32 MLPs"),
+}
+
+
+def algorithmic_cost(name, units, wl):
+    """(bytes, flops) one launch of C-ABI entry `name` must move / compute for `units` points."""
+    nn, nl = wl["nn"], wl["nl"]
+    if name == "dns_encode_fwd":
+        return units * (16 * 8 * 2 * 4 + 12), 0            # 1024 B gathered per point + the point
+    if name == "dns_encode_bwd":
+        return units * (2 * 16 * 8 * 2 * 4 + 12), 0        # read-modify-write of the same 128 table cells
+    if name == "dns_composite_fwd" or name == "dns_composite_bwd":
+        return units * 64 * (4 + 1 + 8) * 4, 0             # units = rays; raw + z + logits per sample
+    return 0, 0
+
+
+def build(wl, device, seed, dist_ctx):
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    bound, cam, frames = synthetic.make_scene(4, seed=0)
+    n_per_frame = sum(wl["rays"])
+    cfg = synthetic.default_cfg(n_pixels=4 * n_per_frame, n_samples_ray=wl["nu"], n_surface_ray=wl["ns"], n_frames=4,
+                                hash_size=wl["hash_size"], voxel_size=wl["voxel"], n_neurons=wl["nn"],
+                                n_hidden_layers=wl["nl"], smooth_pts=wl["smooth_pts"])
+    torch.manual_seed(1234)                                  # identical initial parameters on every rank
+    dec = Decoder(cfg["model"], bound, n_class=8).to(device)
+    mapper = Mapper(cfg, dec, bound, cam, device=device)
+    mapper.rays_per_frame = wl["rays"]
+    mapper.dist = dist_ctx
+    mapper.is_BA = True
+    mapper.set_decoder(frames)
+    optimizer, quad_list, T_list = mapper.set_optimizer(frames)
+    optimizer.param_groups[0]["lr"] = mapper.lr
+    optimizer.param_groups[1]["lr"] = mapper.BA_cam_lr
+    optimizer.param_groups[2]["lr"] = mapper.BA_cam_lr
+    prep = mapper.prepare_frames(frames)
+    torch.manual_seed(seed)                                  # per-rank ray draws
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+
+    def step():
+        optimizer.zero_grad(set_to_none=True)
+        samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep)
+        loss, terms = mapper.iteration_loss(samples, lambda_lt=10.0, smooth=True)
+        loss.backward()
+        dist_ctx.allreduce_grads(params)
+        optimizer.step()
+        return loss
+
+    return cfg, bound, cam, frames, mapper, step
+
+
+def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
+    """The oracle (PyTorch CPU fp32 restatement, oracle/) timed on this host: full mapping iterations of the SAME
+    workload (sample -> render -> 7 losses -> backward), as many as fit the budget (>= 1)."""
+    from oracle import slam_ref as sr
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import oracle_cfg_from
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    om = sr.OracleModel(oracle_cfg_from(cfg, 8), bound, fine_classes=frames["label_dict"])
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    from dns_slam_amd.common import get_quad_from_c2w
+    quats = [get_quad_from_c2w(frames["est_c2w"][f]) for f in range(4)]
+    Ts = [frames["est_c2w"][f][:3, 3].clone() for f in range(4)]
+    img5 = [torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
+            for f in range(4)]
+    npf = sum(wl["rays"])
+    lc = sr.LossCfg(smooth_pts=wl["smooth_pts"])
+    g = torch.Generator().manual_seed(0)
+    times = []
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        om.zero_grad()
+        fr = []
+        for f in range(4):
+            idx = torch.randint(cam["H"] * cam["W"], (npf,), generator=g)
+            t = torch.rand(wl["ns"], generator=g)
+            t[wl["ns"] // 2 + 1] = 0.5
+            fr.append(sr.frame_samples(img5[f], quats[f], Ts[f], camt, bound, idx, t, torch.rand(wl["ns"], generator=g),
+                                       wl["nu"], wl["ns"]))
+        so = sr.mapper_target_samples(fr)
+        loss, _, _ = sr.mapping_loss(om, so, lc, torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g))
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 8:
+            break
+    best = min(times)
+    n_samples = 4 * npf * (wl["nu"] + wl["ns"])
+    return {"value": n_samples / best, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full mapping iteration(s) of the same workload (4096 rays x 64 samples + 63^3 "
+                      f"smoothness lattice, fwd+bwd, no optimiser step), best of {len(times)}: {best * 1e3:.0f} ms/iter, "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from dns_slam_amd import dist as ddist
+    from dns_slam_amd import ops
+    ctx = ddist.init_from_env()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    wl = WORKLOADS[args.workload]
+    cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + ctx.rank, dist_ctx=ctx)
+    n_rays = 4 * sum(wl["rays"])
+    S = wl["nu"] + wl["ns"]
+
+    for _ in range(args.warmup):
+        step()
+    ctx.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        ops.timer.arm()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_times = ops.timer.disarm() if not args.no_kernel_timing else {}
+    elapsed = ctx.max_over_ranks(elapsed, device)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = n_rays * S * ctx.world_size / (ms_per_step / 1e3)
+
+    if ctx.rank != 0:
+        return
+    roofline = None
+    breakdown = {}
+    if kernel_times:
+        tot_ms = sum(v[1] for v in kernel_times.values()) or 1.0
+        for k, (calls, ms, units) in sorted(kernel_times.items(), key=lambda kv: -kv[1][1]):
+            breakdown[k] = {"calls_per_step": calls / args.steps, "ms_per_step": ms / args.steps, "share": ms / tot_ms}
+        # dominant memory-bound entry point
+        name = max(kernel_times, key=lambda k: kernel_times[k][1])
+        calls, ms, units = kernel_times[name]
+        nbytes, flops = algorithmic_cost(name, units, wl)
+        if nbytes:
+            ach = nbytes / (ms / 1e3) / 1e9
+            roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": ms / calls, "units_per_step": units / args.steps}
+        else:
+            # MFMA-bound MLP entry points: flops of the launches / time
+            fl = mlp_flops(name, kernel_times, wl, n_rays * S, args.steps)
+            ach = fl / (ms / 1e3) / 1e12
+            roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / calls}
+    out = {
+        "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
+                   "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
+        "roofline": roofline,
+        "kernel_breakdown": breakdown,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, cfg, bound, cam, frames)
+    print(json.dumps(out))
+
+
+def mlp_flops(name, kernel_times, wl, n_points, steps):
+    """Total flops the MLP launches of the timed region performed (forward 2*MACs; backward ~2x forward + recompute)."""
+    nn, nl = wl["nn"], wl["nl"]
+    def macs(n_in, n_out):
+        return n_in * nn + (nl - 1) * nn * nn + nn * n_out
+    lattice = (wl["smooth_pts"] - 1) ** 3
+    per_step_fwd = 2 * (n_points * (2 * macs(80, 33) + macs(112, 3) + macs(112, 8)) + lattice * macs(80, 33))
+    if name == "dns_mlp_fwd":
+        return per_step_fwd * steps
+    return 3 * per_step_fwd * steps        # recompute + data grads + weight grads
+
+
+if __name__ == "__main__":
+    main()

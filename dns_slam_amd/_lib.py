@@ -1,0 +1,99 @@
+"""ctypes binding of libdns_hip.so (C ABI declared in include/dns_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C dns_slam_amd/csrc``.  Loading fails
+loudly: there is no Python or CPU fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdns_hip.so")
+DNS_MAX_LEVELS = 32
+ABI_VERSION = 1
+
+
+class DnsGridMeta(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("log2_hashmap_size", C.c_uint32),
+        ("base_resolution", C.c_uint32), ("total_rows", C.c_uint32), ("per_level_scale", C.c_float),
+        ("scale", C.c_float * DNS_MAX_LEVELS), ("resolution", C.c_uint32 * DNS_MAX_LEVELS),
+        ("size", C.c_uint32 * DNS_MAX_LEVELS), ("offset", C.c_uint32 * DNS_MAX_LEVELS),
+        ("hashed", C.c_uint32 * DNS_MAX_LEVELS),
+    ]
+
+
+_P = C.c_void_p
+_U = C.c_uint32
+_I = C.c_int
+
+# name -> (restype, argtypes); must list every symbol include/dns_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "dns_abi_version": (C.c_int, []),
+    "dns_last_error": (C.c_char_p, []),
+    "dns_grid_meta_init": (C.c_int, [C.POINTER(DnsGridMeta), _U, _U, _U, _U, C.c_double]),
+    "dns_raygen_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I,
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dns_sample_along_rays": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dns_raygen_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dns_encode_fwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _P, _U, _P, _U, _P]),
+    "dns_encode_bwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _U, _P, _U, _P, _P, _P]),
+    "dns_hashgrid_indices": (C.c_int, [_P, _U, C.POINTER(DnsGridMeta), _P, _P]),
+    "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P]),
+    "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P]),
+    "dns_mlp_bwd_ws_floats": (C.c_uint64, [_U, _U, _U]),
+    "dns_composite_fwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P]),
+    "dns_composite_bwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP hot-path library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dns_slam_amd/csrc`). "
+            "dns_slam_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.dns_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"libdns_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Raise on a negative return code: -1 -> ValueError (argument), others -> RuntimeError (launch)."""
+    if rc == 0:
+        return
+    msg = lib.dns_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise ValueError("dns_slam_amd ops run on the GPU only (got a non-CUDA tensor); there is no CPU fallback")
+        if not t.is_contiguous():
+            raise ValueError("dns_slam_amd ops need contiguous tensors")

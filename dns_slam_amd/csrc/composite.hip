@@ -1,0 +1,249 @@
+// Along-ray occupancy compositing: one wave64 per ray, wavefront shuffles for the scan and the reductions.
+//
+// Replaces raw2nerf_color (reference utils/common.py:506-537, occupancy mode) and the logit composite
+// sum_s w_s * logits_s (slams/mapping.py:633, slams/tracking.py:212):
+//   alpha = sigmoid(10 occ);  T_i = prod_{j<i}(1 - alpha_j + 1e-10);  u = alpha T;  w = u / sum(u)  (no eps, D9)
+//   depth = sum w z;  var = sum w (z - depth)^2;  rgb = sum w c;  sem = sum w logits.
+// A lane owns E = ceil(S/64) consecutive samples; the exclusive product is a local product followed by a
+// 6-step wave scan (shuffle-up), reductions are xor-butterflies.  Memory-bound: (4+1+C)*4 B per sample.
+#include "common.hpp"
+
+namespace dns {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// exclusive multiplicative scan across the 64 lanes
+__device__ __forceinline__ float wave_excl_prod(float v, uint32_t lane) {
+  float inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(inc, o);
+    if (lane >= (uint32_t)o) inc *= t;
+  }
+  const float ex = __shfl_up(inc, 1);
+  return lane == 0 ? 1.0f : ex;
+}
+
+// exclusive additive suffix scan: sum over lanes > lane
+__device__ __forceinline__ float wave_suffix_excl_sum(float v, uint32_t lane) {
+  float inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_down(inc, o);
+    if (lane + o < 64u) inc += t;
+  }
+  const float ex = __shfl_down(inc, 1);
+  return lane == 63 ? 0.0f : ex;
+}
+
+__device__ __forceinline__ float sigmoid10(float occ) { return 1.0f / (1.0f + expf(-10.0f * occ)); }
+
+template <int E>
+struct RayState {
+  float alpha[E], om[E], T[E], u[E], w[E], z[E];
+  float sumu, depth;
+};
+
+template <int E>
+__device__ __forceinline__ void ray_forward(const float* __restrict__ raw, const float* __restrict__ zv, uint32_t n,
+                                            uint32_t S, uint32_t lane, RayState<E>& st) {
+  float lp = 1.0f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t s = lane * E + e;
+    const bool ok = s < S;
+    const float occ = ok ? raw[((size_t)n * S + s) * 4 + 3] : 0.f;
+    st.z[e] = ok ? zv[(size_t)n * S + s] : 0.f;
+    st.alpha[e] = ok ? sigmoid10(occ) : 0.f;
+    st.om[e] = ok ? (1.0f - st.alpha[e]) + 1e-10f : 1.0f;
+    st.T[e] = lp;  // local exclusive product
+    lp *= st.om[e];
+  }
+  const float pre = wave_excl_prod(lp, lane);
+  float su = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    st.T[e] *= pre;
+    st.u[e] = st.alpha[e] * st.T[e];
+    su += st.u[e];
+  }
+  st.sumu = wave_sum(su);
+  float sd = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    st.w[e] = st.u[e] / st.sumu;
+    sd += st.w[e] * st.z[e];
+  }
+  st.depth = wave_sum(sd);
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ zv,
+                                                            const float* __restrict__ logits, uint32_t N, uint32_t S,
+                                                            uint32_t C, float* __restrict__ depth, float* __restrict__ var,
+                                                            float* __restrict__ rgb, float* __restrict__ weights,
+                                                            float* __restrict__ sem) {
+  extern __shared__ float lds[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float* wl = lds + wave * (64 * E);
+  RayState<E> st;
+  ray_forward<E>(raw, zv, n, S, lane, st);
+  float sv = 0.f, sc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t s = lane * E + e;
+    const float t = st.z[e] - st.depth;
+    sv += st.w[e] * t * t;
+    if (s < S) {
+      const float* r = raw + ((size_t)n * S + s) * 4;
+      sc[0] += st.w[e] * r[0];
+      sc[1] += st.w[e] * r[1];
+      sc[2] += st.w[e] * r[2];
+      if (weights) weights[(size_t)n * S + s] = st.w[e];
+    }
+    wl[s] = st.w[e];
+  }
+  sv = wave_sum(sv);
+  sc[0] = wave_sum(sc[0]);
+  sc[1] = wave_sum(sc[1]);
+  sc[2] = wave_sum(sc[2]);
+  if (lane == 0) {
+    depth[n] = st.depth;
+    var[n] = sv;
+    rgb[(size_t)n * 3 + 0] = sc[0];
+    rgb[(size_t)n * 3 + 1] = sc[1];
+    rgb[(size_t)n * 3 + 2] = sc[2];
+  }
+  if (C) {
+    // lanes over classes: coalesced reads of logits[n, s, :], w_s broadcast from LDS (wave-private, no barrier)
+    for (uint32_t c = lane; c < C; c += 64) {
+      float acc = 0.f;
+      const float* lp = logits + (size_t)n * S * C + c;
+      for (uint32_t s = 0; s < S; ++s) acc += wl[s] * lp[(size_t)s * C];
+      sem[(size_t)n * C + c] = acc;
+    }
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ zv,
+                                                            const float* __restrict__ logits, uint32_t N, uint32_t S,
+                                                            uint32_t C, const float* __restrict__ d_depth,
+                                                            const float* __restrict__ d_var, const float* __restrict__ d_rgb,
+                                                            const float* __restrict__ d_weights,
+                                                            const float* __restrict__ d_sem, float* __restrict__ d_raw,
+                                                            float* __restrict__ d_logits) {
+  extern __shared__ float lds[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float* wl = lds + wave * (64 * E);
+  RayState<E> st;
+  ray_forward<E>(raw, zv, n, S, lane, st);
+  const float gD = d_depth ? d_depth[n] : 0.f;
+  const float gV = d_var ? d_var[n] : 0.f;
+  float gc[3] = {0.f, 0.f, 0.f};
+  if (d_rgb) {
+    gc[0] = d_rgb[(size_t)n * 3];
+    gc[1] = d_rgb[(size_t)n * 3 + 1];
+    gc[2] = d_rgb[(size_t)n * 3 + 2];
+  }
+  // g_i = dL/dw_i (w treated as free), then through the normalisation and the transmittance product
+  float g[E];
+  float gbar = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t s = lane * E + e;
+    g[e] = 0.f;
+    if (s < S) {
+      const float* r = raw + ((size_t)n * S + s) * 4;
+      const float t = st.z[e] - st.depth;
+      float v = gc[0] * r[0] + gc[1] * r[1] + gc[2] * r[2] + gD * st.z[e] + gV * t * t;
+      if (d_weights) v += d_weights[(size_t)n * S + s];
+      if (C && d_sem) {
+        const float* lp = logits + ((size_t)n * S + s) * C;
+        const float* gs = d_sem + (size_t)n * C;
+        float dot = 0.f;
+        for (uint32_t c = 0; c < C; ++c) dot += gs[c] * lp[c];
+        v += dot;
+      }
+      g[e] = v;
+    }
+    gbar += st.w[e] * g[e];
+    wl[s] = st.w[e];
+  }
+  gbar = wave_sum(gbar);
+  float du[E], lsum = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    du[e] = (g[e] - gbar) / st.sumu;
+    lsum += du[e] * st.u[e];
+  }
+  const float after = wave_suffix_excl_sum(lsum, lane);  // sum over later lanes of du*u
+  float tail = after;
+#pragma unroll
+  for (int e = E - 1; e >= 0; --e) {
+    const uint32_t s = lane * E + e;
+    const float dalpha = du[e] * st.T[e] - tail / st.om[e];
+    tail += du[e] * st.u[e];
+    if (s < S) {
+      float* o = d_raw + ((size_t)n * S + s) * 4;
+      o[0] = st.w[e] * gc[0];
+      o[1] = st.w[e] * gc[1];
+      o[2] = st.w[e] * gc[2];
+      o[3] = 10.0f * st.alpha[e] * (1.0f - st.alpha[e]) * dalpha;
+    }
+  }
+  if (C && d_logits) {
+    for (uint32_t c = lane; c < C; c += 64) {
+      const float gs = d_sem ? d_sem[(size_t)n * C + c] : 0.f;
+      float* lp = d_logits + (size_t)n * S * C + c;
+      for (uint32_t s = 0; s < S; ++s) lp[(size_t)s * C] = wl[s] * gs;
+    }
+  }
+}
+
+}  // namespace dns
+
+using namespace dns;
+
+extern "C" int dns_composite_fwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
+                                 uint32_t C, float* depth, float* var, float* rgb, float* weights, float* sem,
+                                 void* stream) {
+  DNS_REQUIRE(raw && z && depth && var && rgb, "dns_composite_fwd: NULL argument");
+  DNS_REQUIRE(S >= 1 && S <= 256, "dns_composite_fwd: S=%u out of range [1,256]", S);
+  DNS_REQUIRE(C == 0 || (logits && sem), "dns_composite_fwd: C>0 needs logits and sem");
+  if (N == 0) return DNS_OK;
+  const uint32_t blocks = (N + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
+  const size_t ldsb = 4 * 64 * E * sizeof(float);
+  if (E == 1) hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
+  else if (E == 2) hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
+  else hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
+  return check_launch("dns_composite_fwd");
+}
+
+extern "C" int dns_composite_bwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
+                                 uint32_t C, const float* d_depth, const float* d_var, const float* d_rgb,
+                                 const float* d_weights, const float* d_sem, float* d_raw, float* d_logits,
+                                 void* stream) {
+  DNS_REQUIRE(raw && z && d_raw, "dns_composite_bwd: NULL argument");
+  DNS_REQUIRE(S >= 1 && S <= 256, "dns_composite_bwd: S=%u out of range [1,256]", S);
+  DNS_REQUIRE(C == 0 || logits, "dns_composite_bwd: C>0 needs logits");
+  if (N == 0) return DNS_OK;
+  const uint32_t blocks = (N + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
+  const size_t ldsb = 4 * 64 * E * sizeof(float);
+  if (E == 1) hipLaunchKernelGGL(composite_bwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
+  else if (E == 2) hipLaunchKernelGGL(composite_bwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
+  else hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
+  return check_launch("dns_composite_bwd");
+}

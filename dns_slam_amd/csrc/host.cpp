@@ -1,0 +1,62 @@
+// Host-only pieces of the C ABI: error slot, ABI version, hash-grid level table.
+#include <math.h>
+#include <string.h>
+#include "common.hpp"
+
+namespace dns {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace dns
+
+extern "C" int dns_abi_version(void) { return DNS_ABI_VERSION; }
+extern "C" const char* dns_last_error(void) { return dns::g_err; }
+
+// tcnn GridEncoding constructor arithmetic:
+//   scale = exp2(l * log2(pls)) * base - 1;  res = ceilf(scale) + 1;
+// tcnn evaluates `scale` in float32 with CUDA's exp2f, whose last bits no other platform reproduces; at the
+// finest level the exact value is an integer (desired_resolution - 1), so one ulp flips the resolution.  The
+// table is therefore DEFINED here as the float64 value rounded once to float32 (finest level = exactly
+// desired_resolution - 1), computed on the host only and handed to every kernel and to the oracle's check.
+//   size  = min(next_multiple(res^3, 8), 2^log2_T);
+//   dense index while the running stride stays <= size, hashed once it exceeds it.
+extern "C" int dns_grid_meta_init(DnsGridMeta* meta, uint32_t n_levels, uint32_t n_features,
+                                  uint32_t log2_hashmap_size, uint32_t base_resolution, double per_level_scale) {
+  DNS_REQUIRE(meta != nullptr, "dns_grid_meta_init: meta is NULL");
+  DNS_REQUIRE(n_levels >= 1 && n_levels <= DNS_MAX_LEVELS, "dns_grid_meta_init: n_levels %u out of range", n_levels);
+  DNS_REQUIRE(n_features == 2, "dns_grid_meta_init: only 2 features per level are supported (got %u)", n_features);
+  DNS_REQUIRE(log2_hashmap_size >= 3 && log2_hashmap_size <= 28, "dns_grid_meta_init: log2_hashmap_size %u", log2_hashmap_size);
+  memset(meta, 0, sizeof(*meta));
+  meta->n_levels = n_levels;
+  meta->n_features = n_features;
+  meta->log2_hashmap_size = log2_hashmap_size;
+  meta->base_resolution = base_resolution;
+  meta->per_level_scale = (float)per_level_scale;
+  const double log2_pls = log2(per_level_scale);
+  const uint32_t T = 1u << log2_hashmap_size;
+  uint64_t offset = 0;
+  for (uint32_t l = 0; l < n_levels; ++l) {
+    volatile double e = exp2((double)l * log2_pls);      // volatile: no fused contraction into the mul/sub below
+    volatile double m = e * (double)base_resolution;
+    const float scale = (float)(m - 1.0);
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    uint64_t dense = (uint64_t)res * res * res;
+    dense = (dense + 7u) / 8u * 8u;
+    const uint32_t size = dense < T ? (uint32_t)dense : T;
+    uint32_t stride = 1;
+    for (int d = 0; d < 3 && stride <= size; ++d) stride *= res;   // uint32 wrap, as tcnn
+    meta->scale[l] = scale;
+    meta->resolution[l] = res;
+    meta->size[l] = size;
+    meta->offset[l] = (uint32_t)offset;
+    meta->hashed[l] = size < stride ? 1u : 0u;
+    offset += size;
+    DNS_REQUIRE(offset < (1ull << 31), "dns_grid_meta_init: table too large");
+  }
+  meta->total_rows = (uint32_t)offset;
+  return DNS_OK;
+}

@@ -1,0 +1,617 @@
+// Bias-free ReLU MLP on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces tcnn.Network{CutlassMLP} (reference models/decoder.py:58-64,84-90,101-116,
+// slams/mapping.py:737-743): y = W_out relu(W_h relu(W_in x)), no bias.
+//
+// Orientation (CDNA4-first, not a CUTLASS tiling): POINTS live on the MFMA column/lane axis, weights are
+// the A operand.  D[32 feat x 32 pts] += A[32 feat x 2] * B[2 x 32 pts]:
+//   lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; D: col = l&31, row = (r&3)+8*(r>>2)+4*(l>>5).
+// With points on lanes, a layer's accumulator IS the next layer's B operand (lane half h already holds the
+// rows whose bit 2 equals h), so activations never leave registers between layers: no LDS round trip, no
+// transposes.  Weights are staged once per workgroup into LDS in "A-operand images" -- for each k-step the
+// 64 dwords the 64 lanes need, contiguous -- so every A fetch is one conflict-free ds_read_b32.
+// Input rows are read as two contiguous halves (lane half h reads x[row][h*K/2 .. ) as float4).
+//
+// A workgroup = 4 waves = 128 point slots; a wave = one 32-point tile.  Optional row_index maps slot ->
+// row of x / y (-1 = padding) and tile_group selects per-128-slot weight sets (per-class fine decoders,
+// slams/mapping.py:590-601) without copying activations.
+//
+// Roofline: exact-fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s); these kernels are MFMA-bound for
+// n_in >= 80 (x traffic 320-448 B/point vs 14-45 kFLOP/point).
+#include "common.hpp"
+
+namespace dns {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t acc_row(uint32_t r, uint32_t h) { return (r & 3u) + 8u * (r >> 2) + 4u * h; }
+
+enum KMap { K_SPLIT = 0, K_CHAIN = 1 };
+
+// A-operand image: img[(rt*nsteps + s)*64 + lane] = Meff[rt*32 + (lane&31)][kmap(s, lane>>5)]
+// Meff[i][k] = transpose ? M[k][i] : M[i][k];  M is row-major [R x C] (logical rows/cols of M).
+// K_SPLIT: k = h*khalf + s (s < khalf);  K_CHAIN: k = (s/16)*32 + acc_row(s%16, h).
+__device__ void build_image(float* __restrict__ img, const float* __restrict__ M, uint32_t R, uint32_t C, bool transpose,
+                            uint32_t row_tiles, uint32_t nsteps, int kmap, uint32_t khalf, uint32_t klimit) {
+  const uint32_t total = row_tiles * nsteps * 64u;
+  for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const uint32_t lane = e & 63u;
+    const uint32_t s = (e >> 6) % nsteps;
+    const uint32_t rt = (e >> 6) / nsteps;
+    const uint32_t i = rt * 32u + (lane & 31u);
+    const uint32_t h = lane >> 5;
+    const uint32_t k = (kmap == K_SPLIT) ? (h * khalf + s) : ((s >> 4) * 32u + acc_row(s & 15u, h));
+    float v = 0.f;
+    if (k < klimit) {
+      if (!transpose) {
+        if (i < R && k < C) v = M[(size_t)i * C + k];
+      } else {
+        if (k < R && i < C) v = M[(size_t)k * C + i];
+      }
+    }
+    img[e] = v;
+  }
+}
+
+// VALU-row image for the trailing (n_out % 32) output rows: imgv[(v*nsteps + s)*2 + h] = W[row0+v][chain k(s,h)]
+__device__ void build_valu_image(float* __restrict__ img, const float* __restrict__ W, uint32_t row0, uint32_t nrows,
+                                 uint32_t C, uint32_t nsteps) {
+  const uint32_t total = nrows * nsteps * 2u;
+  for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const uint32_t h = e & 1u;
+    const uint32_t s = (e >> 1) % nsteps;
+    const uint32_t v = (e >> 1) / nsteps;
+    const uint32_t k = (s >> 4) * 32u + acc_row(s & 15u, h);
+    img[e] = W[(size_t)(row0 + v) * C + k];
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+struct MlpShape {
+  uint32_t n_in, n_out, out_pad;
+  uint32_t mt;   // MFMA output row tiles
+  uint32_t vr;   // trailing output rows done on the VALU
+};
+
+__host__ __device__ inline MlpShape make_shape(uint32_t n_in, uint32_t n_out) {
+  MlpShape s;
+  s.n_in = n_in;
+  s.n_out = n_out;
+  s.out_pad = (n_out + 15u) / 16u * 16u;
+  s.mt = n_out / 32u;
+  s.vr = n_out - 32u * s.mt;
+  if (s.vr > 8u) {
+    s.mt += 1;
+    s.vr = 0;
+  }
+  return s;
+}
+
+// ---- layer 0: acc[t] = W_in[t-th 32 rows] * x  (x streamed from global as float4, split halves) ----
+template <int NT>
+__device__ __forceinline__ void layer_in(const float* __restrict__ xrow, bool valid, uint32_t khalf,
+                                         const float* __restrict__ img, uint32_t lane, f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = zero16();
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xrow);
+  const uint32_t n4 = khalf >> 2;
+#pragma unroll 2
+  for (uint32_t q = 0; q < n4; ++q) {
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) xv = x4[q];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t s = q * 4 + e;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float a = img[(t * khalf + s) * 64u + lane];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[e], acc[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// ---- chained layer: out[t] = W[t-th 32 rows] * act   (act in accumulator layout = B operand) ----
+template <int NT_OUT, int NT_IN>
+__device__ __forceinline__ void layer_chain(const f32x16 (&act)[NT_IN], const float* __restrict__ img, uint32_t lane,
+                                            uint32_t out_tiles, f32x16 (&out)[NT_OUT]) {
+  constexpr uint32_t nsteps = NT_IN * 16;
+#pragma unroll
+  for (int t = 0; t < NT_OUT; ++t) out[t] = zero16();
+#pragma unroll
+  for (int ti = 0; ti < NT_IN; ++ti) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t s = ti * 16 + r;
+      const float b = act[ti][r];
+#pragma unroll
+      for (int t = 0; t < NT_OUT; ++t) {
+        if ((uint32_t)t < out_tiles) {
+          const float a = img[(t * nsteps + s) * 64u + lane];
+          out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void relu(f32x16 (&a)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[t][r] = fmaxf(a[t][r], 0.f);
+}
+
+__device__ __forceinline__ uint32_t param_off_hidden(uint32_t nn, uint32_t n_in) { return nn * n_in; }
+
+// LDS layout helpers (floats)
+template <int NN, int NL>
+struct FwdLds {
+  static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
+  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return NN * n_in; }
+  static __host__ __device__ uint32_t img_out(uint32_t n_in) { return NN * n_in + (NL - 1) * NN * NN; }
+  static __host__ __device__ uint32_t img_valu(uint32_t n_in, uint32_t mt) { return img_out(n_in) + mt * 32 * NN; }
+  static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t mt, uint32_t vr) { return img_valu(n_in, mt) + vr * NN; }
+};
+
+template <int NN, int NL>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ x, uint32_t ldx,
+                                                      const float* __restrict__ params, MlpShape sh,
+                                                      float* __restrict__ y, uint32_t ldy, uint32_t n_slots,
+                                                      const int32_t* __restrict__ row_index,
+                                                      const int32_t* __restrict__ tile_group, uint32_t param_stride,
+                                                      uint32_t tiles_per_block) {
+  constexpr int NT = NN / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using L = FwdLds<NN, NL>;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t khalf = sh.n_in / 2;
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  const uint32_t bt0 = blockIdx.x * tiles_per_block;
+  const uint32_t bt1 = min(bt0 + tiles_per_block, n_btiles);
+  int cur_group = -2;
+  for (uint32_t bt = bt0; bt < bt1; ++bt) {
+    const int grp = tile_group ? tile_group[bt] : 0;
+    if (grp != cur_group) {
+      __syncthreads();
+      if (grp >= 0) {
+        const float* pw = params + (size_t)grp * param_stride;
+        build_image(lds + L::img_in(sh.n_in), pw, NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
+        if (NL == 2)
+          build_image(lds + L::img_h(sh.n_in), pw + NN * sh.n_in, NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+        const float* wout = pw + NN * sh.n_in + (NL - 1) * NN * NN;
+        if (sh.mt) build_image(lds + L::img_out(sh.n_in), wout, sh.n_out, NN, false, sh.mt, NN / 2, K_CHAIN, 0, NN);
+        if (sh.vr) build_valu_image(lds + L::img_valu(sh.n_in, sh.mt), wout, sh.mt * 32, sh.vr, NN, NN / 2);
+      }
+      cur_group = grp;
+      __syncthreads();
+    }
+    if (grp < 0) continue;
+    const uint32_t slot = bt * 128u + wave * 32u + (lane & 31u);
+    const uint32_t h = lane >> 5;
+    int row = -1;
+    if (slot < n_slots) row = row_index ? row_index[slot] : (int)slot;
+    const bool valid = row >= 0;
+    const float* xrow = x + (size_t)(valid ? row : 0) * ldx + h * khalf;
+
+    f32x16 a0[NT];
+    layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, a0);
+    relu<NT>(a0);
+    f32x16 a1[NT];
+    if (NL == 2) {
+      layer_chain<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, NT, a1);
+      relu<NT>(a1);
+    }
+    const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
+    float* yrow = y + (size_t)(valid ? row : 0) * ldy;
+    if (sh.mt) {
+      f32x16 o[2];
+      layer_chain<2, NT>(hl, lds + L::img_out(sh.n_in), lane, sh.mt, o);
+      if (valid) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if ((uint32_t)t < sh.mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t orow = t * 32 + acc_row(r, h);
+              if (orow < sh.n_out) yrow[orow] = o[t][r];
+            }
+          }
+        }
+      }
+    }
+    if (sh.vr) {
+      const float* iv = lds + L::img_valu(sh.n_in, sh.mt);
+      for (uint32_t v = 0; v < sh.vr; ++v) {
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += iv[(v * (NN / 2) + t * 16 + r) * 2 + h] * hl[t][r];
+        sum += __shfl_xor(sum, 32);
+        if (valid && h == 0) yrow[sh.mt * 32 + v] = sum;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward, data path: recompute hidden activations, dH_l = W^T dH_{l+1} (.) relu', dX = W_in^T dH_1.
+// Writes H_l and dH_l (slot-major [n_slots, NN]) to the workspace for the weight-gradient GEMMs.
+// ws layout: [H_1 | dH_1 | H_2 | dH_2] each n_slots*NN floats.
+template <int NN, int NL>
+struct BwdLds {
+  static __host__ __device__ uint32_t in_pad(uint32_t n_in) { return (n_in + 31u) / 32u * 32u; }
+  static __host__ __device__ uint32_t ko2(uint32_t n_out) { return (n_out + 1u) / 2u; }
+  static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
+  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return NN * n_in; }
+  static __host__ __device__ uint32_t img_outT(uint32_t n_in) { return img_h(n_in) + (NL - 1) * NN * NN; }
+  static __host__ __device__ uint32_t img_hT(uint32_t n_in, uint32_t n_out) { return img_outT(n_in) + NN * 2 * ko2(n_out); }
+  static __host__ __device__ uint32_t img_inT(uint32_t n_in, uint32_t n_out) { return img_hT(n_in, n_out) + (NL - 1) * NN * NN; }
+  static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, bool need_dx) {
+    return img_inT(n_in, n_out) + (need_dx ? in_pad(n_in) * NN : 0);
+  }
+};
+
+template <int NT>
+__device__ __forceinline__ void store_acc_rows(float* __restrict__ dst, const f32x16 (&a)[NT], uint32_t h) {
+  // dst = row base of a [NN]-wide slot row; 4 contiguous floats per (tile, quad)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+      *reinterpret_cast<float4*>(dst + t * 32 + 8 * q + 4 * h) = v;
+    }
+}
+
+template <int NN, int NL>
+__global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const float* __restrict__ x, uint32_t ldx,
+                                                           const float* __restrict__ dy, uint32_t lddy,
+                                                           const float* __restrict__ params, MlpShape sh,
+                                                           float* __restrict__ dx, uint32_t lddx,
+                                                           float* __restrict__ ws, uint32_t n_slots,
+                                                           const int32_t* __restrict__ row_index,
+                                                           const int32_t* __restrict__ tile_group,
+                                                           uint32_t param_stride, uint32_t tiles_per_block) {
+  constexpr int NT = NN / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using L = BwdLds<NN, NL>;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t khalf = sh.n_in / 2;
+  const uint32_t ko2 = L::ko2(sh.n_out);
+  const uint32_t in_tiles = L::in_pad(sh.n_in) / 32u;
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  const uint32_t bt0 = blockIdx.x * tiles_per_block;
+  const uint32_t bt1 = min(bt0 + tiles_per_block, n_btiles);
+  float* wsH1 = ws;
+  float* wsD1 = ws + (size_t)n_slots * NN;
+  float* wsH2 = ws + (size_t)2 * n_slots * NN;
+  float* wsD2 = ws + (size_t)3 * n_slots * NN;
+  int cur_group = -2;
+  for (uint32_t bt = bt0; bt < bt1; ++bt) {
+    const int grp = tile_group ? tile_group[bt] : 0;
+    if (grp != cur_group) {
+      __syncthreads();
+      if (grp >= 0) {
+        const float* pw = params + (size_t)grp * param_stride;
+        const float* wh = pw + NN * sh.n_in;
+        const float* wout = wh + (NL - 1) * NN * NN;
+        build_image(lds + L::img_in(sh.n_in), pw, NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
+        if (NL == 2) {
+          build_image(lds + L::img_h(sh.n_in), wh, NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+          build_image(lds + L::img_hT(sh.n_in, sh.n_out), wh, NN, NN, true, NT, NN / 2, K_CHAIN, 0, NN);
+        }
+        // A = W_out^T: rows = hidden (NN), k over outputs in split halves of ko2
+        build_image(lds + L::img_outT(sh.n_in), wout, sh.n_out, NN, true, NT, ko2, K_SPLIT, ko2, sh.n_out);
+        if (dx) build_image(lds + L::img_inT(sh.n_in, sh.n_out), pw, NN, sh.n_in, true, in_tiles, NN / 2, K_CHAIN, 0, NN);
+      }
+      cur_group = grp;
+      __syncthreads();
+    }
+    const uint32_t slot = bt * 128u + wave * 32u + (lane & 31u);
+    const uint32_t h = lane >> 5;
+    int row = -1;
+    if (slot < n_slots && grp >= 0) row = row_index ? row_index[slot] : (int)slot;
+    const bool valid = row >= 0;
+    if (grp < 0) {
+      // padding tile of an empty group: zero its workspace rows so the weight GEMMs see zeros
+      if (slot < n_slots) {
+        f32x16 z[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) z[t] = zero16();
+        store_acc_rows<NT>(wsH1 + (size_t)slot * NN, z, h);
+        store_acc_rows<NT>(wsD1 + (size_t)slot * NN, z, h);
+        if (NL == 2) {
+          store_acc_rows<NT>(wsH2 + (size_t)slot * NN, z, h);
+          store_acc_rows<NT>(wsD2 + (size_t)slot * NN, z, h);
+        }
+      }
+      continue;
+    }
+    const float* xrow = x + (size_t)(valid ? row : 0) * ldx + h * khalf;
+    f32x16 h1[NT], h2[NT];
+    layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, h1);
+    relu<NT>(h1);
+    if (NL == 2) {
+      layer_chain<NT, NT>(h1, lds + L::img_h(sh.n_in), lane, NT, h2);
+      relu<NT>(h2);
+    }
+    // dH_last = W_out^T dY
+    f32x16 dl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dl[t] = zero16();
+    {
+      const float* dyrow = dy + (size_t)(valid ? row : 0) * lddy;
+      const float* img = lds + L::img_outT(sh.n_in);
+      for (uint32_t s = 0; s < ko2; ++s) {
+        const uint32_t k = h * ko2 + s;
+        const float b = (valid && k < sh.n_out) ? dyrow[k] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float a = img[(t * ko2 + s) * 64u + lane];
+          dl[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dl[t], 0, 0, 0);
+        }
+      }
+    }
+    const f32x16(&hl)[NT] = (NL == 2) ? h2 : h1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dl[t][r] = hl[t][r] > 0.f ? dl[t][r] : 0.f;
+    f32x16 d1[NT];
+    if (NL == 2) {
+      layer_chain<NT, NT>(dl, lds + L::img_hT(sh.n_in, sh.n_out), lane, NT, d1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[t][r] = h1[t][r] > 0.f ? d1[t][r] : 0.f;
+    }
+    const f32x16(&dfirst)[NT] = (NL == 2) ? d1 : dl;
+    if (slot < n_slots) {
+      store_acc_rows<NT>(wsH1 + (size_t)slot * NN, h1, h);
+      store_acc_rows<NT>(wsD1 + (size_t)slot * NN, dfirst, h);
+      if (NL == 2) {
+        store_acc_rows<NT>(wsH2 + (size_t)slot * NN, h2, h);
+        store_acc_rows<NT>(wsD2 + (size_t)slot * NN, dl, h);
+      }
+    }
+    if (dx) {
+      // dX = W_in^T dH_1, two input tiles at a time to bound accumulator registers
+      const float* img = lds + L::img_inT(sh.n_in, sh.n_out);
+      float* dxrow = dx + (size_t)(valid ? row : 0) * lddx;
+      for (uint32_t it0 = 0; it0 < in_tiles; it0 += 2) {
+        f32x16 o[2];
+        const uint32_t nt = min(2u, in_tiles - it0);
+        layer_chain<2, NT>(dfirst, img + (size_t)it0 * (NN / 2) * 64u, lane, nt, o);
+        if (valid) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if ((uint32_t)t < nt) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const uint32_t c0 = (it0 + t) * 32 + 8 * q + 4 * h;
+                if (c0 + 3 < sh.n_in) {
+                  if ((lddx & 3u) == 0) {
+                    *reinterpret_cast<float4*>(dxrow + c0) = make_float4(o[t][4 * q], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]);
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dxrow[c0 + e] = o[t][4 * q + e];
+                  }
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (c0 + e < sh.n_in) dxrow[c0 + e] = o[t][4 * q + e];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients: C[M x N] += sum_p A[p][m] * B[p][n]   (K dimension = points), per parameter group.
+// A operand lane (i,h) reads A[p0+2s+h][mt*32+i]; B operand lane (j,h) reads B[p0+2s+h][nt*32+j]: both are
+// 128-byte row segments straight from global/L2 -- no LDS.  Each wave owns up to 2 of the <=8 output tiles.
+struct GemmTnArgs {
+  const float* A;
+  uint32_t lda;
+  const int32_t* a_index;  // optional slot -> row (-1 = zero row)
+  uint32_t M;
+  const float* B;
+  uint32_t ldb;
+  const int32_t* b_index;
+  uint32_t N;
+  float* C;                // [M x ldc] (+ group*c_stride)
+  uint32_t ldc;
+  uint32_t c_stride;
+  uint32_t n_slots;
+  const int32_t* tile_group;  // per 128 slots
+  uint32_t tiles_per_block;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t MT = (g.M + 31u) / 32u, NT = (g.N + 31u) / 32u;
+  const uint32_t ntiles = MT * NT;
+  const uint32_t n_btiles = (g.n_slots + 127u) / 128u;
+  const uint32_t bt0 = blockIdx.x * g.tiles_per_block;
+  const uint32_t bt1 = min(bt0 + g.tiles_per_block, n_btiles);
+  const uint32_t i = lane & 31u, h = lane >> 5;
+  f32x16 acc[2];
+  acc[0] = zero16();
+  acc[1] = zero16();
+  uint32_t tile_id[2] = {wave, wave + 4u};
+  int cur_group = -2;
+  auto flush = [&](int grp) {
+    if (grp < 0) return;
+    float* C = g.C + (size_t)grp * g.c_stride;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (tile_id[t] < ntiles) {
+        const uint32_t mt = tile_id[t] / NT, nt = tile_id[t] % NT;
+        const uint32_t col = nt * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t row = mt * 32 + acc_row(r, h);
+          if (row < g.M && col < g.N) atomicAdd(C + (size_t)row * g.ldc + col, acc[t][r]);
+        }
+      }
+      acc[t] = zero16();
+    }
+  };
+  for (uint32_t bt = bt0; bt < bt1; ++bt) {
+    const int grp = g.tile_group ? g.tile_group[bt] : 0;
+    if (grp != cur_group) {
+      flush(cur_group);
+      cur_group = grp;
+    }
+    if (grp < 0) continue;
+    const uint32_t p0 = bt * 128u;
+#pragma unroll 4
+    for (uint32_t s = 0; s < 64u; ++s) {
+      const uint32_t slot = p0 + 2 * s + h;
+      int ra = -1, rb = -1;
+      if (slot < g.n_slots) {
+        ra = g.a_index ? g.a_index[slot] : (int)slot;
+        rb = g.b_index ? g.b_index[slot] : (int)slot;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (tile_id[t] < ntiles) {
+          const uint32_t mt = tile_id[t] / NT, nt = tile_id[t] % NT;
+          const uint32_t ca = mt * 32 + i, cb = nt * 32 + i;
+          const float a = (ra >= 0 && ca < g.M) ? g.A[(size_t)ra * g.lda + ca] : 0.f;
+          const float b = (rb >= 0 && cb < g.N) ? g.B[(size_t)rb * g.ldb + cb] : 0.f;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  flush(cur_group);
+}
+
+static bool shape_ok(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
+  return (nn == 32 || nn == 64) && (nl == 1 || nl == 2) && n_in >= 8 && n_in <= 128 && (n_in % 8) == 0 && n_out >= 1 &&
+         n_out <= 64;
+}
+
+static uint32_t pick_tiles_per_block(uint32_t n_btiles, const int32_t* tile_group) {
+  // persistent-ish: ~2 workgroups per CU, contiguous ranges so a group's LDS images are rebuilt rarely
+  const uint32_t target_blocks = 512;
+  uint32_t tpb = (n_btiles + target_blocks - 1) / target_blocks;
+  if (tpb < 1) tpb = 1;
+  (void)tile_group;
+  return tpb;
+}
+
+}  // namespace dns
+
+using namespace dns;
+
+extern "C" uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers) {
+  return (uint64_t)2 * n_hidden_layers * n_slots * n_neurons;
+}
+
+extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
+                           uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
+                           const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream) {
+  DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
+  DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
+              n_in, n_out, n_neurons, n_hidden_layers);
+  DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
+  DNS_REQUIRE(ldy >= n_out, "dns_mlp_fwd: ldy < n_out");
+  if (n_slots == 0) return DNS_OK;
+  const MlpShape sh = make_shape(n_in, n_out);
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  const uint32_t tpb = pick_tiles_per_block(n_btiles, tile_group);
+  const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_FWD(NN, NL)                                                                                         \
+  {                                                                                                                \
+    const size_t lds_bytes = (size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) * sizeof(float);                    \
+    hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, params, sh, y, ldy, \
+                       n_slots, row_index, tile_group, param_stride, tpb);                                         \
+  }
+  if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
+  else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
+  else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_FWD(64, 1)
+  else LAUNCH_FWD(64, 2)
+#undef LAUNCH_FWD
+  return check_launch("dns_mlp_fwd");
+}
+
+extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
+                           uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* d_x,
+                           uint32_t lddx, float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
+                           const int32_t* tile_group, uint32_t param_stride, void* stream) {
+  DNS_REQUIRE(x && dy && params && ws, "dns_mlp_bwd: NULL argument");
+  DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
+              n_in, n_out, n_neurons, n_hidden_layers);
+  DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_bwd: x must be 16-byte aligned with ldx %% 4 == 0");
+  DNS_REQUIRE((((uintptr_t)ws) % 16) == 0, "dns_mlp_bwd: ws must be 16-byte aligned");
+  if (d_x) DNS_REQUIRE(lddx >= n_in && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
+  if (n_slots == 0) return DNS_OK;
+  const MlpShape sh = make_shape(n_in, n_out);
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  const uint32_t tpb = pick_tiles_per_block(n_btiles, tile_group);
+  const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t NNr = n_neurons;
+#define LAUNCH_BWD(NN, NL)                                                                                          \
+  {                                                                                                                 \
+    const size_t lds_bytes = (size_t)BwdLds<NN, NL>::total(n_in, n_out, d_x != nullptr) * sizeof(float);            \
+    hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                        (int)lds_bytes);                                                                            \
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, dy, lddy,     \
+                       params, sh, d_x, lddx, ws, n_slots, row_index, tile_group, param_stride, tpb);               \
+  }
+  if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_BWD(32, 1)
+  else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_BWD(32, 2)
+  else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_BWD(64, 1)
+  else LAUNCH_BWD(64, 2)
+#undef LAUNCH_BWD
+  int rc = check_launch("dns_mlp_bwd(data)");
+  if (rc != DNS_OK) return rc;
+  if (!d_params) return DNS_OK;
+  // weight gradients: dW_in = dH1^T X ; dW_h = dH2^T H1 ; dW_out = dY^T H_last
+  const size_t SN = (size_t)n_slots * NNr;
+  float* wsH1 = ws;
+  float* wsD1 = ws + SN;
+  float* wsH2 = ws + 2 * SN;
+  float* wsD2 = ws + 3 * SN;
+  GemmTnArgs g;
+  g.n_slots = n_slots;
+  g.tile_group = tile_group;
+  g.tiles_per_block = tpb;
+  g.c_stride = param_stride;
+  // dW_in [NN x n_in]
+  g.A = wsD1; g.lda = NNr; g.a_index = nullptr; g.M = NNr;
+  g.B = x; g.ldb = ldx; g.b_index = row_index; g.N = n_in;
+  g.C = d_params; g.ldc = n_in;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), 0, st, g);
+  float* dwo = d_params + (size_t)NNr * n_in;
+  if (n_hidden_layers == 2) {
+    g.A = wsD2; g.lda = NNr; g.a_index = nullptr; g.M = NNr;
+    g.B = wsH1; g.ldb = NNr; g.b_index = nullptr; g.N = NNr;
+    g.C = dwo; g.ldc = NNr;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), 0, st, g);
+    dwo += (size_t)NNr * NNr;
+  }
+  g.A = dy; g.lda = lddy; g.a_index = row_index; g.M = n_out;
+  g.B = (n_hidden_layers == 2) ? wsH2 : wsH1; g.ldb = NNr; g.b_index = nullptr; g.N = NNr;
+  g.C = dwo; g.ldc = NNr;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), 0, st, g);
+  return check_launch("dns_mlp_bwd(weights)");
+}

@@ -1,0 +1,400 @@
+// Ray generation + depth-guided sampling, one wave64 per ray.
+//
+// Replaces the per-frame body of Mapper/Tracker.get_target_samples (reference slams/mapping.py:487-531,
+// slams/tracking.py:133-160): get_rotation_from_quad (utils/common.py:447-458 -> quad2rotation :406-429),
+// get_sample_uv / select_uv (:266-293; the drawn indices are an INPUT), get_rays_from_uv (:248-264), the fp64
+// box far clip (mapping.py:519-527), sample_along_rays (common.py:561-599) and pts = o + d*z (mapping.py:531).
+//
+// The reference builds two HxW meshgrids per call just to index them, launches ~40 tiny kernels and a
+// device-wide sort over [n,47]; here a wave owns a ray, every lane builds one (or E) z value and the per-ray
+// sort is a bitonic network over wave shuffles on order-preserving uint keys.  All arithmetic that decides
+// a value bit-for-bit (the fp64 promotions through `bound`, the unfused fp32 products) is spelled with
+// __fmul_rn/__fadd_rn so the compiler cannot contract it; this file is compiled with -ffp-contract=off too.
+// Latency-bound (a few hundred bytes per ray); launch count is what it removes.
+#include "common.hpp"
+
+namespace dns {
+
+struct Cam {
+  float fx, fy, cx, cy;
+};
+struct BoundD {
+  double b[6];  // b0x,b1x,b0y,b1y,b0z,b1z
+};
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  if (f != f) return 0xFFC00000u;  // every NaN sorts after +inf (torch.sort puts NaN last), below the pad key
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+__device__ __forceinline__ double max_nan(double a, double b) { return (a != a || b != b) ? (a + b) : (a > b ? a : b); }
+__device__ __forceinline__ double min_nan(double a, double b) { return (a != a || b != b) ? (a + b) : (a < b ? a : b); }
+
+__device__ __forceinline__ void quat_to_R(const float* __restrict__ q, float R[9]) {
+  const float qr = q[0], qi = q[1], qj = q[2], qk = q[3];
+  const float nrm = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(qr, qr), __fmul_rn(qi, qi)), __fmul_rn(qj, qj)), __fmul_rn(qk, qk));
+  const float two_s = 2.0f / nrm;
+  const float jj = __fmul_rn(qj, qj), kk = __fmul_rn(qk, qk), ii = __fmul_rn(qi, qi);
+  const float ij = __fmul_rn(qi, qj), kr = __fmul_rn(qk, qr), ik = __fmul_rn(qi, qk), jr = __fmul_rn(qj, qr);
+  const float jk = __fmul_rn(qj, qk), ir = __fmul_rn(qi, qr);
+  R[0] = __fsub_rn(1.0f, __fmul_rn(two_s, __fadd_rn(jj, kk)));
+  R[1] = __fmul_rn(two_s, __fsub_rn(ij, kr));
+  R[2] = __fmul_rn(two_s, __fadd_rn(ik, jr));
+  R[3] = __fmul_rn(two_s, __fadd_rn(ij, kr));
+  R[4] = __fsub_rn(1.0f, __fmul_rn(two_s, __fadd_rn(ii, kk)));
+  R[5] = __fmul_rn(two_s, __fsub_rn(jk, ir));
+  R[6] = __fmul_rn(two_s, __fsub_rn(ik, jr));
+  R[7] = __fmul_rn(two_s, __fadd_rn(jk, ir));
+  R[8] = __fsub_rn(1.0f, __fmul_rn(two_s, __fadd_rn(ii, jj)));
+}
+
+__device__ __forceinline__ void pixel_dir(int64_t q, int H0, int W0, int wwin, Cam cam, int& row, int& col, float dir[3]) {
+  row = H0 + (int)(q / wwin);
+  col = W0 + (int)(q % wwin);
+  dir[0] = __fdiv_rn(__fsub_rn((float)col, cam.cx), cam.fx);
+  dir[1] = -__fdiv_rn(__fsub_rn((float)row, cam.cy), cam.fy);
+  dir[2] = -1.0f;
+}
+
+__global__ void depth_max_kernel(const int64_t* __restrict__ pix_idx, const float* __restrict__ depth, int H, int W,
+                                 int H0, int W0, int wwin, int n_frames, int npf, uint32_t* __restrict__ ws) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_frames * npf) return;
+  const int f = n / npf;
+  const int64_t q = pix_idx[n];
+  const int row = H0 + (int)(q / wwin), col = W0 + (int)(q % wwin);
+  const float d = depth[((size_t)f * H + row) * W + col];
+  if (d > 0.f) atomicMax(ws + f, __float_as_uint(d));  // non-negative floats order like their bit patterns
+}
+
+// z values of one ray (utils/common.py:561-599) as sorted order-preserving keys; lane owns elements e*64+lane.
+// `far` is far_bb AFTER the +0.01 (fp64).  Surface part fp32, uniform part fp64 then rounded, as the reference.
+template <int E>
+__device__ __forceinline__ void sample_and_sort(float gd, double far, float dmax, const float* __restrict__ t_uniform,
+                                                const float* __restrict__ t_surf, const float* __restrict__ t_zero,
+                                                int nu, int ns, uint32_t lane, uint32_t (&key)[E]) {
+  const int S = nu + ns;
+  const double hi = (double)__fmul_rn(dmax, 1.2f);
+  double farc = far;                      // torch.clamp(far, 0, hi): NaN propagates
+  if (farc == farc) {
+    farc = farc < 0.0 ? 0.0 : farc;
+    farc = farc > hi ? hi : farc;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int s = e * 64 + (int)lane;
+    float zv;
+    if (s < nu) {
+      const float tv = t_uniform[s];
+      const float near = __fmul_rn(gd, 0.001f);
+      const float a = __fmul_rn(near, __fsub_rn(1.0f, tv));
+      zv = (float)__dadd_rn((double)a, __dmul_rn(farc, (double)tv));
+    } else if (s < S) {
+      const int k = s - nu;
+      if (gd > 0.f) {
+        const float t = t_surf[k];
+        zv = __fadd_rn(__fmul_rn(__fmul_rn(0.95f, gd), __fsub_rn(1.0f, t)), __fmul_rn(__fmul_rn(1.05f, gd), t));
+      } else {
+        const float t = t_zero[k];
+        zv = __fadd_rn(__fmul_rn(0.001f, __fsub_rn(1.0f, t)), __fmul_rn(dmax, t));
+      }
+    } else {
+      zv = 0.f;
+    }
+    key[e] = (s < S) ? f2key(zv) : 0xFFFFFFFFu;
+  }
+  // bitonic sort of 64*E keys; element id g = e*64 + lane
+  constexpr int NTOT = 64 * E;
+#pragma unroll
+  for (int k = 2; k <= NTOT; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      if (j >= 64) {
+        const int je = j >> 6;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int pe = e ^ je;
+          if (pe > e) {
+            const int g = e * 64 + (int)lane;
+            const bool up = (g & k) == 0;
+            const uint32_t lo = min(key[e], key[pe]), hi2 = max(key[e], key[pe]);
+            key[e] = up ? lo : hi2;
+            key[pe] = up ? hi2 : lo;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int g = e * 64 + (int)lane;
+          const uint32_t other = (uint32_t)__shfl_xor((int)key[e], j);
+          const bool up = (g & k) == 0;
+          const bool lower = (g & j) == 0;
+          key[e] = (lower == up) ? min(key[e], other) : max(key[e], other);
+        }
+      }
+    }
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void raygen_sample_kernel(
+    const int64_t* __restrict__ pix_idx, const float* __restrict__ color, const float* __restrict__ depth,
+    const float* __restrict__ label, const float* __restrict__ quat, const float* __restrict__ trans, Cam cam,
+    BoundD bd, int H, int W, int H0, int W0, int wwin, int n_frames, int npf, const float* __restrict__ t_uniform,
+    const float* __restrict__ t_surf, const float* __restrict__ t_zero, int nu, int ns,
+    const uint32_t* __restrict__ dmax_ws, float* __restrict__ rays_o, float* __restrict__ rays_d,
+    float* __restrict__ gt_color, float* __restrict__ gt_depth, int64_t* __restrict__ gt_label,
+    uint8_t* __restrict__ inside, float* __restrict__ z_out, float* __restrict__ pts_out) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= n_frames * npf) return;
+  const int f = n / npf;
+  const int S = nu + ns;
+  int row, col;
+  float dir[3];
+  pixel_dir(pix_idx[n], H0, W0, wwin, cam, row, col, dir);
+  const size_t pix = ((size_t)f * H + row) * W + col;
+  float R[9];
+  quat_to_R(quat + 4 * f, R);
+  float o[3], d[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    o[a] = trans[3 * f + a];
+    d[a] = __fadd_rn(__fadd_rn(__fmul_rn(dir[0], R[3 * a]), __fmul_rn(dir[1], R[3 * a + 1])), __fmul_rn(dir[2], R[3 * a + 2]));
+  }
+  const float gd = depth[pix];
+  // box far clip in fp64 (bound is float64 in the reference, so everything promotes)
+  double far = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double t0 = (bd.b[2 * a] - (double)o[a]) / (double)d[a];
+    const double t1 = (bd.b[2 * a + 1] - (double)o[a]) / (double)d[a];
+    const double m = max_nan(t0, t1);
+    far = (a == 0) ? m : min_nan(far, m);
+  }
+  const bool in = far >= (double)gd;
+  far += 0.01;
+  const float dmax = __uint_as_float(dmax_ws[f]);
+  uint32_t key[E];
+  sample_and_sort<E>(gd, far, dmax, t_uniform, t_surf, t_zero, nu, ns, lane, key);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int s = e * 64 + (int)lane;
+    if (s < S) {
+      const float zv = key2f(key[e]);
+      z_out[(size_t)n * S + s] = zv;
+      if (pts_out) {
+        float* p = pts_out + ((size_t)n * S + s) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a] = __fadd_rn(o[a], __fmul_rn(d[a], zv));
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      rays_o[(size_t)n * 3 + a] = o[a];
+      rays_d[(size_t)n * 3 + a] = d[a];
+      gt_color[(size_t)n * 3 + a] = color[pix * 3 + a];
+    }
+    gt_depth[n] = gd;
+    gt_label[n] = (int64_t)label[pix];
+    inside[n] = in ? 1 : 0;
+  }
+}
+
+
+// Stand-alone sample_along_rays(gt_depth, n_samples, n_surface, far_bb) (utils/common.py:561): far_bb is an input.
+__global__ void depth_max_flat_kernel(const float* __restrict__ depth, int n, uint32_t* __restrict__ ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && depth[i] > 0.f) atomicMax(ws, __float_as_uint(depth[i]));
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void sample_along_rays_kernel(const float* __restrict__ depth, const double* __restrict__ far_bb,
+                                                                int n_rays, const float* __restrict__ t_uniform,
+                                                                const float* __restrict__ t_surf, const float* __restrict__ t_zero,
+                                                                int nu, int ns, const uint32_t* __restrict__ dmax_ws,
+                                                                float* __restrict__ z_out) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= n_rays) return;
+  const int S = nu + ns;
+  uint32_t key[E];
+  sample_and_sort<E>(depth[n], far_bb[n], __uint_as_float(dmax_ws[0]), t_uniform, t_surf, t_zero, nu, ns, lane, key);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int s = e * 64 + (int)lane;
+    if (s < S) z_out[(size_t)n * S + s] = key2f(key[e]);
+  }
+}
+
+// d_pts [n,S,3] (+ optional direct d_rays_o / d_rays_d) -> per-frame sums of dL/dR (9) and dL/dT (3)
+__global__ __launch_bounds__(256) void raygen_bwd_reduce_kernel(const int64_t* __restrict__ pix_idx, Cam cam, int H0, int W0,
+                                                                int wwin, int n_frames, int npf, int S,
+                                                                const float* __restrict__ z, const float* __restrict__ d_pts,
+                                                                const float* __restrict__ d_ro, const float* __restrict__ d_rd,
+                                                                float* __restrict__ ws) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= n_frames * npf) return;
+  const int f = n / npf;
+  float go[3] = {0.f, 0.f, 0.f}, gdv[3] = {0.f, 0.f, 0.f};
+  if (d_pts) {
+    for (int s = lane; s < S; s += 64) {
+      const float zv = z[(size_t)n * S + s];
+      const float* g = d_pts + ((size_t)n * S + s) * 3;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        go[a] += g[a];
+        gdv[a] += g[a] * zv;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        go[a] += __shfl_xor(go[a], off);
+        gdv[a] += __shfl_xor(gdv[a], off);
+      }
+  }
+  if (lane == 0) {
+    if (d_ro)
+      for (int a = 0; a < 3; ++a) go[a] += d_ro[(size_t)n * 3 + a];
+    if (d_rd)
+      for (int a = 0; a < 3; ++a) gdv[a] += d_rd[(size_t)n * 3 + a];
+    int row, col;
+    float dir[3];
+    pixel_dir(pix_idx[n], H0, W0, wwin, cam, row, col, dir);
+    float* w = ws + 12 * f;
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) atomicAdd(w + 3 * a + b, gdv[a] * dir[b]);  // dL/dR[a][b] = sum dL/dd[a] * dir[b]
+      atomicAdd(w + 9 + a, go[a]);
+    }
+  }
+}
+
+__global__ void raygen_bwd_pose_kernel(const float* __restrict__ quat, const float* __restrict__ ws, int n_frames,
+                                       float* __restrict__ d_quat, float* __restrict__ d_trans) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  const float* G = ws + 12 * f;
+  const float r = quat[4 * f], i = quat[4 * f + 1], j = quat[4 * f + 2], k = quat[4 * f + 3];
+  const float nrm = r * r + i * i + j * j + k * k;
+  const float two_s = 2.0f / nrm;
+  // R = I + two_s * M(q)
+  const float M[9] = {-(j * j + k * k), i * j - k * r, i * k + j * r, i * j + k * r, -(i * i + k * k),
+                      j * k - i * r,    i * k - j * r, j * k + i * r, -(i * i + j * j)};
+  float gm = 0.f;
+  for (int e = 0; e < 9; ++e) gm += G[e] * M[e];
+  const float dr = -k * G[1] + j * G[2] + k * G[3] - i * G[5] - j * G[6] + i * G[7];
+  const float di = j * (G[1] + G[3]) + k * (G[2] + G[6]) - 2.f * i * (G[4] + G[8]) + r * (G[7] - G[5]);
+  const float dj = -2.f * j * (G[0] + G[8]) + i * (G[1] + G[3]) + r * (G[2] - G[6]) + k * (G[5] + G[7]);
+  const float dk = -2.f * k * (G[0] + G[4]) + r * (G[3] - G[1]) + i * (G[2] + G[6]) + j * (G[5] + G[7]);
+  const float c = two_s * two_s * gm;
+  if (d_quat) {
+    d_quat[4 * f + 0] += two_s * dr - c * r;
+    d_quat[4 * f + 1] += two_s * di - c * i;
+    d_quat[4 * f + 2] += two_s * dj - c * j;
+    d_quat[4 * f + 3] += two_s * dk - c * k;
+  }
+  if (d_trans)
+    for (int a = 0; a < 3; ++a) d_trans[3 * f + a] += G[9 + a];
+}
+
+}  // namespace dns
+
+using namespace dns;
+
+static Cam make_cam(const double* cam) {
+  Cam c;
+  c.fx = (float)cam[0];
+  c.fy = (float)cam[1];
+  c.cx = (float)cam[2];
+  c.cy = (float)cam[3];
+  return c;
+}
+
+extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, const float* depth, const float* label,
+                                 const float* quat, const float* trans, const double* cam, const double* bound, int H,
+                                 int W, int H0, int H1, int W0, int W1, int n_frames, int n_per_frame,
+                                 const float* t_uniform, const float* t_surf, const float* t_zero, int n_uniform,
+                                 int n_surface, uint32_t* depth_max_ws, float* rays_o, float* rays_d, float* gt_color,
+                                 float* gt_depth, int64_t* gt_label, uint8_t* inside, float* z, float* pts,
+                                 void* stream) {
+  DNS_REQUIRE(pix_idx && color && depth && label && quat && trans && cam && bound, "dns_raygen_sample: NULL input");
+  DNS_REQUIRE(rays_o && rays_d && gt_color && gt_depth && gt_label && inside && z && depth_max_ws, "dns_raygen_sample: NULL output");
+  DNS_REQUIRE(0 <= H0 && H0 < H1 && H1 <= H && 0 <= W0 && W0 < W1 && W1 <= W, "dns_raygen_sample: bad window");
+  DNS_REQUIRE(n_uniform >= 0 && n_surface >= 1 && n_uniform + n_surface <= 256, "dns_raygen_sample: samples per ray %d+%d out of range", n_uniform, n_surface);
+  DNS_REQUIRE(n_uniform == 0 || t_uniform, "dns_raygen_sample: t_uniform is NULL");
+  DNS_REQUIRE(t_surf && t_zero, "dns_raygen_sample: jitter vectors are NULL");
+  const int n = n_frames * n_per_frame;
+  if (n <= 0) return DNS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(depth_max_ws, 0, sizeof(uint32_t) * n_frames, st) != hipSuccess) {
+    set_error("dns_raygen_sample: memset failed");
+    return DNS_E_LAUNCH;
+  }
+  const int wwin = W1 - W0;
+  hipLaunchKernelGGL(depth_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pix_idx, depth, H, W, H0, W0, wwin, n_frames, n_per_frame, depth_max_ws);
+  BoundD bd;
+  for (int i = 0; i < 6; ++i) bd.b[i] = bound[i];
+  const Cam c = make_cam(cam);
+  const int S = n_uniform + n_surface;
+  const dim3 grid((n + 3) / 4), block(256);
+#define LAUNCH_RS(E)                                                                                                   \
+  hipLaunchKernelGGL(raygen_sample_kernel<E>, grid, block, 0, st, pix_idx, color, depth, label, quat, trans, c, bd, H, \
+                     W, H0, W0, wwin, n_frames, n_per_frame, t_uniform, t_surf, t_zero, n_uniform, n_surface,          \
+                     depth_max_ws, rays_o, rays_d, gt_color, gt_depth, gt_label, inside, z, pts)
+  if (S <= 64) LAUNCH_RS(1);
+  else if (S <= 128) LAUNCH_RS(2);
+  else LAUNCH_RS(4);
+#undef LAUNCH_RS
+  return check_launch("dns_raygen_sample");
+}
+
+extern "C" int dns_sample_along_rays(const float* gt_depth, const double* far_bb, int n_rays, const float* t_uniform,
+                                     const float* t_surf, const float* t_zero, int n_uniform, int n_surface,
+                                     uint32_t* depth_max_ws, float* z, void* stream) {
+  DNS_REQUIRE(gt_depth && far_bb && t_surf && t_zero && depth_max_ws && z, "dns_sample_along_rays: NULL argument");
+  DNS_REQUIRE(n_uniform >= 0 && n_surface >= 1 && n_uniform + n_surface <= 256, "dns_sample_along_rays: samples per ray %d+%d out of range", n_uniform, n_surface);
+  DNS_REQUIRE(n_uniform == 0 || t_uniform, "dns_sample_along_rays: t_uniform is NULL");
+  if (n_rays <= 0) return DNS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(depth_max_ws, 0, sizeof(uint32_t), st) != hipSuccess) {
+    set_error("dns_sample_along_rays: memset failed");
+    return DNS_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(depth_max_flat_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, st, gt_depth, n_rays, depth_max_ws);
+  const int S = n_uniform + n_surface;
+  const dim3 grid((n_rays + 3) / 4), block(256);
+  if (S <= 64) hipLaunchKernelGGL(sample_along_rays_kernel<1>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
+  else if (S <= 128) hipLaunchKernelGGL(sample_along_rays_kernel<2>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
+  else hipLaunchKernelGGL(sample_along_rays_kernel<4>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
+  return check_launch("dns_sample_along_rays");
+}
+
+extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const double* cam, int H0, int H1, int W0,
+                              int W1, int n_frames, int n_per_frame, int S, const float* z, const float* d_pts,
+                              const float* d_rays_o, const float* d_rays_d, float* ws, float* d_quat, float* d_trans,
+                              void* stream) {
+  DNS_REQUIRE(pix_idx && quat && cam && ws, "dns_raygen_bwd: NULL argument");
+  DNS_REQUIRE(!d_pts || z, "dns_raygen_bwd: d_pts needs z");
+  (void)H1;
+  const int n = n_frames * n_per_frame;
+  if (n <= 0) return DNS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 12 * n_frames, st) != hipSuccess) {
+    set_error("dns_raygen_bwd: memset failed");
+    return DNS_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(raygen_bwd_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
+                     n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);
+  hipLaunchKernelGGL(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
+  return check_launch("dns_raygen_bwd");
+}

@@ -1,0 +1,101 @@
+"""Ray-batch data parallelism over the GPUs of one node: one process per GPU, parameters
+replicated, every rank renders its own slice of the ray batch, ONE flat all-reduce of the gradients per
+iteration (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" on CPU for tests).
+
+The reference has no live distributed path (its NCCL helpers utils/common.py:79-162 are dead code); this is the
+north_star's addition.  Exactness w.r.t. one GPU rendering the union batch:
+  * plain means over rays / points (photometric, CE, latent, fs/opacity): every rank holds the same number of rays,
+    so the AVERAGE of per-rank gradients is the gradient of the global mean;
+  * masked means (depth loss over d > 0): the per-rank term is rescaled by W * count_r / sum(count) BEFORE backward
+    (``global_mean_scale``), one tiny all-reduce of the counts, no host sync;
+  * the fs/opacity branch flag (utils/common.py:794) is evaluated on the global counts (``global_any``).
+Bucket: all gradients are flattened into one fp32 buffer -- 6.8 MB (T=2^16) .. 59 MB (T=2^20) + <1 MB of MLPs
++ 7 floats per frame -- so the collective is one large message; xGMI is point-to-point (7 links x ~153 GB/s), a
+ring all-reduce of M bytes moves 2*(7/8)*M over each link: 6.8 MB -> ~80 us, 59 MB -> ~0.7 ms.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DistCtx:
+    def __init__(self, world_size: int = 1, rank: int = 0, group=None):
+        self.world_size, self.rank, self.group = world_size, rank, group
+
+    @property
+    def enabled(self):
+        return self.world_size > 1
+
+    # ---- loss fix-ups -----------------------------------------------------------------------
+    def global_mean_scale(self, local_count: torch.Tensor) -> torch.Tensor:
+        """Factor s_r = W * count_r / sum_r(count_r) for a masked mean whose denominator is ``local_count``."""
+        if not self.enabled:
+            return torch.ones((), device=local_count.device, dtype=torch.float32)
+        tot = local_count.detach().clone().float()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        return self.world_size * local_count.detach().float() / tot
+
+    def global_any(self, local_flag: torch.Tensor) -> torch.Tensor:
+        if not self.enabled:
+            return local_flag
+        f = local_flag.detach().clone().float()
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
+        return f
+
+    # ---- gradient exchange ------------------------------------------------------------------
+    def allreduce_grads(self, params: Iterable[torch.Tensor]) -> None:
+        """Average the gradients of ``params`` over the ranks with ONE all-reduce of a flat fp32 bucket.
+        Parameters without a gradient on this rank (e.g. a frozen pose) contribute zeros."""
+        if not self.enabled:
+            return
+        ps: List[torch.Tensor] = [p for p in params if p.requires_grad]
+        if not ps:
+            return
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, device=ps[0].device, dtype=torch.float32)
+        o = 0
+        for p in ps:
+            if p.grad is not None:
+                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            o += p.numel()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world_size)
+        o = 0
+        for p in ps:
+            g = flat[o:o + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += p.numel()
+
+    def barrier(self):
+        if self.enabled:
+            dist.barrier(group=self.group)
+
+    def max_over_ranks(self, value: float, device) -> float:
+        if not self.enabled:
+            return value
+        t = torch.tensor([value], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+
+def init_from_env(backend: Optional[str] = None) -> DistCtx:
+    """One process per GPU, launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return DistCtx()
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return DistCtx(world, rank)

@@ -1,0 +1,386 @@
+"""Mirror of the Mapper optimise-step bodies (reference slams/mapping.py) on the gfx950 kernels.
+
+Same method names, argument meaning and return values as the reference for the part of ``Mapper`` that is
+the hot path:
+
+    set_decoder / fine_fn        slams/mapping.py:727-761, :590-601
+    get_target_samples           :471-588   (2-D feature branch = an input here)
+    renderer                     :603-635
+    smoothness                   :129-159
+    compute_*_loss               :110-126
+    set_optimizer / optimize     :438-468, :839-949 (iteration driver)
+
+Keyframe selection, visualisation, meshing, checkpointing and the process loop (``run``) are out of scope
+(components 8-14).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from . import tcnn_shim as tcnn
+from .common import get_opacity_loss, get_quad_from_c2w, get_rotation_from_quad
+from .decoder import fused_cat
+
+
+class FineDecoderPool(nn.Module):
+    """The Mapper's ``fine_decoders`` dict (slams/mapping.py:736-749): one 80->33 network per semantic class,
+    added lazily.  All weight sets live in ONE [capacity, count] buffer so the grouped MFMA kernel can switch
+    sets per 128-point tile; ``self[class_id]`` is a ``tcnn_shim.Network`` whose ``.params`` is a view of its row,
+    so optimisers, ``state_dict`` and pickling see ordinary per-class modules."""
+
+    def __init__(self, n_in, n_out, net_cfg, capacity=64, device="cuda"):
+        super().__init__()
+        self.n_in, self.n_out, self.net_cfg = n_in, n_out, dict(net_cfg)
+        self.nn_, self.nl = int(net_cfg["n_neurons"]), int(net_cfg["n_hidden_layers"])
+        self.count = ops.mlp_param_count(n_in, n_out, self.nn_, self.nl)
+        self.pool = nn.Parameter(torch.zeros(capacity, self.count, device=device))
+        self.slot: Dict[int, int] = {}
+        self._lut: Optional[torch.Tensor] = None
+
+    def keys(self):
+        return self.slot.keys()
+
+    def __contains__(self, k):
+        return int(k) in self.slot
+
+    def __len__(self):
+        return len(self.slot)
+
+    def add(self, class_id: int, seed: int = 1337):
+        class_id = int(class_id)
+        if class_id in self.slot:
+            return
+        s = len(self.slot)
+        if s >= self.pool.shape[0]:
+            raise ValueError("FineDecoderPool capacity exceeded")
+        init = tcnn.Network(self.n_in, self.n_out, self.net_cfg, seed=seed).params.data
+        with torch.no_grad():
+            self.pool[s].copy_(init.to(self.pool.device))
+        self.slot[class_id] = s
+        self._lut = None
+
+    def lut(self, max_class: int) -> torch.Tensor:
+        """class id -> pool row (-1 = no decoder), on device."""
+        if self._lut is None or self._lut.numel() <= max_class:
+            n = max(max_class + 1, (max(self.slot) + 1) if self.slot else 1)
+            l = torch.full((n,), -1, dtype=torch.int64)
+            for c, s in self.slot.items():
+                l[c] = s
+            self._lut = l.to(self.pool.device)
+        return self._lut
+
+    def params_of(self, class_id: int) -> torch.Tensor:
+        return self.pool[self.slot[int(class_id)]]
+
+    def parameters_for(self, class_ids):
+        # one tensor holds every class: the optimiser steps the pool (rows of absent classes get zero grad)
+        return [self.pool]
+
+
+class Mapper:
+    """Hot-path subset of reference ``Mapper`` (slams/mapping.py:24-1146)."""
+
+    def __init__(self, cfg: dict, decoder, bound: torch.Tensor, cam: dict, device="cuda",
+                 label_layout: str = "reference_tiled"):
+        self.cfg = cfg
+        self.device = device
+        self.decoder = decoder
+        self.bound = bound.to(torch.float64)           # float64, as dns_slam.py:102-107
+        self.bound_dev = self.bound.to(device)
+        self.H, self.W = cam["H"], cam["W"]
+        self.fx, self.fy, self.cx, self.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+        tr, mp = cfg["training"], cfg["mapping"]
+        self.lr = tr["lr"]
+        self.lambda_p, self.lambda_d, self.lambda_l = tr["lambda_color"], tr["lambda_depth"], tr["lambda_label"]
+        self.lambda_sm, self.lambda_fs, self.lambda_opacity = tr["lambda_smooth"], tr["lambda_fs"], tr["lambda_opacity"]
+        self.n_samples_ray, self.n_surface_ray = tr["n_samples_ray"], tr["n_surface_ray"]
+        self.n_pixels = mp["n_pixels"]
+        self.n_target_frame = mp["n_joint_optimize_frames"]
+        self.BA_cam_lr = mp["BA_cam_lr"]
+        self.start_optimize_idx = mp.get("start_optimize_idx", 10)
+        self.hidden_dim = decoder.hidden_dim
+        self.pe_dim, self.grid_dim = decoder.pe_dim, decoder.grid_dim
+        self.label_layout = label_layout
+        self.is_BA = True
+        self.dist = None                                 # dns_slam_amd.dist.DistCtx for ray-batch data parallelism
+        net_cfg = decoder.coarse_fn.decoder.network_config
+        self.fine_decoders = FineDecoderPool(self.pe_dim + self.grid_dim, self.hidden_dim + 1, net_cfg, device=device)
+        self.exist_decoders: Dict[int, int] = {}
+        self.class2label_dict = cfg.get("class2label_dict", None)
+        self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
+
+    # ------------------------------------------------------------------ losses (slams/mapping.py:110-126)
+    def compute_photometric_loss(self, gt_color, pred_color):
+        return ((gt_color - pred_color) ** 2).mean()
+
+    def compute_depth_loss(self, gt_depth, pred_depth):
+        mask = gt_depth > 0
+        w = mask.float()
+        cnt = w.sum()
+        loss = (torch.abs(gt_depth - pred_depth) * w).sum() / cnt          # == mean over d>0, no host sync
+        if self.dist is not None and self.dist.enabled:
+            loss = loss * self.dist.global_mean_scale(cnt)                  # masked mean over the GLOBAL batch
+        return loss
+
+    def compute_label_loss(self, gt_label, pred_logits):
+        return F.cross_entropy(pred_logits, gt_label)
+
+    def compute_latent_loss(self, coarse, fine):
+        return ((coarse - fine) ** 2).mean()
+
+    # ------------------------------------------------------------------ slams/mapping.py:129-159
+    def smoothness(self, sample_points=64, voxel_size=0.1, margin=0.05, u_offset=None, u_jitter=None):
+        bound = self.bound
+        volume = bound[:, 1] - bound[:, 0]
+        grid_size = (sample_points - 1) * voxel_size
+        offset_max = bound[:, 1] - bound[:, 0] - grid_size - 2 * margin
+        if u_offset is None:
+            u_offset = torch.rand(3)
+        if u_jitter is None:
+            u_jitter = torch.rand((1, 1, 1, 3))
+        offset = u_offset.to(offset_max) * offset_max + margin
+        n = sample_points - 1
+        key = (n, str(self.device))
+        if getattr(self, "_lattice_key", None) != key:
+            ar = torch.arange(0, n, dtype=torch.long)
+            gx, gy, gz = torch.meshgrid(ar, ar, ar, indexing="ij")
+            self._lattice = torch.stack([gx, gy, gz], dim=-1).to(torch.float64).to(self.device)
+            self._lattice_key = key
+        # reference: float64 through `volume`; (coords + jitter) * voxel + b0 + offset, then normalise by the bound
+        bd = self.bound_dev
+        pts = (self._lattice + u_jitter.to(torch.float64).to(self.device)) * voxel_size + bd[:, 0] + offset.to(self.device)
+        pts = (pts - bd[:, 0]) / (bd[:, 1] - bd[:, 0])
+        shp = pts.shape
+        pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
+        coarse = self.decoder.coarse_fn(pe, features=grid_pts)
+        occ = coarse[:, 0:1].reshape(*shp[:3], 1)          # intended shape of :152
+        tv_x = torch.pow(occ[1:, ...] - occ[:-1, ...], 2).sum()
+        tv_y = torch.pow(occ[:, 1:, ...] - occ[:, :-1, ...], 2).sum()
+        tv_z = torch.pow(occ[:, :, 1:, ...] - occ[:, :, :-1, ...], 2).sum()
+        return (tv_x + tv_y + tv_z) / (sample_points ** 3)
+
+    # ------------------------------------------------------------------ slams/mapping.py:727-761
+    def set_decoder(self, target_frames):
+        label_dict = target_frames["label_dict"]
+        new_list = []
+        for obj_id in label_dict:
+            obj_id = int(obj_id)
+            if self.class2label_dict is not None and obj_id not in self.class2label_dict:
+                raise ValueError("Unknown semantic class", obj_id, "Existed class:", self.class2label_dict.keys())
+            if obj_id not in self.fine_decoders:
+                self.fine_decoders.add(obj_id)
+                self.exist_decoders[obj_id] = 1
+            else:
+                self.exist_decoders[obj_id] += 1
+            if self.exist_decoders[obj_id] <= 4:
+                new_list.append(obj_id)
+        min_obj = min(self.exist_decoders, key=self.exist_decoders.get)
+        if min_obj not in new_list and self.exist_decoders[min_obj] < 10:
+            self.exist_decoders[min_obj] += 1
+            new_list.append(min_obj)
+        return new_list
+
+    # ------------------------------------------------------------------ slams/mapping.py:438-468
+    def set_optimizer(self, target_frames):
+        net_para_list = list(self.decoder.parameters())
+        net_para_list += self.fine_decoders.parameters_for(target_frames["label_dict"])
+        quad_list, T_list = [], []
+        for frame in range(self.n_target_frame):
+            c2w = target_frames["est_c2w"][frame]
+            quad = get_quad_from_c2w(c2w).clone().detach().to(self.device)
+            T = c2w[:3, 3].clone().detach().to(self.device)
+            if (self.n_target_frame == 1 or frame != 0) and self.is_BA:
+                quad.requires_grad_(True)
+                T.requires_grad_(True)
+            quad_list.append(quad)
+            T_list.append(T)
+        net_para_list = [p for p in net_para_list if p.numel() > 0]
+        optimizer = torch.optim.Adam([{"params": net_para_list, "lr": 0},
+                                      {"params": quad_list, "lr": 0},
+                                      {"params": T_list, "lr": 0}])
+        return optimizer, quad_list, T_list
+
+    # ------------------------------------------------------------------ pixel picking (a1, a2)
+    def prepare_frames(self, target_frames):
+        """Once per optimize(): stack the K frames and build the per-frame class tables that
+        ``select_by_class`` (utils/common.py:307-338) rebuilds with nonzero() every iteration."""
+        K = self.n_target_frame
+        color = torch.stack([target_frames["gt_color"][i] for i in range(K)]).to(self.device).float().contiguous()
+        depth = torch.stack([target_frames["gt_depth"][i] for i in range(K)]).to(self.device).float().contiguous()
+        label = torch.stack([target_frames["gt_label"][i] for i in range(K)]).to(self.device).float().contiguous()
+        n_pixels = self.n_pixels // K
+        n1, n2 = n_pixels // 3 * 2, n_pixels // 3           # slams/mapping.py:498,505
+        if getattr(self, "rays_per_frame", None) is not None:  # benchmark override: exact (uniform, by-class) counts
+            n1, n2 = self.rays_per_frame
+        HW = self.H * self.W
+        sorted_pix, starts, counts = [], [], []
+        for f in range(K):
+            lab = label[f].reshape(-1)
+            order = torch.argsort(lab, stable=True)
+            classes, cnt = torch.unique_consecutive(lab[order], return_counts=True)
+            n_class = int(classes.numel())                       # one host sync per frame per optimize()
+            n_k = n2 // n_class
+            m = torch.full((n_class,), n_k, dtype=torch.int64)
+            m[0] = n2 - n_k * (n_class - 1)
+            st = torch.cumsum(cnt, 0) - cnt
+            slot_class = torch.repeat_interleave(torch.arange(n_class), m).to(self.device)   # class of each of the n2 draws
+            sorted_pix.append(order)
+            starts.append(st[slot_class])
+            counts.append(cnt[slot_class])
+        return {"color": color, "depth": depth, "label": label, "n1": n1, "n2": n2, "HW": HW,
+                "sorted_pix": sorted_pix, "starts": starts, "counts": counts}
+
+    def draw_pixels(self, prep):
+        """Indices of one iteration: per frame n1 uniform picks (select_uv, common.py:274) then n2 class-balanced
+        picks (select_by_class :313-328), concatenated in the reference's order."""
+        out = []
+        for f in range(self.n_target_frame):
+            i1 = torch.randint(prep["HW"], (prep["n1"],), device=self.device)
+            u = torch.rand(prep["n2"], device=self.device, dtype=torch.float64)
+            k = prep["counts"][f]
+            j = torch.minimum((u * k).to(torch.int64), k - 1)
+            i2 = prep["sorted_pix"][f][prep["starts"][f] + j]
+            out += [i1, i2]
+        return torch.cat(out)
+
+    def draw_jitter(self):
+        """The two CPU draws of sample_along_rays (utils/common.py:571-574,582), forced 0.5 included."""
+        ns = self.n_surface_ray
+        t = torch.rand(ns)
+        if not torch.any(t == 0.5):
+            t[ns // 2 + 1] = 0.5
+        t0 = torch.rand(ns)
+        return t.to(self.device), t0.to(self.device)
+
+    # ------------------------------------------------------------------ slams/mapping.py:471-588
+    def get_target_samples(self, target_frames, quad_list, T_list, refer_frames=None, features=None,
+                           prep=None, pix_idx=None, jitter=None):
+        """All K frames in one launch.  NB ``sample_along_rays`` is called once per frame in the reference with
+        fresh jitter each time; here one jitter pair is shared by the K frames of an iteration unless ``jitter`` is
+        a list of K pairs."""
+        if prep is None:
+            prep = self.prepare_frames(target_frames)
+        K = self.n_target_frame
+        if pix_idx is None:
+            pix_idx = self.draw_pixels(prep)
+        npf = pix_idx.numel() // K
+        quat = torch.stack(list(quad_list))
+        trans = torch.stack(list(T_list))
+        cam = (self.fx, self.fy, self.cx, self.cy)
+        window = (0, self.H, 0, self.W)
+        if jitter is None:
+            jitter = self.draw_jitter()
+        if isinstance(jitter, (list,)) and len(jitter) == K and isinstance(jitter[0], (tuple, list)):
+            parts = []
+            for f in range(K):
+                parts.append(ops.raygen_sample(quat[f:f + 1], trans[f:f + 1], pix_idx[f * npf:(f + 1) * npf].contiguous(),
+                                               prep["color"][f:f + 1], prep["depth"][f:f + 1], prep["label"][f:f + 1],
+                                               cam, self.bound, window, npf, self.t_uniform, jitter[f][0], jitter[f][1]))
+            res = [torch.cat([p[i] for p in parts], 0) for i in range(8)]
+        else:
+            res = ops.raygen_sample(quat, trans, pix_idx, prep["color"], prep["depth"], prep["label"], cam, self.bound,
+                                    window, npf, self.t_uniform, jitter[0], jitter[1])
+        rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = res
+        N, S = z.shape
+        if features is None:
+            code = torch.zeros(N, S, self.hidden_dim, device=self.device)
+        else:
+            d = gt_depth[:, None]
+            front = (z < d * 0.95).float()
+            back = (z > d * 1.05).float()
+            trunc = (1.0 - front) * (1.0 - back) * (d > 0.0).float()        # :553-556
+            code = features * trunc[..., None]
+        mask = inside.bool()
+        if bool(mask.all()):                                                # the reference syncs here too (:576)
+            sel = lambda t: t
+        else:
+            sel = lambda t: t[mask]
+        return {"gt_color": sel(gt_color), "gt_depth": sel(gt_depth), "gt_label": sel(gt_label),
+                "rays_o": sel(rays_o), "rays_d": sel(rays_d), "pts": sel(pts), "z_vals": sel(z), "features": sel(code)}
+
+    # ------------------------------------------------------------------ slams/mapping.py:590-601
+    def fine_fn(self, pes, classes=None, features=None, strict=True):
+        lut = self.fine_decoders.lut(0)
+        cls = classes.clamp(min=0, max=lut.numel() - 1)
+        slot = torch.where((classes >= 0) & (classes < lut.numel()), lut[cls], torch.full_like(classes, -1))
+        if strict and bool((slot < 0).any()):
+            missing = torch.unique(classes[slot < 0]).tolist()
+            raise ValueError("Fine decoders does NOT have class", missing)
+        x = fused_cat(pes, features)
+        n = len(self.fine_decoders)
+        return ops.mlp_grouped(x, self.fine_decoders.pool[:max(n, 1)], slot, self.pe_dim + self.grid_dim,
+                               self.hidden_dim + 1, self.fine_decoders.nn_, self.fine_decoders.nl)
+
+    # ------------------------------------------------------------------ slams/mapping.py:603-635
+    def renderer(self, samples, strict=True):
+        pts = samples["pts"]
+        n_pts, n_samples, _ = pts.shape
+        z_vals = samples["z_vals"]
+        gt_label = samples["gt_label"]
+        if self.label_layout == "reference_tiled":
+            classes = gt_label.repeat(1, n_samples).flatten(0, 1)          # :613 -- tiles, SURVEY D1
+        else:
+            classes = gt_label.repeat_interleave(n_samples)
+        pixel_pts = samples["features"].flatten(0, 1)
+        buf = self.decoder.pe_fn.forward_world(pts.flatten(0, 1), self.bound)     # :608 + pe_fn, fused
+        pe, grid_pts = buf[:, :self.pe_dim], buf[:, self.pe_dim:]
+        coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts)
+        fine_latents = self.fine_fn(pe, classes=classes, features=grid_pts, strict=strict)
+        color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((fine_latents[:, 1:], pixel_pts), -1))
+        values_pts = torch.cat((color_pts, fine_latents[:, 0:1]), -1).reshape(n_pts, n_samples, -1)
+        logits_pts = logits_pts.reshape(n_pts, n_samples, -1)
+        pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)
+        return pred_color, pred_depth, pred_depth_var, pred_logits, fine_latents, coarse_latents
+
+    # ------------------------------------------------------------------ slams/mapping.py:887-907
+    def iteration_loss(self, samples, lambda_lt=10.0, smooth=True, u_offset=None, u_jitter=None, strict=False):
+        pred_color, pred_depth, _, pred_logits, fine_latents, coarse_latents = self.renderer(samples, strict=strict)
+        d_loss = self.compute_depth_loss(samples["gt_depth"], pred_depth)
+        p_loss = self.compute_photometric_loss(samples["gt_color"], pred_color)
+        l_loss = self.compute_label_loss(samples["gt_label"], pred_logits)
+        lt_loss = self.compute_latent_loss(coarse_latents, fine_latents)
+        fs_loss, opacity_loss = get_opacity_loss(samples["z_vals"], samples["gt_depth"], fine_latents[..., -1],
+                                                 self.cfg["training"]["opacity_sigma"])
+        loss = self.lambda_p * p_loss + self.lambda_d * d_loss + self.lambda_l * l_loss + lambda_lt * lt_loss + \
+            self.lambda_fs * fs_loss + self.lambda_opacity * opacity_loss
+        terms = {"p_loss": p_loss, "d_loss": d_loss, "l_loss": l_loss, "lt_loss": lt_loss, "fs_loss": fs_loss,
+                 "opacity_loss": opacity_loss}
+        if smooth:
+            smooth_loss = self.smoothness(sample_points=self.cfg["training"]["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
+            loss = loss + self.lambda_sm * smooth_loss
+            terms["smooth_loss"] = smooth_loss
+        return loss, terms
+
+    # ------------------------------------------------------------------ slams/mapping.py:839-949
+    def optimize(self, n_iters, cur_idx, target_frames, features=None, smooth=True):
+        """Iteration driver.  ``target_frames`` is what ``set_target_refer_frames`` (:329, host-side keyframe
+        bookkeeping, out of scope) returns: gt_color/gt_depth/gt_label per frame, est_c2w, label_dict."""
+        self.is_BA = cur_idx >= self.start_optimize_idx
+        new_decoder_idx = self.set_decoder(target_frames)
+        optimizer, quad_list, T_list = self.set_optimizer(target_frames)
+        optimizer.param_groups[0]["lr"] = self.lr
+        optimizer.param_groups[1]["lr"] = self.BA_cam_lr * self.is_BA
+        optimizer.param_groups[2]["lr"] = self.BA_cam_lr * self.is_BA
+        prep = self.prepare_frames(target_frames)
+        terms = {}
+        for iter_ in range(n_iters):
+            optimizer.zero_grad()
+            samples = self.get_target_samples(target_frames, quad_list, T_list, features=features, prep=prep)
+            if len(new_decoder_idx) > 0:
+                lambda_lt = 10 if iter_ > n_iters // 2 else 0
+            else:
+                lambda_lt = 10
+            loss, terms = self.iteration_loss(samples, lambda_lt=lambda_lt, smooth=smooth)
+            loss.backward()
+            optimizer.step()
+        bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self.device)
+        R = get_rotation_from_quad(quad_list[-1].detach())
+        cur_c2w = torch.cat([torch.cat((R, T_list[-1].detach()[:, None]), -1), bottom], dim=0)
+        self.last_quad_list, self.last_T_list = quad_list, T_list
+        return cur_c2w, terms

@@ -1,0 +1,393 @@
+"""torch.autograd bindings of the HIP entry points (include/dns_hip.h).
+
+PyTorch is plumbing here: device buffers, the current stream and the autograd graph.  All arithmetic
+happens in libdns_hip.so; nothing in this module has a CPU or eager-torch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import DnsGridMeta, check, lib as _rawlib, ptr, require_cuda, stream_ptr
+
+
+class _TimedLib:
+    """Pass-through to libdns_hip.so that, when ``ops.timer`` is armed, brackets every launch-carrying entry point
+    with events on the current stream (the stream the kernels are launched on) -- bench.py's per-kernel durations."""
+
+    def __init__(self, raw):
+        self._raw = raw
+        self.records = None          # list of (name, start_event, end_event) while armed
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_last_error", "dns_abi_version"):
+            return fn
+
+        ui = self._UNITS_ARG.get(name)
+
+        def timed(*a):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            units = 0 if ui is None else (a[ui] if not isinstance(ui, tuple) else a[ui[0]] * a[ui[1]])
+            self.records.append((name, e0, e1, int(units)))
+            return rc
+        return timed
+
+    # argument index holding the number of units (points / slots / rays) a launch processes
+    _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 9, "dns_mlp_bwd": 13,
+                  "dns_composite_fwd": 3, "dns_composite_bwd": 3, "dns_raygen_sample": (14, 15), "dns_raygen_bwd": (7, 8),
+                  "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2}
+
+    def arm(self):
+        self.records = []
+
+    def disarm(self):
+        """-> {entry point: (calls, total_ms, total_units)}; call after a device synchronise."""
+        recs, self.records = self.records or [], None
+        out = {}
+        for name, e0, e1, units in recs:
+            c, t, u = out.get(name, (0, 0.0, 0))
+            out[name] = (c + 1, t + e0.elapsed_time(e1), u + units)
+        return out
+
+
+lib = _TimedLib(_rawlib)
+timer = lib
+
+
+# ----------------------------------------------------------------------------- grid meta
+class GridMeta:
+    """Host-side hash-grid level table (tcnn GridEncoding constructor; reference call site
+    models/pos_encoding.py:31-46).  ``per_level_scale`` follows pos_encoding.py:33 in float64."""
+
+    def __init__(self, log2_hashmap_size: int, desired_resolution: int, n_levels: int = 16,
+                 n_features: int = 2, base_resolution: int = 16, per_level_scale: Optional[float] = None):
+        if per_level_scale is None:
+            per_level_scale = float(np.exp2(np.log2(desired_resolution / base_resolution) / (n_levels - 1)))
+        self.c = DnsGridMeta()
+        check(lib.dns_grid_meta_init(C.byref(self.c), n_levels, n_features, log2_hashmap_size, base_resolution,
+                                     per_level_scale), "dns_grid_meta_init")
+        self.n_levels = n_levels
+        self.n_features = n_features
+        self.total_rows = int(self.c.total_rows)
+        self.out_dim = n_levels * n_features
+        self._args = (log2_hashmap_size, desired_resolution, n_levels, n_features, base_resolution, per_level_scale)
+
+    def levels(self):
+        c = self.c
+        return [dict(scale=np.float32(c.scale[l]), resolution=int(c.resolution[l]), size=int(c.size[l]),
+                     offset=int(c.offset[l]), hashed=bool(c.hashed[l])) for l in range(self.n_levels)]
+
+    # picklable (spawn / torch.save / deepcopy of modules that own one)
+    def __getstate__(self):
+        return {"args": self._args}
+
+    def __setstate__(self, st):
+        a = st["args"]
+        self.__init__(a[0], a[1], a[2], a[3], a[4], a[5])
+
+
+def _bound6(bound) -> Optional[C.Array]:
+    """[3,2] float64 bound -> 6 host doubles b0x,b1x,b0y,b1y,b0z,b1z."""
+    if bound is None:
+        return None
+    if isinstance(bound, C.Array):
+        return bound
+    cached = getattr(bound, "_dns_b6", None) if isinstance(bound, torch.Tensor) else None
+    if cached is not None:
+        return cached
+    b = torch.as_tensor(bound, dtype=torch.float64).detach().cpu().reshape(3, 2)   # one sync, then cached on the tensor
+    b6 = (C.c_double * 6)(*[float(v) for v in b.reshape(-1)])
+    if isinstance(bound, torch.Tensor):
+        try:
+            bound._dns_b6 = b6
+        except Exception:
+            pass
+    return b6
+
+
+# ----------------------------------------------------------------------------- encoding
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, table, meta: Optional[GridMeta], bound, n_bins: int, want_pe: bool, want_grid: bool):
+        require_cuda(pts, table)
+        P = pts.shape[0]
+        pts = pts.contiguous().float()
+        pe_dim = 3 * n_bins if want_pe else 0
+        g_dim = meta.out_dim if want_grid else 0
+        ld = pe_dim + g_dim
+        out = torch.empty(P, ld, device=pts.device, dtype=torch.float32)
+        b6 = _bound6(bound)
+        x = torch.empty(P, 3, device=pts.device, dtype=torch.float32) if b6 is not None else pts
+        pe_ptr = ptr(out) if want_pe else None
+        grid_ptr = C.c_void_p(out.data_ptr() + 4 * pe_dim) if want_grid else None
+        check(lib.dns_encode_fwd(ptr(pts), b6, P, n_bins, ptr(table) if want_grid else None,
+                                 C.byref(meta.c) if want_grid else None,
+                                 ptr(x) if b6 is not None else None, pe_ptr, ld, grid_ptr, ld, stream_ptr()),
+              "dns_encode_fwd")
+        ctx.save_for_backward(x, table if want_grid else None)
+        ctx.meta, ctx.b6, ctx.n_bins, ctx.pe_dim, ctx.g_dim = meta, b6, n_bins, pe_dim, g_dim
+        ctx.need_x = pts.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, table = ctx.saved_tensors
+        P = x.shape[0]
+        d_out = d_out.contiguous()
+        ld = ctx.pe_dim + ctx.g_dim
+        need_x = ctx.needs_input_grad[0]
+        need_t = ctx.g_dim > 0 and ctx.needs_input_grad[1]
+        d_x = torch.empty(P, 3, device=x.device, dtype=torch.float32) if need_x else None
+        d_table = torch.zeros_like(table) if need_t else None
+        d_pe = ptr(d_out) if ctx.pe_dim else None
+        d_grid = C.c_void_p(d_out.data_ptr() + 4 * ctx.pe_dim) if ctx.g_dim else None
+        check(lib.dns_encode_bwd(ptr(x), ctx.b6, P, ctx.n_bins, ptr(table) if ctx.g_dim else None,
+                                 C.byref(ctx.meta.c) if ctx.g_dim else None, d_pe, ld, d_grid, ld,
+                                 ptr(d_table), ptr(d_x), stream_ptr()), "dns_encode_bwd")
+        return d_x, d_table, None, None, None, None, None
+
+
+def encode(pts: torch.Tensor, table: Optional[torch.Tensor], meta: Optional[GridMeta], bound=None, n_bins: int = 16,
+           want_pe: bool = True, want_grid: bool = True) -> torch.Tensor:
+    """[P,3] -> [P, 3*n_bins (+) L*F] (OneBlob channels first).  With ``bound`` the input is world points and
+    the fp64 normalisation of slams/mapping.py:608 happens in-kernel."""
+    if table is None:
+        table = pts.new_zeros(1)
+    return _EncodeFn.apply(pts, table, meta, bound, n_bins, want_pe, want_grid)
+
+
+def hashgrid_rows(x: torch.Tensor, meta: GridMeta) -> torch.Tensor:
+    """Debug/parity: absolute table rows [P, L, 8] (int64) of the corners the kernel gathers."""
+    require_cuda(x)
+    x = x.contiguous().float()
+    rows = torch.empty(x.shape[0], meta.n_levels, 8, device=x.device, dtype=torch.int32)
+    check(lib.dns_hashgrid_indices(ptr(x), x.shape[0], C.byref(meta.c), ptr(rows), stream_ptr()), "dns_hashgrid_indices")
+    return rows.to(torch.int64) & 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- MLP
+def mlp_out_padded(n_out: int) -> int:
+    return (n_out + 15) // 16 * 16
+
+
+def mlp_param_count(n_in: int, n_out: int, n_neurons: int, n_hidden_layers: int) -> int:
+    return n_neurons * n_in + (n_hidden_layers - 1) * n_neurons * n_neurons + mlp_out_padded(n_out) * n_neurons
+
+
+def _row_major_2d(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+        if x.data_ptr() % 16 != 0:
+            x = x.clone()
+    return x
+
+
+class _MlpFn(torch.autograd.Function):
+    """y = MLP(x; params).  ``params`` is [G, count] (G weight sets, G=1 for a plain network)."""
+
+    @staticmethod
+    def forward(ctx, x, params, shape, row_index, tile_group, n_slots):
+        n_in, n_out, nn, nl = shape
+        require_cuda(x, params, row_index, tile_group)
+        x = _row_major_2d(x.float())
+        P = x.shape[0]
+        if row_index is None:
+            y = torch.empty(P, n_out, device=x.device, dtype=torch.float32)
+            n_slots = P
+        else:
+            y = torch.zeros(P, n_out, device=x.device, dtype=torch.float32)
+        stride = params.shape[-1] if params.dim() == 2 else 0
+        check(lib.dns_mlp_fwd(ptr(x), x.stride(0), ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, n_slots,
+                              ptr(row_index), ptr(tile_group), stride, stream_ptr()), "dns_mlp_fwd")
+        ctx.save_for_backward(x, params, row_index, tile_group)
+        ctx.shape, ctx.n_slots, ctx.stride = shape, n_slots, stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, params, row_index, tile_group = ctx.saved_tensors
+        n_in, n_out, nn, nl = ctx.shape
+        dy = dy.contiguous()
+        P = x.shape[0]
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if row_index is None:
+            d_x = torch.empty(P, n_in, device=x.device, dtype=torch.float32) if need_x else None
+        else:
+            d_x = torch.zeros(P, n_in, device=x.device, dtype=torch.float32) if need_x else None
+        d_p = torch.zeros_like(params) if need_p else None
+        ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(ctx.n_slots, nn, nl)), device=x.device, dtype=torch.float32)
+        check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(d_x), n_in,
+                              ptr(d_p), ptr(ws), ctx.n_slots, ptr(row_index), ptr(tile_group), ctx.stride,
+                              stream_ptr()), "dns_mlp_bwd")
+        return d_x, d_p, None, None, None, None
+
+
+def mlp(x: torch.Tensor, params: torch.Tensor, n_in: int, n_out: int, n_neurons: int = 32,
+        n_hidden_layers: int = 1) -> torch.Tensor:
+    """Bias-free ReLU MLP, fp32 on the matrix cores (tcnn CutlassMLP replacement)."""
+    return _MlpFn.apply(x, params, (n_in, n_out, n_neurons, n_hidden_layers), None, None, 0)
+
+
+def group_slots(slot_of_point: torch.Tensor, n_groups: int, min_count: int = 2):
+    """Device-side (sync-free) layout for the grouped MLP: points sorted by weight-set id and padded to 128-slot
+    tiles.  ``slot_of_point`` [P] int64 in [0, n_groups) (negative = no network).  Returns (row_index int32
+    [n_slots], tile_group int32 [n_slots/128], n_slots).  Groups with fewer than ``min_count`` points are skipped,
+    as ``Mapper.fine_fn`` does (slams/mapping.py:597: ``if index.sum() > 1``)."""
+    P = slot_of_point.shape[0]
+    dev = slot_of_point.device
+    n_slots = (P + 127) // 128 * 128 + 128 * n_groups
+    key = torch.where(slot_of_point < 0, torch.full_like(slot_of_point, n_groups), slot_of_point)
+    order = torch.argsort(key, stable=True)
+    counts = torch.bincount(key, minlength=n_groups + 1)[:n_groups]
+    padded = (counts + 127) // 128 * 128
+    pad_end = torch.cumsum(padded, 0)
+    pad_start = pad_end - padded
+    cnt_start = torch.cumsum(counts, 0) - counts
+    skey = key[order]
+    valid = skey < n_groups
+    g = skey.clamp(max=n_groups - 1)
+    rank = torch.arange(P, device=dev) - cnt_start[g]
+    pos = pad_start[g] + rank
+    row_index = torch.full((n_slots,), -1, device=dev, dtype=torch.int32)
+    pos = torch.where(valid, pos, torch.full_like(pos, n_slots - 1))   # invalid points land on a padding slot
+    row_index[pos] = torch.where(valid, order, torch.full_like(order, -1)).to(torch.int32)
+    tiles = torch.arange(n_slots // 128, device=dev) * 128
+    tg = torch.searchsorted(pad_end, tiles, right=True)
+    live = (tg < n_groups)
+    tgc = tg.clamp(max=n_groups - 1)
+    live = live & (counts[tgc] >= min_count)
+    tile_group = torch.where(live, tgc, torch.full_like(tgc, -1)).to(torch.int32)
+    return row_index, tile_group, n_slots
+
+
+def mlp_grouped(x: torch.Tensor, params_pool: torch.Tensor, slot_of_point: torch.Tensor, n_in: int, n_out: int,
+                n_neurons: int = 32, n_hidden_layers: int = 1, min_count: int = 2) -> torch.Tensor:
+    """Per-point weight sets (the per-class fine decoders, slams/mapping.py:590-601): point p runs through
+    ``params_pool[slot_of_point[p]]``; points with no network / tiny groups get zeros."""
+    G = params_pool.shape[0]
+    row_index, tile_group, n_slots = group_slots(slot_of_point, G, min_count)
+    return _MlpFn.apply(x, params_pool, (n_in, n_out, n_neurons, n_hidden_layers), row_index, tile_group, n_slots)
+
+
+# ----------------------------------------------------------------------------- compositing
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z, logits):
+        require_cuda(raw, z, logits)
+        raw = raw.contiguous().float()
+        z = z.contiguous().float()
+        N, S = z.shape
+        Cn = 0 if logits is None else logits.shape[-1]
+        if logits is not None:
+            logits = logits.contiguous().float()
+        dev = raw.device
+        depth = torch.empty(N, device=dev)
+        var = torch.empty(N, device=dev)
+        rgb = torch.empty(N, 3, device=dev)
+        weights = torch.empty(N, S, device=dev)
+        sem = torch.empty(N, Cn, device=dev) if Cn else None
+        check(lib.dns_composite_fwd(ptr(raw), ptr(z), ptr(logits), N, S, Cn, ptr(depth), ptr(var), ptr(rgb),
+                                    ptr(weights), ptr(sem), stream_ptr()), "dns_composite_fwd")
+        ctx.save_for_backward(raw, z, logits)
+        ctx.dims = (N, S, Cn)
+        if sem is None:
+            sem = raw.new_zeros(N, 0)
+        return depth, var, rgb, weights, sem
+
+    @staticmethod
+    def backward(ctx, d_depth, d_var, d_rgb, d_weights, d_sem):
+        raw, z, logits = ctx.saved_tensors
+        N, S, Cn = ctx.dims
+        d_raw = torch.empty_like(raw)
+        d_logits = torch.empty_like(logits) if Cn else None
+        c = lambda t: None if t is None else t.contiguous()
+        check(lib.dns_composite_bwd(ptr(raw), ptr(z), ptr(logits), N, S, Cn, ptr(c(d_depth)), ptr(c(d_var)),
+                                    ptr(c(d_rgb)), ptr(c(d_weights)), ptr(c(d_sem)) if Cn else None, ptr(d_raw),
+                                    ptr(d_logits), stream_ptr()), "dns_composite_bwd")
+        return d_raw, None, d_logits
+
+
+def composite(raw: torch.Tensor, z_vals: torch.Tensor, logits: Optional[torch.Tensor] = None):
+    """raw [N,S,4], z [N,S], logits [N,S,C] -> depth [N], var [N], rgb [N,3], weights [N,S], sem [N,C]."""
+    return _CompositeFn.apply(raw, z_vals, logits)
+
+
+# ----------------------------------------------------------------------------- ray generation + sampling
+class _RaygenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, quat, trans, pix_idx, color, depth, label, cam, bound, window, npf, t_uniform, t_surf, t_zero):
+        require_cuda(quat, trans, pix_idx, color, depth, label, t_uniform, t_surf, t_zero)
+        K, H, W = depth.shape
+        H0, H1, W0, W1 = window
+        n = K * npf
+        nu = 0 if t_uniform is None else t_uniform.numel()
+        ns = t_surf.numel()
+        S = nu + ns
+        dev = quat.device
+        quat = quat.contiguous().float()
+        trans = trans.contiguous().float()
+        rays_o = torch.empty(n, 3, device=dev)
+        rays_d = torch.empty(n, 3, device=dev)
+        gt_color = torch.empty(n, 3, device=dev)
+        gt_depth = torch.empty(n, device=dev)
+        gt_label = torch.empty(n, device=dev, dtype=torch.int64)
+        inside = torch.empty(n, device=dev, dtype=torch.uint8)
+        z = torch.empty(n, S, device=dev)
+        pts = torch.empty(n, S, 3, device=dev)
+        ws = torch.empty(K, device=dev, dtype=torch.int32)
+        camv = (C.c_double * 4)(*[float(v) for v in cam])
+        b6 = _bound6(bound)
+        check(lib.dns_raygen_sample(ptr(pix_idx), ptr(color), ptr(depth), ptr(label), ptr(quat), ptr(trans), camv, b6,
+                                    H, W, H0, H1, W0, W1, K, npf, ptr(t_uniform), ptr(t_surf), ptr(t_zero), nu, ns,
+                                    ptr(ws), ptr(rays_o), ptr(rays_d), ptr(gt_color), ptr(gt_depth), ptr(gt_label),
+                                    ptr(inside), ptr(z), ptr(pts), stream_ptr()), "dns_raygen_sample")
+        ctx.save_for_backward(pix_idx, quat, z)
+        ctx.misc = (camv, window, K, npf, S)
+        ctx.mark_non_differentiable(gt_color, gt_depth, gt_label, inside, z)
+        return rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z
+
+    @staticmethod
+    def backward(ctx, d_ro, d_rd, d_pts, *_):
+        pix_idx, quat, z = ctx.saved_tensors
+        camv, (H0, H1, W0, W1), K, npf, S = ctx.misc
+        dev = quat.device
+        d_quat = torch.zeros(K, 4, device=dev)
+        d_trans = torch.zeros(K, 3, device=dev)
+        ws = torch.empty(12 * K, device=dev)
+        c = lambda t: None if t is None else t.contiguous()
+        check(lib.dns_raygen_bwd(ptr(pix_idx), ptr(quat), camv, H0, H1, W0, W1, K, npf, S, ptr(z), ptr(c(d_pts)),
+                                 ptr(c(d_ro)), ptr(c(d_rd)), ptr(ws), ptr(d_quat), ptr(d_trans), stream_ptr()),
+              "dns_raygen_bwd")
+        return (d_quat, d_trans) + (None,) * 11
+
+
+def raygen_sample(quat, trans, pix_idx, color, depth, label, cam, bound, window, n_per_frame, t_uniform, t_surf, t_zero):
+    """K stacked frames -> (rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z).  quat [K,4], trans [K,3],
+    pix_idx [K*n_per_frame] int64 window-flat indices, color [K,H,W,3], depth/label [K,H,W] fp32,
+    cam=(fx,fy,cx,cy), bound [3,2] fp64, window=(H0,H1,W0,W1)."""
+    return _RaygenFn.apply(quat, trans, pix_idx, color, depth, label, tuple(cam), bound, tuple(window), n_per_frame,
+                           t_uniform, t_surf, t_zero)
+
+
+def sample_along_rays(gt_depth, far_bb, t_uniform, t_surf, t_zero):
+    """Stand-alone depth-guided sampling (utils/common.py:561-599) with explicit jitter: gt_depth [n] fp32,
+    far_bb [n] or [n,1] fp64 (+0.01 already applied) -> z [n, S] ascending fp32."""
+    require_cuda(gt_depth, far_bb, t_uniform, t_surf, t_zero)
+    gt_depth = gt_depth.reshape(-1).contiguous().float()
+    far_bb = far_bb.reshape(-1).contiguous().double()
+    n = gt_depth.numel()
+    nu = 0 if t_uniform is None else t_uniform.numel()
+    ns = t_surf.numel()
+    z = torch.empty(n, nu + ns, device=gt_depth.device)
+    ws = torch.empty(1, device=gt_depth.device, dtype=torch.int32)
+    check(lib.dns_sample_along_rays(ptr(gt_depth), ptr(far_bb), n, ptr(t_uniform), ptr(t_surf), ptr(t_zero), nu, ns,
+                                    ptr(ws), ptr(z), stream_ptr()), "dns_sample_along_rays")
+    return z

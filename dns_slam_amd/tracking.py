@@ -1,0 +1,140 @@
+"""Mirror of the Tracker optimise-step bodies (reference slams/tracking.py) on the gfx950 kernels.
+
+    compute_*_loss        slams/tracking.py:85-96
+    set_optimizer         :108-126
+    get_target_samples    :128-186  (20-px border window; 2-D feature branch = an input)
+    renderer              :188-214  (coarse-only)
+    track_frame           the per-frame loop body :313-340 (keep-best-pose included)
+
+The process loop (``run`` :229: data loading, mapper synchronisation, logging) is out of scope.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .common import get_quad_from_c2w, get_rotation_from_quad
+
+
+class Tracker:
+    def __init__(self, cfg: dict, decoder, bound: torch.Tensor, cam: dict, device="cuda"):
+        self.cfg = cfg
+        self.device = device
+        self.decoder = decoder
+        self.bound = bound.to(torch.float64)
+        self.H, self.W = cam["H"], cam["W"]
+        self.fx, self.fy, self.cx, self.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+        tr, tk = cfg["training"], cfg["tracking"]
+        self.lambda_p, self.lambda_d, self.lambda_l = tr["lambda_color"], tr["lambda_depth"], tr["lambda_label"]
+        self.n_samples_ray, self.n_surface_ray = tr["n_samples_ray"], tr["n_surface_ray"]
+        self.cam_lr, self.n_iters, self.n_pixels = tk["cam_lr"], tk["n_iters"], tk["n_pixels"]
+        self.seperate_LR = cfg.get("seperate_LR", False)
+        self.hidden_dim = decoder.hidden_dim
+        self.pe_dim = decoder.pe_dim
+        self.border = 20
+        self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
+
+    # slams/tracking.py:85-96 -- masked means written as weighted sums (no boolean-mask gather / host sync)
+    def compute_photometric_loss(self, gt_color, pred_color, mask):
+        w = mask.to(gt_color.dtype)
+        return (((gt_color - pred_color) ** 2) * w[:, None]).sum() / (w.sum() * gt_color.shape[1])
+
+    def compute_depth_loss(self, gt_depth, pred_depth, pred_depth_var, mask):
+        w = mask.to(gt_depth.dtype)
+        return ((torch.abs(gt_depth - pred_depth) / torch.sqrt(pred_depth_var + 1e-10)) * w).sum() / w.sum()
+
+    def compute_label_loss(self, gt_label, pred_logits, mask):
+        w = mask.to(pred_logits.dtype)
+        ce = F.cross_entropy(pred_logits, gt_label, reduction="none")
+        return (ce * w).sum() / w.sum()
+
+    # slams/tracking.py:108-126
+    def set_optimizer(self, c2w, idx=None):
+        lr = self.cam_lr
+        quad = get_quad_from_c2w(c2w).clone().detach().to(self.device).requires_grad_(True)
+        T = c2w[:3, 3].clone().detach().to(self.device).float().requires_grad_(True)
+        lrT = lr * 0.2 if self.seperate_LR else lr
+        optimizer = torch.optim.Adam([{"params": [T], "lr": lrT}, {"params": [quad], "lr": lr}])
+        return optimizer, quad, T
+
+    def draw_pixels(self):
+        b = self.border
+        return torch.randint((self.H - 2 * b) * (self.W - 2 * b), (self.n_pixels,), device=self.device)
+
+    def draw_jitter(self):
+        ns = self.n_surface_ray
+        t = torch.rand(ns)
+        if not torch.any(t == 0.5):
+            t[ns // 2 + 1] = 0.5
+        t0 = torch.rand(ns)
+        return t.to(self.device), t0.to(self.device)
+
+    def prepare_frame(self, cur_frames):
+        f = lambda t: t.to(self.device).float().contiguous()[None]
+        return {"color": f(cur_frames["gt_color"]), "depth": f(cur_frames["gt_depth"]), "label": f(cur_frames["gt_label"])}
+
+    # slams/tracking.py:128-186
+    def get_target_samples(self, cur_frames, refer_frames=None, features=None, prep=None, pix_idx=None, jitter=None):
+        if prep is None:
+            prep = self.prepare_frame(cur_frames)
+        if pix_idx is None:
+            pix_idx = self.draw_pixels()
+        if jitter is None:
+            jitter = self.draw_jitter()
+        b = self.border
+        rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = ops.raygen_sample(
+            cur_frames["est_quad"][None], cur_frames["est_T"][None], pix_idx, prep["color"], prep["depth"], prep["label"],
+            (self.fx, self.fy, self.cx, self.cy), self.bound, (b, self.H - b, b, self.W - b), pix_idx.numel(),
+            self.t_uniform, jitter[0], jitter[1])
+        N, S = z.shape
+        if features is None:
+            code = torch.zeros(N, S, self.hidden_dim, device=self.device)
+        else:
+            d = gt_depth[:, None]
+            trunc = (1.0 - (z < d * 0.95).float()) * (1.0 - (z > d * 1.05).float()) * (d > 0.0).float()
+            code = features * trunc[..., None]
+        mask = (gt_depth > 0.01) & inside.bool()            # :171-172; kept on device (reference: .cpu().numpy())
+        return {"gt_color": gt_color, "gt_depth": gt_depth, "gt_label": gt_label, "rays_o": rays_o, "rays_d": rays_d,
+                "pts": pts, "z_vals": z, "mask": mask, "features": code}
+
+    # slams/tracking.py:188-214
+    def renderer(self, samples):
+        pts = samples["pts"]
+        z_vals = samples["z_vals"]
+        n_pts, n_samples = z_vals.shape
+        pixel_pts = samples["features"].flatten(0, 1)
+        buf = self.decoder.pe_fn.forward_world(pts.flatten(0, 1), self.bound)
+        pe, grid_pts = buf[:, :self.pe_dim], buf[:, self.pe_dim:]
+        latents = self.decoder.coarse_fn(pe, features=grid_pts)
+        color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((latents[:, 1:], pixel_pts), -1))
+        values_pts = torch.cat((color_pts, latents[:, 0:1]), -1).reshape(n_pts, n_samples, -1)
+        logits_pts = logits_pts.reshape(n_pts, n_samples, -1)
+        pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)
+        return pred_color, pred_depth, pred_depth_var, pred_logits
+
+    # slams/tracking.py:313-340
+    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None):
+        """Optimise (quat, T) of one frame against the frozen scene; returns the best-loss camera tensor [7]."""
+        n_iters = self.n_iters if n_iters is None else n_iters
+        optimizer, quad, T = self.set_optimizer(est_c2w)
+        frames = dict(cur_frames)
+        frames["est_quad"], frames["est_T"] = quad, T
+        prep = self.prepare_frame(cur_frames)
+        best_loss = torch.full((), float("inf"), device=self.device)
+        best_cam = torch.cat((quad, T), 0).detach().clone()
+        for _ in range(n_iters):
+            optimizer.zero_grad()
+            samples = self.get_target_samples(frames, features=features, prep=prep)
+            pred_color, pred_depth, pred_depth_var, pred_logits = self.renderer(samples)
+            p_loss = self.compute_photometric_loss(samples["gt_color"], pred_color, samples["mask"])
+            d_loss = self.compute_depth_loss(samples["gt_depth"], pred_depth, pred_depth_var, samples["mask"])
+            l_loss = self.compute_label_loss(samples["gt_label"], pred_logits, samples["mask"])
+            loss = self.lambda_p * p_loss + self.lambda_d * d_loss + self.lambda_l * l_loss
+            with torch.no_grad():                       # keep-best without the host sync of :331
+                better = loss < best_loss
+                best_loss = torch.where(better, loss.detach(), best_loss)
+                best_cam = torch.where(better, torch.cat((quad, T), 0).detach(), best_cam)
+            loss.backward()
+            optimizer.step()
+        return best_cam, best_loss

@@ -1,0 +1,156 @@
+/*
+ * dns_hip.h -- C ABI of libdns_hip.so, the MI355X (gfx950) implementation of the
+ * DNS-SLAM volumetric-rendering hot path.
+ *
+ * Drop-in boundary.  The reference is pure Python; the only native
+ * code on its path is the third-party CUDA package `tinycudann`, reached through
+ *   tcnn.Encoding(...)  reference models/pos_encoding.py:16,34,50,63,76,88
+ *   tcnn.Network(...)   reference models/decoder.py:58,84,101,110, slams/mapping.py:737
+ * plus stock torch ops in utils/common.py.  Each entry point below names the reference
+ * interface it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked [host];
+ *   - the caller owns all buffers (the library never allocates or frees device memory);
+ *   - every launch goes to the caller's stream `stream` (a hipStream_t passed as void*);
+ *     no entry point synchronises the device;
+ *   - gradient outputs marked (+=) are ACCUMULATED into caller-initialised buffers;
+ *   - return 0 on success, a negative DNS_E_* code on failure; dns_last_error() then holds
+ *     a thread-local message.  No C++ exception crosses this boundary.
+ *   - row-major tensors; `ld*` = leading dimension in elements.
+ */
+#ifndef DNS_HIP_H
+#define DNS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNS_ABI_VERSION 1
+#define DNS_MAX_LEVELS 32
+
+#define DNS_OK 0
+#define DNS_E_ARG (-1)      /* bad argument / unsupported shape */
+#define DNS_E_LAUNCH (-2)   /* HIP launch error */
+
+/* Multi-resolution hash-grid level table (tcnn GridEncoding constructor; reference call site
+ * models/pos_encoding.py:31-46).  Built once on the host by dns_grid_meta_init and passed by
+ * pointer [host] to every grid entry point. */
+typedef struct DnsGridMeta {
+  uint32_t n_levels;
+  uint32_t n_features;            /* features per level; this build supports 2 */
+  uint32_t log2_hashmap_size;
+  uint32_t base_resolution;
+  uint32_t total_rows;            /* sum of size[] */
+  float per_level_scale;
+  float scale[DNS_MAX_LEVELS];    /* exp2f(l*log2f(pls))*base - 1 */
+  uint32_t resolution[DNS_MAX_LEVELS];
+  uint32_t size[DNS_MAX_LEVELS];  /* rows in the level */
+  uint32_t offset[DNS_MAX_LEVELS];/* first row of the level */
+  uint32_t hashed[DNS_MAX_LEVELS];/* 1 = coherent-prime hash, 0 = dense index */
+} DnsGridMeta;
+
+int dns_abi_version(void);
+const char* dns_last_error(void);
+
+/* [host] fills *meta.  per_level_scale is the float64 value reference pos_encoding.py:33 computes. */
+int dns_grid_meta_init(DnsGridMeta* meta, uint32_t n_levels, uint32_t n_features,
+                       uint32_t log2_hashmap_size, uint32_t base_resolution, double per_level_scale);
+
+/* ---- ray generation + depth-guided sampling ------------------------------------------------
+ * Replaces, for K stacked target frames of n_per_frame rays each:
+ *   get_rotation_from_quad  utils/common.py:447 (quat -> R, in-kernel)
+ *   get_sample_uv/select_uv utils/common.py:266-293 (pixel gather; indices are an INPUT)
+ *   get_rays_from_uv        utils/common.py:248-264
+ *   box far clip            slams/mapping.py:519-527, slams/tracking.py:148-156 (fp64)
+ *   sample_along_rays       utils/common.py:561-599 (per-frame max depth, per-ray sort)
+ * pix_idx: flat index inside the window [H0,H1)x[W0,W1).  color [K,H,W,3], depth [K,H,W],
+ * label [K,H,W] fp32.  quat [K,4] (w,x,y,z), trans [K,3].  cam = fx,fy,cx,cy [host].
+ * bound [host] = 6 doubles b0x,b1x,b0y,b1y,b0z,b1z.  t_uniform [n_uniform] = linspace(0,1),
+ * t_surf / t_zero [n_surface] the two jitter draws (t_surf already holds the forced 0.5).
+ * depth_max_ws: K uint32 scratch.  Outputs: rays_o,rays_d,gt_color [n,3], gt_depth [n],
+ * gt_label [n] int64, inside [n] uint8 (far_bb >= depth, before the +0.01), z [n, n_uniform+n_surface]
+ * ascending. */
+int dns_raygen_sample(const int64_t* pix_idx, const float* color, const float* depth, const float* label,
+                      const float* quat, const float* trans, const double* cam, const double* bound,
+                      int H, int W, int H0, int H1, int W0, int W1, int n_frames, int n_per_frame,
+                      const float* t_uniform, const float* t_surf, const float* t_zero,
+                      int n_uniform, int n_surface, uint32_t* depth_max_ws,
+                      float* rays_o, float* rays_d, float* gt_color, float* gt_depth, int64_t* gt_label,
+                      uint8_t* inside, float* z, float* pts /* [n,S,3] = o + d*z (slams/mapping.py:531), NULL = skip */,
+                      void* stream);
+
+/* Stand-alone sample_along_rays(gt_depth, n_samples, n_surface, far_bb, device) (utils/common.py:561-599):
+ * gt_depth [n] fp32, far_bb [n] fp64 (already carrying the +0.01), batch-global max depth taken over the n
+ * rays.  depth_max_ws: 1 uint32 scratch.  z [n, n_uniform+n_surface] ascending. */
+int dns_sample_along_rays(const float* gt_depth, const double* far_bb, int n_rays, const float* t_uniform,
+                          const float* t_surf, const float* t_zero, int n_uniform, int n_surface,
+                          uint32_t* depth_max_ws, float* z, void* stream);
+
+/* Backward of the ray generation w.r.t. the pose (autograd of pts = o + d*z, get_rays_from_uv and
+ * quad2rotation, utils/common.py:248-264,406-429): d_quat [K,4] (+=), d_trans [K,3] (+=) from d_pts [n,S,3]
+ * and/or direct d_rays_o / d_rays_d [n,3] (each may be NULL).  ws: 12*K floats of scratch. */
+int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const double* cam,
+                   int H0, int H1, int W0, int W1, int n_frames, int n_per_frame, int S,
+                   const float* z, const float* d_pts, const float* d_rays_o, const float* d_rays_d,
+                   float* ws, float* d_quat, float* d_trans, void* stream);
+
+/* ---- point encoding: OneBlob + hash grid ---------------------------------------------------
+ * Replaces Pos_Encoding.forward (models/decoder.py:45-48) = tcnn OneBlob (pos_encoding.py:61-71)
+ * + tcnn HashGrid (pos_encoding.py:31-46), optionally preceded by the fp64 normalisation
+ * (pts - b0)/(b1 - b0) of slams/mapping.py:608 / slams/tracking.py:190 when bound != NULL.
+ * in [P,3]; if bound != NULL [host, 6 doubles] `in` holds world points and x_out [P,3] receives the
+ * normalised fp32 coordinates (may be NULL).  pe_out [P, ld_pe] gets 3*n_bins channels (NULL = skip),
+ * grid_out [P, ld_grid] gets n_levels*n_features channels (NULL = skip).  table [total_rows, F]. */
+int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_bins,
+                   const float* table, const DnsGridMeta* meta,
+                   float* x_out, float* pe_out, uint32_t ld_pe, float* grid_out, uint32_t ld_grid,
+                   void* stream);
+
+/* Backward.  x [P,3] normalised coordinates.  d_pe / d_grid may be NULL.  d_table (+=) [total_rows,F]
+ * (NULL = skip), d_x [P,3] (overwritten; NULL = skip) = dL/dx of the NORMALISED coordinate; if
+ * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point). */
+int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins,
+                   const float* table, const DnsGridMeta* meta,
+                   const float* d_pe, uint32_t ld_dpe, const float* d_grid, uint32_t ld_dgrid,
+                   float* d_table, float* d_x, void* stream);
+
+/* Debug / parity: absolute table rows of the 8 corners of every level, [P, n_levels, 8] uint32. */
+int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, uint32_t* rows, void* stream);
+
+/* ---- bias-free ReLU MLP (tcnn CutlassMLP; decoder.py:58-64,84-90,101-116, mapping.py:737-743) ----
+ * params: flat fp32 [n_neurons*n_in | (n_hidden_layers-1)*n_neurons^2 | out_pad*n_neurons], row-major
+ * matrices, out_pad = next multiple of 16 of n_out.  n_neurons in {32,64}; n_hidden_layers in {1,2};
+ * n_in a multiple of 8 and <= 128; n_out <= 64; x 16-byte aligned with ldx % 4 == 0.
+ * A workgroup handles 128 consecutive point SLOTS.  row_index (NULL = identity) maps slot -> row of x / y /
+ * dy / d_x, -1 = padding slot (computes on zeros, stores nothing).  tile_group (NULL = one net) gives, per
+ * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class
+ * fine decoders of slams/mapping.py:590-601 without gathering activations. */
+int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
+                uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
+                const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream);
+
+/* Backward.  Recomputes the hidden activations from x.  d_x [rows, lddx] written for valid slots (NULL =
+ * skip); d_params (+=) same layout as params (+ group*param_stride), NULL = skip.  ws: 16-byte aligned
+ * float workspace of dns_mlp_bwd_ws_floats(n_slots, n_neurons, n_hidden_layers) elements. */
+int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
+                uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
+                float* d_x, uint32_t lddx, float* d_params, float* ws, uint32_t n_slots,
+                const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream);
+uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers);
+
+/* ---- occupancy compositing (raw2nerf_color, utils/common.py:506-537, + the logit composite of
+ * slams/mapping.py:633 / slams/tracking.py:212) ----------------------------------------------
+ * raw [N,S,4] (rgb, occ), z [N,S], logits [N,S,C] (C may be 0).  Outputs depth,var [N], rgb [N,3],
+ * weights [N,S], sem [N,C]. */
+int dns_composite_fwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C,
+                      float* depth, float* var, float* rgb, float* weights, float* sem, void* stream);
+/* d_weights may be NULL.  d_raw [N,S,4], d_logits [N,S,C] overwritten. */
+int dns_composite_bwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C,
+                      const float* d_depth, const float* d_var, const float* d_rgb, const float* d_weights,
+                      const float* d_sem, float* d_raw, float* d_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNS_HIP_H */

@@ -64,17 +64,18 @@ def per_level_scale(desired_res: int, base_resolution: int = 16, n_levels: int =
 def grid_meta(log2_hashmap_size: int, desired_res: int, n_levels: int = 16, n_features: int = 2,
               base_resolution: int = 16) -> GridMeta:
     """tcnn GridEncoding constructor: per level
-    scale = exp2f(l * log2f(pls)) * base - 1 (all float32), res = ceilf(scale) + 1,
+    scale = exp2(l * log2(pls)) * base - 1, evaluated in float64 and rounded once to float32 (tcnn uses CUDA's
+    float32 exp2f, which cannot be reproduced off-CUDA and is 1-ulp-sensitive at the finest level -- SURVEY
+    Appendix A7; the float64 definition makes the finest scale exactly desired_res - 1), res = ceilf(scale) + 1,
     size = min(next_multiple(res^3, 8), 2^log2_hashmap_size); a level is hashed iff the
     dense stride product exceeds its size."""
     pls = per_level_scale(desired_res, base_resolution, n_levels)
-    log2_pls = np.log2(np.float32(pls)).astype(np.float32)
+    log2_pls = np.log2(np.float64(pls))
     levels = []
     offset = 0
     T = 1 << log2_hashmap_size
     for l in range(n_levels):
-        scale = np.float32(np.exp2(np.float32(np.float32(l) * log2_pls)).astype(np.float32)
-                           * np.float32(base_resolution) - np.float32(1.0))
+        scale = np.float32(np.exp2(np.float64(l) * log2_pls) * np.float64(base_resolution) - 1.0)
         res = int(np.ceil(scale)) + 1
         dense = res ** 3
         size = min(((dense + 7) // 8) * 8, T)

@@ -1,0 +1,331 @@
+"""GPU parity, kernel by kernel: every HIP entry point (called through the C ABI via dns_slam_amd.ops) against the
+CPU oracle on the same seeded inputs, and against the committed golden vectors of the imported reference.
+Integer / index work is bit-exact; floating point within 1e-4 relative (BASELINE.json), the tolerance is in the test.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import render_math as rm
+from oracle import tcnn_ref as tr
+from util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from dns_slam_amd import ops
+    return ops
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ----------------------------------------------------------------------------------------- hash grid
+@pytest.mark.parametrize("hash_size,res", [(16, 592), (20, 231), (12, 64)])
+def test_hashgrid_rows_bit_exact(hash_size, res):
+    ops = _ops()
+    om, pm = tr.grid_meta(hash_size, res), ops.GridMeta(hash_size, res)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(4096, 3, generator=g) * 1.2 - 0.1          # some points outside [0,1]
+    x[:16] = torch.tensor([0.0, 1.0, 0.5] * 16).reshape(16, 3)
+    x[16:32] = (torch.arange(16)[:, None] / 15.0).expand(16, 3)  # level-0 vertices
+    rows_o, _ = tr.hashgrid_indices(x, om)
+    rows_p = ops.hashgrid_rows(x.to(DEV), pm).cpu()
+    assert torch.equal(rows_o, rows_p)
+
+
+@pytest.mark.parametrize("hash_size,res,P", [(16, 592, 5000), (12, 64, 777)])
+def test_encode_forward_backward(hash_size, res, P):
+    ops = _ops()
+    om, pm = tr.grid_meta(hash_size, res), ops.GridMeta(hash_size, res)
+    g = torch.Generator().manual_seed(1)
+    table = (torch.rand(om.total_rows, 2, generator=g) * 2 - 1)
+    x = torch.rand(P, 3, generator=g)
+    gy = torch.randn(P, 80, generator=g)
+    xo = x.clone().requires_grad_(True)
+    to = table.clone().requires_grad_(True)
+    yo = torch.cat((tr.oneblob_forward(xo, 16), tr.hashgrid_forward(xo, to, om)), -1)
+    (yo * gy).sum().backward()
+    xp = x.to(DEV).requires_grad_(True)
+    tp = table.reshape(-1).to(DEV).requires_grad_(True)
+    yp = ops.encode(xp, tp, pm, None, 16, True, True)
+    (yp * gy.to(DEV)).sum().backward()
+    assert_close(yp.cpu(), yo, what="encode fwd")
+    assert_close(tp.grad.cpu().reshape(-1, 2), to.grad, what="d table")
+    # d/dx is piecewise constant with jumps at cell boundaries; points within an ulp of a boundary may differ
+    bad = ((xp.grad.cpu() - xo.grad).abs() > 1e-4 * xo.grad.abs().max()).any(-1)
+    assert bad.float().mean() < 0.002, f"d x mismatch on {int(bad.sum())} points"
+
+
+def test_encode_world_normalisation_fp64():
+    """Fused (pts - b0)/(b1 - b0) in fp64 (slams/mapping.py:608): normalised coordinates bit-exact."""
+    ops = _ops()
+    from dns_slam_amd import synthetic
+    bound = synthetic.load_bound(synthetic.ROOM0_BOUND)
+    pm, om = ops.GridMeta(16, 592), tr.grid_meta(16, 592)
+    g = torch.Generator().manual_seed(2)
+    pts = torch.rand(3000, 3, generator=g) * (bound[:, 1] - bound[:, 0]).float() + bound[:, 0].float()
+    table = torch.rand(om.total_rows, 2, generator=g)
+    x_o = rm.normalise_points(pts, bound).float()
+    rows_o, _ = tr.hashgrid_indices(x_o, om)
+    y_o = torch.cat((tr.oneblob_forward(x_o, 16), tr.hashgrid_forward(x_o, table, om)), -1)
+    y_p = ops.encode(pts.to(DEV), table.reshape(-1).to(DEV), pm, bound, 16, True, True)
+    assert_close(y_p.cpu(), y_o, what="encode(world)")
+    # the saved normalised coordinates drive the indices: check them through the rows
+    from dns_slam_amd._lib import lib, ptr, stream_ptr, check
+    x_p = torch.empty(3000, 3, device=DEV)
+    import ctypes as C
+    b6 = ops._bound6(bound)
+    check(lib.dns_encode_fwd(ptr(pts.to(DEV)), b6, 3000, 16, None, None, ptr(x_p), None, 0, None, 0, stream_ptr()), "x")
+    assert torch.equal(x_p.cpu(), x_o)
+    assert torch.equal(ops.hashgrid_rows(x_p, pm).cpu(), rows_o)
+
+
+def test_encode_known_answers():
+    ops = _ops()
+    pm = ops.GridMeta(16, 592)
+    x = torch.rand(100, 3, device=DEV)
+    zero = ops.encode(x, torch.zeros(pm.total_rows * 2, device=DEV), pm, None, 16, False, True)
+    assert torch.count_nonzero(zero) == 0
+    one = ops.encode(x, torch.ones(pm.total_rows * 2, device=DEV), pm, None, 16, False, True)
+    assert torch.allclose(one, torch.ones_like(one), atol=1e-5)
+    pe = ops.encode(x, None, None, None, 16, True, False).reshape(100, 3, 16)
+    assert torch.allclose(pe.sum(-1), torch.ones(100, 3, device=DEV), atol=1e-5)
+    assert ops.encode(torch.zeros(0, 3, device=DEV), torch.zeros(pm.total_rows * 2, device=DEV), pm).shape == (0, 80)
+
+
+# ----------------------------------------------------------------------------------------- MLP
+SHAPES = [(80, 33, 32, 1), (112, 3, 32, 1), (112, 40, 32, 1), (112, 8, 32, 1), (80, 33, 64, 2), (112, 3, 64, 2),
+          (112, 8, 64, 2), (112, 32, 32, 1), (80, 33, 32, 2), (112, 40, 64, 1), (16, 64, 32, 1)]
+
+
+@pytest.mark.parametrize("n_in,n_out,nn,nl", SHAPES)
+@pytest.mark.parametrize("P", [1000, 129])
+def test_mlp_forward_backward(n_in, n_out, nn, nl, P):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n_in * 7 + n_out * 3 + nn + nl)
+    params = tr.mlp_init(n_in, n_out, nn, nl, g)
+    assert params.numel() == ops.mlp_param_count(n_in, n_out, nn, nl)
+    x = torch.randn(P, n_in, generator=g)
+    gy = torch.randn(P, n_out, generator=g)
+    xo, po = x.clone().requires_grad_(True), params.clone().requires_grad_(True)
+    yo = tr.mlp_forward(xo, po, n_in, n_out, nn, nl)
+    (yo * gy).sum().backward()
+    xp, pp = x.to(DEV).requires_grad_(True), params.to(DEV).requires_grad_(True)
+    yp = ops.mlp(xp, pp, n_in, n_out, nn, nl)
+    (yp * gy.to(DEV)).sum().backward()
+    assert_close(yp.cpu(), yo, what="mlp fwd")
+    assert_close(xp.grad.cpu(), xo.grad, what="mlp dx")
+    op = tr.mlp_out_padded(n_out)
+    used = slice(0, params.numel() - (op - n_out) * nn)            # padded output rows get no gradient
+    assert_close(pp.grad.cpu()[used], po.grad[used], what="mlp dparams")
+    assert torch.count_nonzero(pp.grad.cpu()[used.stop:]) == 0
+
+
+def test_mlp_strided_input_view():
+    """x may be a column view of a wider buffer (the [P,80] encode buffer inside a [P,112] one)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    params = tr.mlp_init(80, 33, 32, 1, g)
+    big = torch.randn(500, 112, generator=g)
+    yo = tr.mlp_forward(big[:, :80], params, 80, 33, 32, 1)
+    yp = ops.mlp(big.to(DEV)[:, :80], params.to(DEV), 80, 33, 32, 1)
+    assert_close(yp.cpu(), yo, what="mlp strided")
+
+
+@pytest.mark.parametrize("nn,nl", [(32, 1), (64, 2)])
+def test_mlp_grouped_matches_per_class_loop(nn, nl):
+    """Per-class fine decoders (slams/mapping.py:590-601): routing, the >1-point rule, zeros elsewhere."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    G, P = 5, 3000
+    pool = torch.stack([tr.mlp_init(80, 33, nn, nl, g) for _ in range(G)])
+    x = torch.randn(P, 80, generator=g)
+    slot = torch.randint(0, G - 1, (P,), generator=g)
+    slot[7] = G - 1                      # a class with exactly one point -> zeros (index.sum() > 1 rule)
+    slot[11] = -1                        # no decoder
+    gy = torch.randn(P, 33, generator=g)
+    xo, po = x.clone().requires_grad_(True), pool.clone().requires_grad_(True)
+    yo = torch.zeros(P, 33)
+    for c in range(G):
+        idx = torch.nonzero(slot == c).reshape(-1)
+        if idx.numel() > 1:
+            yo = yo.index_put((idx,), tr.mlp_forward(xo[idx], po[c], 80, 33, nn, nl))
+    (yo * gy).sum().backward()
+    xp, pp = x.to(DEV).requires_grad_(True), pool.to(DEV).requires_grad_(True)
+    yp = ops.mlp_grouped(xp, pp, slot.to(DEV), 80, 33, nn, nl)
+    (yp * gy.to(DEV)).sum().backward()
+    assert_close(yp.cpu(), yo, what="grouped fwd")
+    assert torch.count_nonzero(yp[7]) == 0 and torch.count_nonzero(yp[11]) == 0
+    assert_close(xp.grad.cpu(), xo.grad, what="grouped dx")
+    used = 80 * nn + (nl - 1) * nn * nn + 33 * nn
+    assert_close(pp.grad.cpu()[:, :used], po.grad[:, :used], what="grouped dparams")
+
+
+# ----------------------------------------------------------------------------------------- compositing
+def test_composite_golden(golden_dir):
+    """raw2nerf_color outputs and input gradient of the IMPORTED reference."""
+    ops = _ops()
+    gd = np.load(os.path.join(golden_dir, "raw2nerf_color.npz"))
+    for ci in range(int(gd["n_cases"])):
+        p = f"c{ci}_"
+        raw = _t(gd[p + "raw"]).to(DEV).requires_grad_(True)
+        z = _t(gd[p + "z"]).to(DEV)
+        depth, var, rgb, w, _ = ops.composite(raw, z, None)
+        for a, k in ((depth, "depth"), (var, "var"), (rgb, "rgb"), (w, "weights")):
+            assert_close(a.cpu(), _t(gd[p + k]), what=f"case {ci} {k}")
+        loss = (depth * _t(gd[p + "g_depth"]).to(DEV)).sum() + (var * _t(gd[p + "g_var"]).to(DEV)).sum() \
+            + (rgb * _t(gd[p + "g_rgb"]).to(DEV)).sum() + (w * _t(gd[p + "g_w"]).to(DEV)).sum()
+        loss.backward()
+        assert_close(raw.grad.cpu(), _t(gd[p + "grad_raw"]), what=f"case {ci} grad_raw")
+
+
+@pytest.mark.parametrize("N,S,C", [(300, 47, 40), (64, 64, 8), (33, 128, 8), (5, 200, 3), (7, 1, 4), (2000, 64, 0)])
+def test_composite_vs_oracle(N, S, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + S + C)
+    raw = torch.randn(N, S, 4, generator=g)
+    raw[..., 3] *= 0.3
+    z = torch.sort(torch.rand(N, S, generator=g) * 4 + 0.1, -1)[0]
+    logits = torch.randn(N, S, C, generator=g) if C else None
+    gs = [torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, max(C, 1), generator=g)]
+    ro = raw.clone().requires_grad_(True)
+    lo = logits.clone().requires_grad_(True) if C else None
+    d, v, c, w = rm.raw2nerf_color(ro, z)
+    loss = (d * gs[0]).sum() + (v * gs[1]).sum() + (c * gs[2]).sum()
+    if C:
+        sem_o = torch.sum(w[..., None] * lo, -2)
+        loss = loss + (sem_o * gs[3]).sum()
+    loss.backward()
+    rp = raw.to(DEV).requires_grad_(True)
+    lp = logits.to(DEV).requires_grad_(True) if C else None
+    dp, vp, cp, wp, sp = ops.composite(rp, z.to(DEV), lp)
+    lossp = (dp * gs[0].to(DEV)).sum() + (vp * gs[1].to(DEV)).sum() + (cp * gs[2].to(DEV)).sum()
+    if C:
+        lossp = lossp + (sp * gs[3].to(DEV)).sum()
+    lossp.backward()
+    assert_close(dp.cpu(), d, what="depth")
+    assert_close(vp.cpu(), v, what="var")
+    assert_close(cp.cpu(), c, what="rgb")
+    assert_close(wp.cpu(), w, what="weights")
+    assert abs(float(wp.sum(-1).mean()) - 1.0) < 1e-5
+    assert_close(rp.grad.cpu(), ro.grad, what="d raw")
+    if C:
+        assert_close(sp.cpu(), sem_o, what="sem")
+        assert_close(lp.grad.cpu(), lo.grad, what="d logits")
+
+
+def test_composite_known_answers_and_nan():
+    ops = _ops()
+    raw = torch.zeros(3, 8, 4, device=DEV)              # alpha = 0.5 everywhere -> w_i ~ 2^-i (1e-10 aside)
+    z = torch.arange(8, device=DEV).float().expand(3, 8).contiguous()
+    _, _, _, w, _ = ops.composite(raw, z, None)
+    ref = 0.5 ** torch.arange(1, 9).float()
+    assert torch.allclose(w[0].cpu(), ref / ref.sum(), atol=1e-6)
+    one = ops.composite(torch.randn(4, 1, 4, device=DEV), torch.rand(4, 1, device=DEV), None)[3]
+    assert torch.allclose(one, torch.ones_like(one))      # single-sample ray -> weight 1
+    dead = torch.zeros(2, 8, 4, device=DEV)
+    dead[..., 3] = -20.0                                  # every alpha underflows: 0/0, reference gives NaN (D9)
+    d = ops.composite(dead, z[:2].contiguous(), None)[0]
+    d_ref = rm.raw2nerf_color(dead.cpu(), z[:2].cpu())[0]
+    assert torch.isnan(d_ref).all() and torch.isnan(d).all()
+
+
+# ----------------------------------------------------------------------------------------- ray generation + sampling
+def _scene_small(seed, H=48, W=64, K=3):
+    g = torch.Generator().manual_seed(seed)
+    color = torch.rand(K, H, W, 3, generator=g)
+    depth = torch.rand(K, H, W, generator=g) * 4 + 0.3
+    depth[torch.rand(K, H, W, generator=g) < 0.05] = 0.0
+    label = torch.randint(0, 6, (K, H, W), generator=g).float()
+    q = torch.randn(K, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True) * (1 + 0.1 * torch.rand(K, 1, generator=g))     # not exactly unit
+    T = torch.randn(K, 3, generator=g) * 0.5
+    return color, depth, label, q, T
+
+
+@pytest.mark.parametrize("nu,ns", [(32, 15), (48, 16), (96, 32), (0, 15), (22, 10)])
+def test_raygen_sample_bit_exact_vs_oracle(nu, ns):
+    ops = _ops()
+    K, H, W, npf = 3, 48, 64, 200
+    color, depth, label, q, T = _scene_small(nu + ns)
+    bound = torch.tensor([[-3.0, 3.5], [-2.5, 4.0], [-2.0, 2.2]], dtype=torch.float64)
+    cam = (50.0, 52.0, (W - 1) / 2.0, (H - 1) / 2.0)
+    g = torch.Generator().manual_seed(9)
+    idx = torch.randint(H * W, (K * npf,), generator=g)
+    t = torch.rand(ns, generator=g)
+    t[ns // 2 + 1] = 0.5
+    t0 = torch.rand(ns, generator=g)
+    tu = torch.linspace(0.0, 1.0, steps=nu) if nu else None
+    outs = ops.raygen_sample(q.to(DEV), T.to(DEV), idx.to(DEV), color.to(DEV), depth.to(DEV), label.to(DEV), cam, bound,
+                             (0, H, 0, W), npf, tu.to(DEV) if nu else None, t.to(DEV), t0.to(DEV))
+    rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = [o.cpu() for o in outs]
+    for f in range(K):
+        sl = slice(f * npf, (f + 1) * npf)
+        img5 = torch.cat((color[f], depth[f][..., None], label[f][..., None]), -1)
+        R = rm.rotation_from_quad(q[f])
+        i, j = rm.uv_from_indices(idx[sl], 0, H, 0, W)
+        px = rm.gather_pixels(idx[sl], img5, 0, H, 0, W)
+        ro, rd = rm.rays_from_uv(i, j, R, T[f], *cam)
+        far, ins = rm.box_far(ro, rd, px[:, 3], bound)
+        zo = rm.sample_along_rays(px[:, 3], nu, ns, far, t, t0)
+        assert torch.equal(gt_color[sl], px[:, :3]) and torch.equal(gt_depth[sl], px[:, 3])
+        assert torch.equal(gt_label[sl], px[:, 4].long())
+        assert_close(rays_d[sl], rd, rtol=1e-6, what="rays_d")       # quat->R summation order may differ by an ulp
+        assert torch.equal(rays_o[sl], ro.contiguous())
+        assert torch.equal(inside[sl].bool(), ins)
+        if torch.equal(rays_d[sl], rd):
+            assert torch.equal(z[sl], zo), f"frame {f}: z not bit-exact"
+            assert torch.equal(pts[sl], rm.points_from_rays(ro, rd, zo))
+        else:
+            assert_close(z[sl], zo, rtol=1e-6, what="z")
+        assert (z[sl][:, 1:] >= z[sl][:, :-1]).all()                  # sorted ascending
+
+
+def test_sample_along_rays_golden_bit_exact(golden_dir):
+    """sample_along_rays of the IMPORTED reference (15 cases: zero depths, negative / huge far_bb, S up to 128)."""
+    from dns_slam_amd import common
+    gd = np.load(os.path.join(golden_dir, "sample_along_rays.npz"))
+    for ci in range(int(gd["n_cases"])):
+        p = f"c{ci}_"
+        nu, ns = [int(v) for v in gd[p + "n"]]
+        t = _t(gd[p + "t_raw"]).clone()
+        if not torch.any(t == 0.5):
+            t[ns // 2 + 1] = 0.5
+        z = common.sample_along_rays(_t(gd[p + "depth"]).to(DEV), nu, ns, _t(gd[p + "far_bb"]).to(DEV), DEV,
+                                     jitter=(t, _t(gd[p + "t_zero"])))
+        assert torch.equal(z.cpu(), _t(gd[p + "z"])), f"golden case {ci} ({nu}+{ns})"
+
+
+def test_raygen_pose_gradient():
+    ops = _ops()
+    K, H, W, npf, nu, ns = 2, 48, 64, 150, 8, 5
+    color, depth, label, q, T = _scene_small(77, K=K)
+    bound = torch.tensor([[-3.0, 3.5], [-2.5, 4.0], [-2.0, 2.2]], dtype=torch.float64)
+    cam = (50.0, 52.0, (W - 1) / 2.0, (H - 1) / 2.0)
+    g = torch.Generator().manual_seed(10)
+    idx = torch.randint(H * W, (K * npf,), generator=g)
+    t, t0 = torch.rand(ns, generator=g), torch.rand(ns, generator=g)
+    tu = torch.linspace(0.0, 1.0, steps=nu)
+    gp = torch.randn(K * npf, nu + ns, 3, generator=g)
+    gd_, go = torch.randn(K * npf, 3, generator=g), torch.randn(K * npf, 3, generator=g)
+    qp, Tp = q.to(DEV).requires_grad_(True), T.to(DEV).requires_grad_(True)
+    outs = ops.raygen_sample(qp, Tp, idx.to(DEV), color.to(DEV), depth.to(DEV), label.to(DEV), cam, bound, (0, H, 0, W),
+                             npf, tu.to(DEV), t.to(DEV), t0.to(DEV))
+    ((outs[2] * gp.to(DEV)).sum() + (outs[1] * gd_.to(DEV)).sum() + (outs[0] * go.to(DEV)).sum()).backward()
+    z = outs[7].cpu()
+    qo, To = q.clone().requires_grad_(True), T.clone().requires_grad_(True)
+    loss = 0
+    for f in range(K):
+        sl = slice(f * npf, (f + 1) * npf)
+        i, j = rm.uv_from_indices(idx[sl], 0, H, 0, W)
+        ro, rd = rm.rays_from_uv(i, j, rm.rotation_from_quad(qo[f]), To[f], *cam)
+        loss = loss + (rm.points_from_rays(ro, rd, z[sl]) * gp[sl]).sum() + (rd * gd_[sl]).sum() + (ro * go[sl]).sum()
+    loss.backward()
+    assert_close(qp.grad.cpu(), qo.grad, what="d quat")
+    assert_close(Tp.grad.cpu(), To.grad, what="d T")

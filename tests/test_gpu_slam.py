@@ -1,0 +1,222 @@
+"""GPU parity at the reference's interface level: Mapper.get_target_samples / renderer / the seven-term loss and its
+gradients (grid, every MLP, per-class fine decoders, quaternion, translation), Tracker.renderer / losses, against the
+oracle on identical parameters, indices and jitter.  Tolerance 1e-4 relative (BASELINE.json)."""
+import pytest
+import torch
+
+from oracle import render_math as rm
+from oracle import slam_ref as sr
+from util import assert_close, oracle_from_product, randomise_, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(n_neurons=32, n_hidden_layers=1, n_pixels=360, ns_ray=32, nsurf=15, layout="reference_tiled", seed=0):
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    cam = synthetic.camera(H=60, W=80, fx=60.0, fy=60.0)
+    bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=seed)
+    cfg = synthetic.default_cfg(n_pixels=n_pixels, n_samples_ray=ns_ray, n_surface_ray=nsurf, n_frames=4, hash_size=14,
+                                voxel_size=0.08, n_neurons=n_neurons, n_hidden_layers=n_hidden_layers, smooth_pts=12)
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    mapper = Mapper(cfg, dec, bound, cam, device=DEV, label_layout=layout)
+    mapper.set_decoder(frames)
+    randomise_(dec, 11, scale=1.0)
+    with torch.no_grad():
+        dec.pe_fn.grid_fn.params.mul_(2000.0)            # U(-1e-4,1e-4) init would hide the grid in rounding noise
+    randomise_([mapper.fine_decoders.pool], 12)
+    return cfg, bound, cam, frames, dec, mapper
+
+
+def _oracle_samples(frames, quats, Ts, cam, bound, pix_idx, jitter, npf, ns_ray, nsurf):
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    out = []
+    for f in range(4):
+        img5 = torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
+        out.append(sr.frame_samples(img5, quats[f], Ts[f], camt, bound, pix_idx[f * npf:(f + 1) * npf], jitter[0], jitter[1],
+                                    ns_ray, nsurf))
+    return sr.mapper_target_samples(out)
+
+
+def test_get_target_samples_matches_oracle():
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    mapper.is_BA = True
+    _, quad_list, T_list = mapper.set_optimizer(frames)
+    prep = mapper.prepare_frames(frames)
+    torch.manual_seed(3)
+    pix = mapper.draw_pixels(prep)
+    jit = mapper.draw_jitter()
+    s = mapper.get_target_samples(frames, quad_list, T_list, prep=prep, pix_idx=pix, jitter=jit)
+    npf = pix.numel() // 4
+    so = _oracle_samples(frames, [q.detach().cpu() for q in quad_list], [t.detach().cpu() for t in T_list], cam, bound,
+                         pix.cpu(), (jit[0].cpu(), jit[1].cpu()), npf, 32, 15)
+    assert torch.equal(s["gt_label"].cpu(), so["gt_label"])
+    assert torch.equal(s["gt_depth"].cpu(), so["gt_depth"]) and torch.equal(s["gt_color"].cpu(), so["gt_color"])
+    assert_close(s["rays_d"].cpu(), so["rays_d"], rtol=1e-6, what="rays_d")
+    assert_close(s["z_vals"].cpu(), so["z_vals"], rtol=1e-6, what="z_vals")
+    assert_close(s["pts"].cpu(), so["pts"], rtol=1e-6, what="pts")
+    # class-balanced part: every class of each frame is drawn (select_by_class, utils/common.py:313-328)
+    n1, n2 = prep["n1"], prep["n2"]
+    lab = s["gt_label"].cpu()
+    assert lab.numel() == 4 * (n1 + n2)
+    for f in range(4):
+        by_class = lab[f * npf + n1:(f + 1) * npf]
+        present = torch.unique(frames["gt_label"][f]).long()
+        assert set(torch.unique(by_class).tolist()) == set(present.tolist())
+
+
+@pytest.mark.parametrize("nn,nl,layout", [(32, 1, "reference_tiled"), (64, 2, "reference_tiled"), (32, 1, "per_ray")])
+def test_mapper_renderer_loss_and_gradients(nn, nl, layout):
+    cfg, bound, cam, frames, dec, mapper = _setup(nn, nl, layout=layout)
+    mapper.is_BA = True
+    _, quad_list, T_list = mapper.set_optimizer(frames)
+    prep = mapper.prepare_frames(frames)
+    torch.manual_seed(5)
+    pix = mapper.draw_pixels(prep)
+    jit = mapper.draw_jitter()
+    g = torch.Generator().manual_seed(6)
+    u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+    samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep, pix_idx=pix, jitter=jit)
+    N, S = samples["z_vals"].shape
+    feats = torch.rand(N, S, 32, generator=g)
+    samples["features"] = feats.to(DEV)
+    loss, terms = mapper.iteration_loss(samples, lambda_lt=10.0, smooth=True, u_offset=u_off, u_jitter=u_jit, strict=True)
+    loss.backward()
+
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    qo = [q.detach().cpu().clone().requires_grad_(q.requires_grad) for q in quad_list]
+    To = [t.detach().cpu().clone().requires_grad_(t.requires_grad) for t in T_list]
+    npf = pix.numel() // 4
+    so = _oracle_samples(frames, qo, To, cam, bound, pix.cpu(), (jit[0].cpu(), jit[1].cpu()), npf, 32, 15)
+    so["features"] = feats
+    lc = sr.LossCfg(smooth_pts=cfg["training"]["smooth_pts"])
+    lo, to, outs = sr.mapping_loss(om, so, lc, u_off, u_jit, label_layout=layout)
+    lo.backward()
+
+    pc, pd, pv, pl, fine, coarse = mapper.renderer(samples)
+    assert_close(pc.cpu(), outs["rgb"], what="pred_color")
+    assert_close(pd.cpu(), outs["depth"], what="pred_depth")
+    assert_close(pv.cpu(), outs["var"], what="pred_depth_var")
+    assert_close(pl.cpu(), outs["logits"], what="pred_logits")
+    assert_close(fine.cpu(), outs["fine"], what="fine_latents")
+    assert_close(coarse.cpu(), outs["coarse"], what="coarse_latents")
+    for k_p, k_o in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"),
+                     ("opacity_loss", "op"), ("smooth_loss", "sm")):
+        a, b = float(terms[k_p]), float(to[k_o])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), f"{k_p}: {a} vs {b}"
+    assert abs(float(loss) - float(lo)) <= 1e-4 * abs(float(lo))
+
+    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what="d table")
+    used = lambda n_in, n_out: nn * n_in + (nl - 1) * nn * nn + n_out * nn
+    assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:used(80, 33)], om.coarse.grad[:used(80, 33)], what="d coarse")
+    assert_close(dec.out_fn.color_decoder.params.grad.cpu()[:used(112, 3)], om.color.grad[:used(112, 3)], what="d color")
+    assert_close(dec.out_fn.logit_decoder.params.grad.cpu()[:used(112, 8)], om.logit.grad[:used(112, 8)], what="d logit")
+    pool_grad = mapper.fine_decoders.pool.grad.cpu()
+    for c, slot in mapper.fine_decoders.slot.items():
+        go = om.fine[c].grad
+        if go is None:
+            assert torch.count_nonzero(pool_grad[slot]) == 0
+        else:
+            assert_close(pool_grad[slot][:used(80, 33)], go[:used(80, 33)], what=f"d fine[{c}]")
+    for f in range(1, 4):                                 # frame 0 is fixed (slams/mapping.py:457)
+        assert_close(quad_list[f].grad.cpu(), qo[f].grad, rtol=2e-4, what=f"d quat[{f}]")
+        assert_close(T_list[f].grad.cpu(), To[f].grad, rtol=2e-4, what=f"d T[{f}]")
+    assert quad_list[0].grad is None
+
+
+def test_fine_fn_unknown_class_raises():
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    pe = torch.rand(256, 48, device=DEV)
+    grid = torch.rand(256, 32, device=DEV)
+    classes = torch.full((256,), 31, device=DEV, dtype=torch.int64)      # no decoder for class 31
+    with pytest.raises(ValueError):
+        mapper.fine_fn(pe, classes=classes, features=grid)
+
+
+def test_tracker_renderer_losses_and_pose_gradient():
+    from dns_slam_amd.tracking import Tracker
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    cfg["tracking"]["n_pixels"] = 200
+    tracker = Tracker(cfg, dec, bound, cam, device=DEV)
+    tracker.border = 5
+    cur = {"gt_color": frames["gt_color"][1], "gt_depth": frames["gt_depth"][1], "gt_label": frames["gt_label"][1]}
+    _, quad, T = tracker.set_optimizer(frames["est_c2w"][1])
+    cur["est_quad"], cur["est_T"] = quad, T
+    torch.manual_seed(8)
+    pix, jit = tracker.draw_pixels(), tracker.draw_jitter()
+    s = tracker.get_target_samples(cur, pix_idx=pix, jitter=jit)
+    g = torch.Generator().manual_seed(9)
+    feats = torch.rand(200, 47, 32, generator=g)
+    s["features"] = feats.to(DEV)
+    pc, pd, pv, pl = tracker.renderer(s)
+    loss = 5.0 * tracker.compute_photometric_loss(s["gt_color"], pc, s["mask"]) \
+        + 5.0 * tracker.compute_depth_loss(s["gt_depth"], pd, pv, s["mask"]) \
+        + 0.1 * tracker.compute_label_loss(s["gt_label"], pl, s["mask"])
+    loss.backward()
+
+    om = oracle_from_product(cfg, bound, dec)
+    qo, To = quad.detach().cpu().clone().requires_grad_(True), T.detach().cpu().clone().requires_grad_(True)
+    img5 = torch.cat((cur["gt_color"], cur["gt_depth"][..., None], cur["gt_label"][..., None]), -1)
+    b = tracker.border
+    so = sr.frame_samples(img5, qo, To, (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]), bound, pix.cpu(),
+                          jit[0].cpu(), jit[1].cpu(), 32, 15, window=(b, cam["H"] - b, b, cam["W"] - b))
+    so["features"] = feats
+    mask = (so["gt_depth"] > 0.01) & so["inside"]
+    assert torch.equal(mask, s["mask"].cpu())
+    lo, _, outs = sr.tracking_loss(om, so, mask)
+    lo.backward()
+    assert_close(pc.cpu(), outs["rgb"], what="color")
+    assert_close(pd.cpu(), outs["depth"], what="depth")
+    assert_close(pv.cpu(), outs["var"], what="var")
+    assert_close(pl.cpu(), outs["logits"], what="logits")
+    assert abs(float(loss) - float(lo)) <= 1e-4 * abs(float(lo))
+    assert_close(quad.grad.cpu(), qo.grad, rtol=2e-4, what="d quat")
+    assert_close(T.grad.cpu(), To.grad, rtol=2e-4, what="d T")
+
+
+def test_mapping_iterations_reduce_loss():
+    """Integration: a few optimise iterations on the analytic room lower the loss (reference has no such test)."""
+    cfg, bound, cam, frames, dec, mapper = _setup(n_pixels=800)
+    from dns_slam_amd.decoder import Decoder
+    dec2 = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    from dns_slam_amd.mapping import Mapper
+    m2 = Mapper(cfg, dec2, bound, cam, device=DEV)
+    torch.manual_seed(0)
+    m2.set_decoder(frames)
+    opt, ql, Tl = m2.set_optimizer(frames)
+    for gidx in range(3):
+        opt.param_groups[gidx]["lr"] = 0.005 if gidx == 0 else 0.0
+    prep = m2.prepare_frames(frames)
+    losses = []
+    for it in range(40):
+        opt.zero_grad()
+        s = m2.get_target_samples(frames, ql, Tl, prep=prep)
+        loss, _ = m2.iteration_loss(s, smooth=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert sum(losses[-5:]) / 5 < 0.6 * (sum(losses[:5]) / 5), losses
+
+
+def test_decoder_module_contract():
+    """.state_dict() keys, deepcopy, pickle, share_memory-free CUDA sharing surface."""
+    import copy
+    import pickle
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    keys = set(dec.state_dict().keys())
+    for k in ("pe_fn.grid_fn.params", "coarse_fn.decoder.params", "out_fn.color_decoder.params",
+              "out_fn.logit_decoder.params", "merge.decoder.params"):
+        assert k in keys
+    d2 = copy.deepcopy(dec)
+    d3 = pickle.loads(pickle.dumps(dec))
+    x = torch.rand(300, 3, device=DEV)
+    for d in (d2, d3):
+        pe, gr = d.pe_fn(x)
+        pe0, gr0 = dec.pe_fn(x)
+        assert torch.equal(pe, pe0) and torch.equal(gr, gr0)
+        assert torch.equal(d.coarse_fn(pe, features=gr), dec.coarse_fn(pe0, features=gr0))
+    assert dec.pe_dim == 48 and dec.grid_dim == 32
+    col, log = dec.out_fn(pe0, torch.rand(300, 64, device=DEV))
+    assert col.shape == (300, 3) and log.shape == (300, 8) and float(col.min()) >= 0 and float(col.max()) <= 1
