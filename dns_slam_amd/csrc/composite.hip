@@ -216,6 +216,7 @@ using namespace dns;
 extern "C" int dns_composite_fwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
                                  uint32_t C, float* depth, float* var, float* rgb, float* weights, float* sem,
                                  void* stream) {
+  if (N == 0) return DNS_OK;
   DNS_REQUIRE(raw && z && depth && var && rgb, "dns_composite_fwd: NULL argument");
   DNS_REQUIRE(S >= 1 && S <= 256, "dns_composite_fwd: S=%u out of range [1,256]", S);
   DNS_REQUIRE(C == 0 || (logits && sem), "dns_composite_fwd: C>0 needs logits and sem");
@@ -234,6 +235,7 @@ extern "C" int dns_composite_bwd(const float* raw, const float* z, const float* 
                                  uint32_t C, const float* d_depth, const float* d_var, const float* d_rgb,
                                  const float* d_weights, const float* d_sem, float* d_raw, float* d_logits,
                                  void* stream) {
+  if (N == 0) return DNS_OK;
   DNS_REQUIRE(raw && z && d_raw, "dns_composite_bwd: NULL argument");
   DNS_REQUIRE(S >= 1 && S <= 256, "dns_composite_bwd: S=%u out of range [1,256]", S);
   DNS_REQUIRE(C == 0 || logits, "dns_composite_bwd: C>0 needs logits");

@@ -258,8 +258,8 @@ using namespace dns;
 extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
                               const DnsGridMeta* meta, float* x_out, float* pe_out, uint32_t ld_pe, float* grid_out,
                               uint32_t ld_grid, void* stream) {
-  DNS_REQUIRE(in != nullptr, "dns_encode_fwd: in is NULL");
   if (P == 0) return DNS_OK;
+  DNS_REQUIRE(in != nullptr, "dns_encode_fwd: in is NULL");
   if (pe_out) DNS_REQUIRE(n_bins >= 1 && n_bins <= 64 && ld_pe >= 3 * n_bins, "dns_encode_fwd: n_bins %u / ld_pe %u", n_bins, ld_pe);
   GridLevels lv = {};
   if (grid_out) {
@@ -277,8 +277,8 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
 extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
                               const DnsGridMeta* meta, const float* d_pe, uint32_t ld_dpe, const float* d_grid,
                               uint32_t ld_dgrid, float* d_table, float* d_x, void* stream) {
-  DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
   if (P == 0) return DNS_OK;
+  DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
   GridLevels lv = {};
   if (d_grid) {
     DNS_REQUIRE(meta && table, "dns_encode_bwd: d_grid given without table/meta");
@@ -293,8 +293,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
 }
 
 extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, uint32_t* rows, void* stream) {
-  DNS_REQUIRE(x && meta && rows, "dns_hashgrid_indices: NULL argument");
   if (P == 0) return DNS_OK;
+  DNS_REQUIRE(x && meta && rows, "dns_hashgrid_indices: NULL argument");
   hipLaunchKernelGGL(hashgrid_indices_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, P,
                      to_levels(meta), rows);
   return check_launch("dns_hashgrid_indices");

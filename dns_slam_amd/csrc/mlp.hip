@@ -527,6 +527,7 @@ extern "C" uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, 
 extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
                            uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
                            const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream) {
+  if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
@@ -556,6 +557,7 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
                            uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* d_x,
                            uint32_t lddx, float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
                            const int32_t* tile_group, uint32_t param_stride, void* stream) {
+  if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params && ws, "dns_mlp_bwd: NULL argument");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);

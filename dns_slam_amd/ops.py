@@ -196,7 +196,9 @@ class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, params, shape, row_index, tile_group, n_slots):
         n_in, n_out, nn, nl = shape
-        require_cuda(x, params, row_index, tile_group)
+        require_cuda(params, row_index, tile_group)
+        if not x.is_cuda:
+            raise ValueError("dns_slam_amd ops run on the GPU only (got a non-CUDA tensor); there is no CPU fallback")
         x = _row_major_2d(x.float())
         P = x.shape[0]
         if row_index is None:
