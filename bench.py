@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="per-step progress on stderr")
     args = ap.parse_args()
 
     from dns_slam_amd import dist as ddist
@@ -153,8 +154,12 @@ def main():
     n_rays = 4 * sum(wl["rays"])
     S = wl["nu"] + wl["ns"]
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        if args.verbose:
+            torch.cuda.synchronize()
+            print(f"[bench] warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     ctx.barrier()
     torch.cuda.synchronize()
     if not args.no_kernel_timing:

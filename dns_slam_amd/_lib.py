@@ -54,6 +54,8 @@ def _load():
             f"{LIB_PATH} is missing: the HIP hot-path library has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dns_slam_amd/csrc`). "
             "dns_slam_amd has no CPU fallback.")
+    # torch first: libdns_hip.so has no HIP runtime of its own and binds to the one PyTorch-ROCm loaded
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
