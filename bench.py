@@ -67,13 +67,14 @@ def build(wl, device, seed, dist_ctx):
     mapper.rays_per_frame = wl["rays"]
     mapper.dist = dist_ctx
     mapper.is_BA = True
+    mapper.static_shapes = True                              # sync-free iteration: capturable in a hipGraph
     mapper.set_decoder(frames)
-    optimizer, quad_list, T_list = mapper.set_optimizer(frames)
-    optimizer.param_groups[0]["lr"] = mapper.lr
-    optimizer.param_groups[1]["lr"] = mapper.BA_cam_lr
-    optimizer.param_groups[2]["lr"] = mapper.BA_cam_lr
+    optimizer, quad_list, T_list = mapper.set_optimizer(frames, capturable=True)
+    for grp, lr in zip(optimizer.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):
+        grp["lr"] = torch.tensor(lr, device=device)          # capturable Adam wants tensor lrs on the device
     prep = mapper.prepare_frames(frames)
     torch.manual_seed(seed)                                  # per-rank ray draws
+    torch.cuda.manual_seed(seed)
     params = [p for g in optimizer.param_groups for p in g["params"]]
 
     def step():
@@ -86,6 +87,22 @@ def build(wl, device, seed, dist_ctx):
         return loss
 
     return cfg, bound, cam, frames, mapper, step
+
+
+def capture(step, n_warm=3):
+    """Capture one full iteration (sampling -> ... -> Adam) into a hipGraph; replays draw fresh rays (graph-safe
+    Philox offsets).  Returns a zero-argument callable."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(n_warm):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    return g.replay
 
 
 def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
@@ -141,6 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-step progress on stderr")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     from dns_slam_amd import dist as ddist
@@ -154,24 +172,39 @@ def main():
     n_rays = 4 * sum(wl["rays"])
     S = wl["nu"] + wl["ns"]
 
+    run = step
+    graphed = False
+    if not args.no_graph:
+        try:
+            run = capture(step)
+            graphed = True
+        except Exception as e:                               # keep the benchmark alive: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            run = step
     for i in range(args.warmup):
         tw = time.perf_counter()
-        step()
+        run()
         if args.verbose:
             torch.cuda.synchronize()
             print(f"[bench] warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     ctx.barrier()
     torch.cuda.synchronize()
-    if not args.no_kernel_timing:
-        ops.timer.arm()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     ctx.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_times = ops.timer.disarm() if not args.no_kernel_timing else {}
     elapsed = ctx.max_over_ranks(elapsed, device)
+    # per-kernel durations for the roofline: the same K steps launched eagerly with an event pair around every
+    # C-ABI call (a replayed graph cannot be bracketed per kernel; kernels and shapes are identical)
+    kernel_times = {}
+    if not args.no_kernel_timing:
+        ops.timer.arm()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        kernel_times = ops.timer.disarm()
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_rays * S * ctx.world_size / (ms_per_step / 1e3)
 
@@ -201,7 +234,7 @@ def main():
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "hip_graph": graphed,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
                    "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
         "roofline": roofline,

@@ -11,6 +11,7 @@
 // Arithmetic contract shared with oracle/tcnn_ref.py: pos = x*scale + 0.5 is two IEEE roundings
 // (__fmul_rn/__fadd_rn, never contracted), the cell is (uint32)(int)floorf(pos); hash primes
 // {1, 2654435761, 805459861}; index % level size.  Those make the table rows bit-exact.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace dns {
@@ -224,6 +225,164 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Table gradient by LDS binning in 64-bit fixed point.
+//
+// Per-corner global atomics (one lane = one random row) run ~17x below the coalesced atomic rate on gfx950
+// and serialise on the 4096-cell coarse levels.  Instead a workgroup owns one CHUNK of one level (8192 rows held
+// in LDS), sweeps a slice of the points, recomputes that level's 8 corner rows per point (cheap integer math)
+// and accumulates the corners that fall in its chunk; the chunk then leaves as fully coalesced global float
+// atomics (256 B per wave instruction, the full-rate shape).
+//
+// The LDS accumulators are 64-bit FIXED POINT, not float: measured on MI355X (tools/lds_atomic_rate.hip) ds_add_f32
+// retires ~1 lane per 3 cycles per CU (195 cycles per wave instruction, 0.2 T lane-atomics/s chip-wide) while
+// ds_add_u64 takes 11.8 cycles per wave instruction (3.3 T/s) -- 16x.  Every contribution w*g (an fp32 product) is
+// scaled by a power of two chosen from max|dL/dy| of the launch (so the product converts to int64 exactly and 2^22
+// contributions cannot overflow) and added as an integer: the per-chunk sums are exact and order-independent.
+struct BinPlan {
+  uint32_t n_levels;
+  uint32_t chunk_rows;                    // rows per chunk
+  uint32_t strided_dense;                 // dense levels: one contiguous run of points per thread
+  uint32_t job_prefix[DNS_MAX_LEVELS + 1];  // prefix sum over levels of chunks[l] * slices[l]
+  uint32_t chunks[DNS_MAX_LEVELS];
+  uint32_t slices[DNS_MAX_LEVELS];
+};
+
+// d_grid rows [P, ld] (32 contiguous floats per point) -> level-major [L][P] float2, so that a binned job reads
+// only its level's 8 bytes per point; also max |d_grid| of the launch (bit pattern, atomicMax) for the fixed-point scale.
+__global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __restrict__ d_grid, uint32_t ld, uint32_t P,
+                                                              uint32_t n_levels, float2* __restrict__ dg_t,
+                                                              uint32_t* __restrict__ gmax) {
+  // 256 points per workgroup through an LDS tile: rows are read as whole 128-byte lines (8 lanes x 16 B per point),
+  // level planes are written as 2-KB contiguous runs (lane = point).  Row stride 34 floats keeps both sides <= 2-way.
+  constexpr uint32_t LDT = 34;
+  __shared__ float tile[256 * LDT];
+  const uint32_t p0 = blockIdx.x * 256u;
+  const uint32_t nf = n_levels * 2;                  // floats per row (<= 32 with the supported 16 levels)
+  const bool vec = ((ld & 3u) == 0) && ((((uintptr_t)d_grid) & 15u) == 0) && ((nf & 3u) == 0);
+  float m = 0.f;
+  for (uint32_t e = threadIdx.x; e < 256u * 8u; e += 256u) {
+    const uint32_t r = e >> 3, q = e & 7u;
+    const uint32_t p = p0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < P && 4 * q < nf) {
+      const float* src = d_grid + (size_t)p * ld + 4 * q;
+      if (vec) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        if (4 * q + 1 < nf) v.y = src[1];
+        if (4 * q + 2 < nf) v.z = src[2];
+        if (4 * q + 3 < nf) v.w = src[3];
+      }
+    }
+    float* d = tile + r * LDT + 4 * q;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  __syncthreads();
+  const uint32_t p = p0 + threadIdx.x;
+  if (p < P) {
+    for (uint32_t l = 0; l < n_levels; ++l)
+      dg_t[(size_t)l * P + p] = make_float2(tile[threadIdx.x * LDT + 2 * l], tile[threadIdx.x * LDT + 2 * l + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63u) == 0 && m > 0.f && m < INFINITY) atomicMax(gmax, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* __restrict__ xin, uint32_t P,
+                                                                    GridLevels lv, BinPlan plan,
+                                                                    const float2* __restrict__ dg_t,
+                                                                    const uint32_t* __restrict__ gmax,
+                                                                    float* __restrict__ d_table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
+  const float mx = __uint_as_float(*gmax);
+  if (!(mx > 0.f)) return;                       // all-zero upstream gradient: nothing to add (uniform exit)
+  int ex;
+  (void)frexpf(mx, &ex);                         // mx < 2^ex
+  const float scale = ldexpf(1.0f, 40 - ex);     // |w*g| * scale < 2^40; 2^22 contributions stay below 2^62
+  const double inv_scale = (double)ldexpf(1.0f, ex - 40);
+  // job -> (level, chunk, slice)
+  uint32_t l = 0;
+  while (l + 1 < plan.n_levels && blockIdx.x >= plan.job_prefix[l + 1]) ++l;
+  const uint32_t rem = blockIdx.x - plan.job_prefix[l];
+  const uint32_t ns = plan.slices[l];
+  const uint32_t chunk = rem / ns, slice = rem % ns;
+  const uint32_t base = chunk * plan.chunk_rows;
+  const uint32_t size = lv.size[l];
+  const uint32_t rows = min(plan.chunk_rows, size - base);
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) bins[i] = 0ull;
+  __syncthreads();
+  const float s = lv.scale[l];
+  const uint32_t res = lv.resolution[l], hashed = lv.hashed[l];
+  const uint32_t p_lo = (uint32_t)(((uint64_t)P * slice) / ns), p_hi = (uint32_t)(((uint64_t)P * (slice + 1)) / ns);
+  const float2* __restrict__ dgl = dg_t + (size_t)l * P;
+  // Hashed levels: consecutive lanes = consecutive points (coalesced reads; the hash spreads neighbouring cells).
+  // Dense (coarse) levels: neighbouring samples of a ray sit in the same cell, so a coalesced walk puts ~64 lanes on a
+  // handful of LDS addresses per atomic; there each thread walks its own contiguous run instead (DNS_SCATTER_WALK=c
+  // forces the coalesced walk everywhere, for measurement).
+  const uint32_t n_it = (p_hi - p_lo + blockDim.x - 1) / blockDim.x;
+  const bool strided = !hashed && plan.strided_dense;
+  auto point_of = [&](uint32_t it) -> uint32_t {
+    return strided ? p_lo + threadIdx.x * n_it + it : p_lo + it * blockDim.x + threadIdx.x;
+  };
+  // software pipeline: the next point's 20 bytes are requested before this point's corners are processed, so the
+  // two L2 round trips per step hide under the integer / LDS work of the 4 waves per SIMD this kernel can hold
+  float2 gg_n = make_float2(0.f, 0.f);
+  float xn[3] = {0.f, 0.f, 0.f};
+  {
+    const uint32_t p = point_of(0);
+    if (n_it > 0 && p < p_hi) {
+      gg_n = dgl[p];
+      xn[0] = xin[(size_t)p * 3];
+      xn[1] = xin[(size_t)p * 3 + 1];
+      xn[2] = xin[(size_t)p * 3 + 2];
+    }
+  }
+  for (uint32_t it = 0; it < n_it; ++it) {
+    const float2 gg = gg_n;
+    const float xc[3] = {xn[0], xn[1], xn[2]};
+    const bool live = point_of(it) < p_hi;
+    gg_n = make_float2(0.f, 0.f);
+    if (it + 1 < n_it) {
+      const uint32_t pn = point_of(it + 1);
+      if (pn < p_hi) {
+        gg_n = dgl[pn];
+        xn[0] = xin[(size_t)pn * 3];
+        xn[1] = xin[(size_t)pn * 3 + 1];
+        xn[2] = xin[(size_t)pn * 3 + 2];
+      }
+    }
+    if (!live || (gg.x == 0.f && gg.y == 0.f)) continue;
+    const float g0 = gg.x * scale, g1 = gg.y * scale;                    // exact: power-of-two scale
+    float f[3];
+    uint32_t g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
+      const float fl = floorf(pos);
+      g[a] = (uint32_t)(int)fl;
+      f[a] = pos - fl;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t local = grid_row(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, size, hashed) - base;
+      if (local < rows) {
+        const float w = ((c & 1) ? f[0] : 1.0f - f[0]) * ((c & 2) ? f[1] : 1.0f - f[1]) * ((c & 4) ? f[2] : 1.0f - f[2]);
+        atomicAdd(bins + 2 * local, (unsigned long long)__float2ll_rn(w * g0));
+        atomicAdd(bins + 2 * local + 1, (unsigned long long)__float2ll_rn(w * g1));
+      }
+    }
+  }
+  __syncthreads();
+  float* out = d_table + 2 * ((size_t)lv.offset[l] + base);
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) {
+    const long long v = (long long)bins[i];
+    if (v != 0) atomicAdd(out + i, (float)((double)v * inv_scale));
+  }
+}
+
 __global__ __launch_bounds__(256) void hashgrid_indices_kernel(const float* __restrict__ xin, uint32_t P, GridLevels lv,
                                                                uint32_t* __restrict__ rows) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,7 +435,7 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
 
 extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
                               const DnsGridMeta* meta, const float* d_pe, uint32_t ld_dpe, const float* d_grid,
-                              uint32_t ld_dgrid, float* d_table, float* d_x, void* stream) {
+                              uint32_t ld_dgrid, float* d_table, float* d_x, float* ws, void* stream) {
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
   GridLevels lv = {};
@@ -286,9 +445,61 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     lv = to_levels(meta);
   }
   if (d_pe) DNS_REQUIRE(n_bins >= 1 && n_bins <= 64 && ld_dpe >= 3 * n_bins, "dns_encode_bwd: n_bins %u / ld %u", n_bins, ld_dpe);
+  hipStream_t st = (hipStream_t)stream;
   const uint32_t blocks = (P + 255) / 256;
-  hipLaunchKernelGGL(encode_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, make_bound(bound),
-                     bound ? 1 : 0, P, n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid, d_table, d_x);
+  // table gradient: LDS-binned scatter unless the table is huge (then contention is low and per-corner atomics
+  // avoid re-reading the points once per chunk) or the caller forces a path with DNS_SCATTER={binned,atomic}
+  static const char* force = getenv("DNS_SCATTER");
+  bool binned = d_table && d_grid && ws && meta->log2_hashmap_size <= 18 && meta->n_levels <= 16;
+  if (force && force[0] == 'a') binned = false;
+  if (force && force[0] == 'b') binned = d_table && d_grid && ws;
+  float* d_table_direct = binned ? nullptr : d_table;
+  if (d_x || d_table_direct) {
+    hipLaunchKernelGGL(encode_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, make_bound(bound), bound ? 1 : 0, P, n_bins,
+                       (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid, d_table_direct, d_x);
+  }
+  if (binned) {
+    static const char* ns_env = getenv("DNS_SCATTER_SLICES");
+    BinPlan plan;
+    plan.n_levels = lv.n_levels;
+    plan.chunk_rows = 8192;
+    static const char* walk = getenv("DNS_SCATTER_WALK");
+    plan.strided_dense = (walk && walk[0] == 'c') ? 0u : 1u;
+    uint32_t total_chunks = 0, chunk_of[DNS_MAX_LEVELS];
+    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+      chunk_of[l] = (lv.size[l] + plan.chunk_rows - 1) / plan.chunk_rows;
+      total_chunks += chunk_of[l];
+    }
+    uint32_t ns = ns_env ? (uint32_t)atoi(ns_env) : (512u + total_chunks - 1) / total_chunks;
+    if (ns < 1) ns = 1;
+    const uint32_t max_ns = (P + 1023) / 1024;                 // at least ~one point per thread
+    if (ns > max_ns) ns = max_ns ? max_ns : 1;
+    uint32_t jobs = 0;
+    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+      plan.chunks[l] = chunk_of[l];
+      // dense (coarse) levels: every corner of every point lands in the chunk -> ~4x the work per point
+      uint32_t nsl = lv.hashed[l] ? ns : ns * (chunk_of[l] == 1 ? 4u : 2u);
+      if (nsl > max_ns) nsl = max_ns ? max_ns : 1;
+      plan.slices[l] = nsl;
+      plan.job_prefix[l] = jobs;
+      jobs += chunk_of[l] * nsl;
+    }
+    for (uint32_t l = lv.n_levels; l <= DNS_MAX_LEVELS; ++l) plan.job_prefix[l] = jobs;
+    const size_t lds_bytes = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr_set = true;
+    }
+    uint32_t* gmax = (uint32_t*)(ws + (size_t)P * lv.n_levels * 2);
+    if (hipMemsetAsync(gmax, 0, sizeof(uint32_t), st) != hipSuccess) {
+      set_error("dns_encode_bwd: memset failed");
+      return DNS_E_LAUNCH;
+    }
+    DNS_REQUIRE(lv.n_levels <= 16, "dns_encode_bwd: binned scatter supports <= 16 levels");
+    hipLaunchKernelGGL(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
+    hipLaunchKernelGGL(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);
+  }
   return check_launch("dns_encode_bwd");
 }
 
@@ -298,4 +509,8 @@ extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMet
   hipLaunchKernelGGL(hashgrid_indices_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, P,
                      to_levels(meta), rows);
   return check_launch("dns_hashgrid_indices");
+}
+
+extern "C" uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta) {
+  return meta ? (uint64_t)P * meta->n_levels * 2 + 2 : 0;   // level-major d_grid copy + max|d_grid| word
 }

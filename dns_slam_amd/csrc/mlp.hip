@@ -94,25 +94,43 @@ __host__ __device__ inline MlpShape make_shape(uint32_t n_in, uint32_t n_out) {
 }
 
 // ---- layer 0: acc[t] = W_in[t-th 32 rows] * x  (x streamed from global as float4, split halves) ----
+// The lane's half row (<= 64 floats) is fetched as two groups of eight 16-byte loads, the second group issued
+// before the first group's MFMAs, so the row's memory latency is paid once, under matrix work.
 template <int NT>
 __device__ __forceinline__ void layer_in(const float* __restrict__ xrow, bool valid, uint32_t khalf,
                                          const float* __restrict__ img, uint32_t lane, f32x16 (&acc)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = zero16();
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xrow);
-  const uint32_t n4 = khalf >> 2;
-#pragma unroll 2
-  for (uint32_t q = 0; q < n4; ++q) {
-    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) xv = x4[q];
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  const uint32_t n4 = khalf >> 2;   // <= 16
+  float4 xa[8], xb[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t s = q * 4 + e;
+  for (int j = 0; j < 8; ++j) {
+    xa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && (uint32_t)j < n4) xa[j] = x4[j];
+  }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float a = img[(t * khalf + s) * 64u + lane];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[e], acc[t], 0, 0, 0);
+  for (int j = 0; j < 8; ++j) {
+    xb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && (uint32_t)(8 + j) < n4) xb[j] = x4[8 + j];
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t q = half * 8 + j;
+      if (q < n4) {
+        const float4 xv = half ? xb[j] : xa[j];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t s = q * 4 + e;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float a = img[(t * khalf + s) * 64u + lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[e], acc[t], 0, 0, 0);
+          }
+        }
       }
     }
   }
@@ -352,13 +370,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const float* __restri
     {
       const float* dyrow = dy + (size_t)(valid ? row : 0) * lddy;
       const float* img = lds + L::img_outT(sh.n_in);
-      for (uint32_t s = 0; s < ko2; ++s) {
-        const uint32_t k = h * ko2 + s;
-        const float b = (valid && k < sh.n_out) ? dyrow[k] : 0.f;
+      float dyv[32];                           // ko2 <= 32: every load of the lane's half row in flight at once
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float a = img[(t * ko2 + s) * 64u + lane];
-          dl[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dl[t], 0, 0, 0);
+      for (int s = 0; s < 32; ++s) {
+        const uint32_t k = h * ko2 + s;
+        dyv[s] = (valid && (uint32_t)s < ko2 && k < sh.n_out) ? dyrow[k] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        if ((uint32_t)s < ko2) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float a = img[(t * ko2 + s) * 64u + lane];
+            dl[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dyv[s], dl[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -441,9 +466,58 @@ struct GemmTnArgs {
   uint32_t tiles_per_block;
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+// Stage 64 rows x Wp columns (Wp = 32..128, multiple of 32) of a row-major matrix into LDS.  4 threads per row,
+// each owning Wp/4 consecutive columns; every global load of the thread is issued before the first LDS store so
+// the (up to 8) 16-byte loads overlap instead of paying one memory latency each.
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, uint32_t Wp, const float* __restrict__ src,
+                                           uint32_t ld, const int32_t* __restrict__ index, uint32_t W, uint32_t p0,
+                                           uint32_t n_slots) {
+  const uint32_t r = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  const uint32_t cw = Wp >> 2;               // columns per thread: 8, 16, 24 or 32
+  const uint32_t c0 = q * cw;
+  const uint32_t slot = p0 + r;
+  int row = -1;
+  if (slot < n_slots) row = index ? index[slot] : (int)slot;
+  const float* sp = src + (size_t)(row >= 0 ? row : 0) * ld;
+  const bool vec = ((ld & 3u) == 0) && ((((uintptr_t)src) & 15u) == 0);
+  float4 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t c = c0 + 4 * j;
+    if ((uint32_t)(4 * j) < cw && row >= 0) {
+      if (vec && c + 3 < W) {
+        v[j] = *reinterpret_cast<const float4*>(sp + c);
+      } else {
+        if (c < W) v[j].x = sp[c];
+        if (c + 1 < W) v[j].y = sp[c + 1];
+        if (c + 2 < W) v[j].z = sp[c + 2];
+        if (c + 3 < W) v[j].w = sp[c + 3];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if ((uint32_t)(4 * j) < cw) *reinterpret_cast<float4*>(dst + r * Wp + c0 + 4 * j) = v[j];
+}
+
+struct GemmTnBatch {
+  GemmTnArgs g[3];
+};
+
+// LDS staging: the workgroup loads a 64-slot sub-tile of A [64 x M] and B [64 x N] once (coalesced, through the
+// optional slot->row index) and all waves read their MFMA operands from it -- lane (i,h) of step s reads
+// row 2s+h, column tile*32+i: two 128-byte row segments per ds_read_b32, conflict-free for any row stride.
+// blockIdx.y selects one of up to three GEMMs (dW_in, dW_hidden, dW_out of one network) sharing the launch.
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GemmTnArgs& g = batch.g[blockIdx.y];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t MT = (g.M + 31u) / 32u, NT = (g.N + 31u) / 32u;
+  const uint32_t M = g.M, N = g.N;
+  const uint32_t MT = (M + 31u) / 32u, NT = (N + 31u) / 32u;
+  const uint32_t Mp = MT * 32u, Np = NT * 32u;      // LDS row strides (padded columns are zero-filled)
+  float* la = lds;
+  float* lb = lds + 64u * Mp;
   const uint32_t ntiles = MT * NT;
   const uint32_t n_btiles = (g.n_slots + 127u) / 128u;
   const uint32_t bt0 = blockIdx.x * g.tiles_per_block;
@@ -452,7 +526,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   f32x16 acc[2];
   acc[0] = zero16();
   acc[1] = zero16();
-  uint32_t tile_id[2] = {wave, wave + 4u};
+  const uint32_t tile_id[2] = {wave, wave + 4u};
   int cur_group = -2;
   auto flush = [&](int grp) {
     if (grp < 0) return;
@@ -465,7 +539,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const uint32_t row = mt * 32 + acc_row(r, h);
-          if (row < g.M && col < g.N) atomicAdd(C + (size_t)row * g.ldc + col, acc[t][r]);
+          if (row < M && col < N) atomicAdd(C + (size_t)row * g.ldc + col, acc[t][r]);
         }
       }
       acc[t] = zero16();
@@ -478,23 +552,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
       cur_group = grp;
     }
     if (grp < 0) continue;
-    const uint32_t p0 = bt * 128u;
-#pragma unroll 4
-    for (uint32_t s = 0; s < 64u; ++s) {
-      const uint32_t slot = p0 + 2 * s + h;
-      int ra = -1, rb = -1;
-      if (slot < g.n_slots) {
-        ra = g.a_index ? g.a_index[slot] : (int)slot;
-        rb = g.b_index ? g.b_index[slot] : (int)slot;
-      }
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+      const uint32_t p0 = bt * 128u + sub * 64u;
+      if (p0 >= g.n_slots) break;
+      __syncthreads();
+      // stage A and B sub-tiles (zero beyond the matrix / for padding slots); all loads of a thread in flight
+      stage_rows(la, Mp, g.A, g.lda, g.a_index, M, p0, g.n_slots);
+      stage_rows(lb, Np, g.B, g.ldb, g.b_index, N, p0, g.n_slots);
+      __syncthreads();
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (tile_id[t] < ntiles) {
           const uint32_t mt = tile_id[t] / NT, nt = tile_id[t] % NT;
-          const uint32_t ca = mt * 32 + i, cb = nt * 32 + i;
-          const float a = (ra >= 0 && ca < g.M) ? g.A[(size_t)ra * g.lda + ca] : 0.f;
-          const float b = (rb >= 0 && cb < g.N) ? g.B[(size_t)rb * g.ldb + cb] : 0.f;
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+          const float* pa = la + h * Mp + mt * 32 + i;
+          const float* pb = lb + h * Np + nt * 32 + i;
+#pragma unroll 8
+          for (uint32_t st = 0; st < 32u; ++st)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * st * Mp], pb[2 * st * Np], acc[t], 0, 0, 0);
         }
       }
     }
@@ -593,27 +667,28 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
   float* wsD1 = ws + SN;
   float* wsH2 = ws + 2 * SN;
   float* wsD2 = ws + 3 * SN;
-  GemmTnArgs g;
-  g.n_slots = n_slots;
-  g.tile_group = tile_group;
-  g.tiles_per_block = tpb;
-  g.c_stride = param_stride;
-  // dW_in [NN x n_in]
-  g.A = wsD1; g.lda = NNr; g.a_index = nullptr; g.M = NNr;
-  g.B = x; g.ldb = ldx; g.b_index = row_index; g.N = n_in;
-  g.C = d_params; g.ldc = n_in;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), 0, st, g);
+  GemmTnBatch batch;
+  int ng = 0;
+  auto add = [&](const float* A, uint32_t lda, const int32_t* ai, uint32_t M, const float* B, uint32_t ldb,
+                 const int32_t* bi, uint32_t N, float* Cp, uint32_t ldc) {
+    GemmTnArgs& g = batch.g[ng++];
+    g.A = A; g.lda = lda; g.a_index = ai; g.M = M;
+    g.B = B; g.ldb = ldb; g.b_index = bi; g.N = N;
+    g.C = Cp; g.ldc = ldc; g.c_stride = param_stride;
+    g.n_slots = n_slots; g.tile_group = tile_group; g.tiles_per_block = tpb;
+  };
+  // dW_in [NN x n_in] = dH1^T X ; dW_h [NN x NN] = dH2^T H1 ; dW_out [n_out x NN] = dY^T H_last
+  add(wsD1, NNr, nullptr, NNr, x, ldx, row_index, n_in, d_params, n_in);
   float* dwo = d_params + (size_t)NNr * n_in;
   if (n_hidden_layers == 2) {
-    g.A = wsD2; g.lda = NNr; g.a_index = nullptr; g.M = NNr;
-    g.B = wsH1; g.ldb = NNr; g.b_index = nullptr; g.N = NNr;
-    g.C = dwo; g.ldc = NNr;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), 0, st, g);
+    add(wsD2, NNr, nullptr, NNr, wsH1, NNr, nullptr, NNr, dwo, NNr);
     dwo += (size_t)NNr * NNr;
   }
-  g.A = dy; g.lda = lddy; g.a_index = row_index; g.M = n_out;
-  g.B = (n_hidden_layers == 2) ? wsH2 : wsH1; g.ldb = NNr; g.b_index = nullptr; g.N = NNr;
-  g.C = dwo; g.ldc = NNr;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), 0, st, g);
+  add(dy, lddy, row_index, n_out, (n_hidden_layers == 2) ? wsH2 : wsH1, NNr, nullptr, NNr, dwo, NNr);
+  for (int k = ng; k < 3; ++k) batch.g[k] = batch.g[0];
+  const uint32_t max_cols = ((n_in + 31u) / 32u) * 32u + NNr > 2 * NNr ? ((n_in + 31u) / 32u) * 32u + NNr : 2 * NNr;
+  const uint32_t out_cols = ((n_out + 31u) / 32u) * 32u + NNr;
+  const size_t gemm_lds = (size_t)64 * (max_cols > out_cols ? max_cols : out_cols) * sizeof(float);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks, ng), dim3(256), gemm_lds, st, batch);
   return check_launch("dns_mlp_bwd(weights)");
 }

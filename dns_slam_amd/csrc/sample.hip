@@ -234,36 +234,43 @@ __global__ __launch_bounds__(256) void sample_along_rays_kernel(const float* __r
   }
 }
 
-// d_pts [n,S,3] (+ optional direct d_rays_o / d_rays_d) -> per-frame sums of dL/dR (9) and dL/dT (3)
+// d_pts [n,S,3] (+ optional direct d_rays_o / d_rays_d) -> per-frame sums of dL/dR (9) and dL/dT (3).
+// grid = (ceil(npf/64), n_frames): a workgroup owns 64 rays of ONE frame (16 per wave, a wave reads a ray's
+// d_pts row coalesced), reduces in registers + LDS and issues 12 atomics.
 __global__ __launch_bounds__(256) void raygen_bwd_reduce_kernel(const int64_t* __restrict__ pix_idx, Cam cam, int H0, int W0,
                                                                 int wwin, int n_frames, int npf, int S,
                                                                 const float* __restrict__ z, const float* __restrict__ d_pts,
                                                                 const float* __restrict__ d_ro, const float* __restrict__ d_rd,
                                                                 float* __restrict__ ws) {
+  __shared__ float part[4][12];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * 4 + wave;
-  if (n >= n_frames * npf) return;
-  const int f = n / npf;
-  float go[3] = {0.f, 0.f, 0.f}, gdv[3] = {0.f, 0.f, 0.f};
-  if (d_pts) {
-    for (int s = lane; s < S; s += 64) {
-      const float zv = z[(size_t)n * S + s];
-      const float* g = d_pts + ((size_t)n * S + s) * 3;
+  const int f = blockIdx.y;
+  float acc[12];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        go[a] += g[a];
-        gdv[a] += g[a] * zv;
+  for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    const int r = blockIdx.x * 64 + wave * 16 + i;
+    if (r >= npf) break;
+    const int n = f * npf + r;
+    float go[3] = {0.f, 0.f, 0.f}, gdv[3] = {0.f, 0.f, 0.f};
+    if (d_pts) {
+      for (int s = lane; s < S; s += 64) {
+        const float zv = z[(size_t)n * S + s];
+        const float* g = d_pts + ((size_t)n * S + s) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          go[a] += g[a];
+          gdv[a] += g[a] * zv;
+        }
       }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          go[a] += __shfl_xor(go[a], off);
+          gdv[a] += __shfl_xor(gdv[a], off);
+        }
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        go[a] += __shfl_xor(go[a], off);
-        gdv[a] += __shfl_xor(gdv[a], off);
-      }
-  }
-  if (lane == 0) {
     if (d_ro)
       for (int a = 0; a < 3; ++a) go[a] += d_ro[(size_t)n * 3 + a];
     if (d_rd)
@@ -271,11 +278,20 @@ __global__ __launch_bounds__(256) void raygen_bwd_reduce_kernel(const int64_t* _
     int row, col;
     float dir[3];
     pixel_dir(pix_idx[n], H0, W0, wwin, cam, row, col, dir);
-    float* w = ws + 12 * f;
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
-      for (int b = 0; b < 3; ++b) atomicAdd(w + 3 * a + b, gdv[a] * dir[b]);  // dL/dR[a][b] = sum dL/dd[a] * dir[b]
-      atomicAdd(w + 9 + a, go[a]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[3 * a + b] += gdv[a] * dir[b];  // dL/dR[a][b] = sum dL/dd[a] * dir[b]
+      acc[9 + a] += go[a];
     }
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int e = 0; e < 12; ++e) part[wave][e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    atomicAdd(ws + 12 * f + threadIdx.x, v);
   }
 }
 
@@ -393,7 +409,7 @@ extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const d
     set_error("dns_raygen_bwd: memset failed");
     return DNS_E_LAUNCH;
   }
-  hipLaunchKernelGGL(raygen_bwd_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
+  hipLaunchKernelGGL(raygen_bwd_reduce_kernel, dim3((n_per_frame + 63) / 64, n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
                      n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);
   hipLaunchKernelGGL(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
   return check_launch("dns_raygen_bwd");

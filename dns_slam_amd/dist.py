@@ -3,12 +3,11 @@ replicated, every rank renders its own slice of the ray batch, ONE flat all-redu
 iteration (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" on CPU for tests).
 
 The reference has no live distributed path (its NCCL helpers utils/common.py:79-162 are dead code); this is the
-north_star's addition.  Exactness w.r.t. one GPU rendering the union batch:
-  * plain means over rays / points (photometric, CE, latent, fs/opacity): every rank holds the same number of rays,
-    so the AVERAGE of per-rank gradients is the gradient of the global mean;
-  * masked means (depth loss over d > 0): the per-rank term is rescaled by W * count_r / sum(count) BEFORE backward
-    (``global_mean_scale``), one tiny all-reduce of the counts, no host sync;
-  * the fs/opacity branch flag (utils/common.py:794) is evaluated on the global counts (``global_any``).
+north_star's addition.  Exactness w.r.t. one GPU rendering the union batch: the fused loss kernel (csrc/losses.hip) first produces the 16
+numerators / counts of the rank's rays; ``allreduce_sums`` makes them global BEFORE they are normalised, so every
+masked mean (depth over d > 0, rays inside the box) uses the global denominator and the fs/opacity branch flag
+(utils/common.py:794) is evaluated on the global counts.  Each rank then back-propagates local numerators over
+global denominators and the gradients are SUMMED; the smoothness lattice, identical on every rank, is weighted 1/W.
 Bucket: all gradients are flattened into one fp32 buffer -- 6.8 MB (T=2^16) .. 59 MB (T=2^20) + <1 MB of MLPs
 + 7 floats per frame -- so the collective is one large message; xGMI is point-to-point (7 links x ~153 GB/s), a
 ring all-reduce of M bytes moves 2*(7/8)*M over each link: 6.8 MB -> ~80 us, 59 MB -> ~0.7 ms.
@@ -46,10 +45,17 @@ class DistCtx:
         dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
         return f
 
+    def allreduce_sums(self, sums: torch.Tensor) -> None:
+        """In-place SUM of the fused loss kernel's numerators / counts (16 floats): every rank then normalises by the
+        GLOBAL denominators and evaluates the fs/opacity branch flag on the GLOBAL counts."""
+        if self.enabled:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+
     # ---- gradient exchange ------------------------------------------------------------------
     def allreduce_grads(self, params: Iterable[torch.Tensor]) -> None:
-        """Average the gradients of ``params`` over the ranks with ONE all-reduce of a flat fp32 bucket.
-        Parameters without a gradient on this rank (e.g. a frozen pose) contribute zeros."""
+        """SUM the gradients of ``params`` over the ranks with ONE all-reduce of a flat fp32 bucket.  Each rank's loss
+        is (local numerators) / (global denominators), so the sum of the per-rank gradients IS the gradient of the loss
+        of the union batch.  Parameters without a gradient on this rank (e.g. a frozen pose) contribute zeros."""
         if not self.enabled:
             return
         ps: List[torch.Tensor] = [p for p in params if p.requires_grad]
@@ -63,7 +69,6 @@ class DistCtx:
                 flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
             o += p.numel()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world_size)
         o = 0
         for p in ps:
             g = flat[o:o + p.numel()].view_as(p)

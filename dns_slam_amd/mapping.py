@@ -109,6 +109,8 @@ class Mapper:
         self.label_layout = label_layout
         self.is_BA = True
         self.dist = None                                 # dns_slam_amd.dist.DistCtx for ray-batch data parallelism
+        self.static_shapes = False                       # True: sync-free iteration (hipGraph-capturable)
+        self.fused_losses = True                         # one HIP loss pass instead of ~60 torch launches
         net_cfg = decoder.coarse_fn.decoder.network_config
         self.fine_decoders = FineDecoderPool(self.pe_dim + self.grid_dim, self.hidden_dim + 1, net_cfg, device=device)
         self.exist_decoders: Dict[int, int] = {}
@@ -123,10 +125,7 @@ class Mapper:
         mask = gt_depth > 0
         w = mask.float()
         cnt = w.sum()
-        loss = (torch.abs(gt_depth - pred_depth) * w).sum() / cnt          # == mean over d>0, no host sync
-        if self.dist is not None and self.dist.enabled:
-            loss = loss * self.dist.global_mean_scale(cnt)                  # masked mean over the GLOBAL batch
-        return loss
+        return (torch.abs(gt_depth - pred_depth) * w).sum() / cnt          # == mean over d>0, no host sync
 
     def compute_label_loss(self, gt_label, pred_logits):
         return F.cross_entropy(pred_logits, gt_label)
@@ -136,25 +135,24 @@ class Mapper:
 
     # ------------------------------------------------------------------ slams/mapping.py:129-159
     def smoothness(self, sample_points=64, voxel_size=0.1, margin=0.05, u_offset=None, u_jitter=None):
-        bound = self.bound
-        volume = bound[:, 1] - bound[:, 0]
-        grid_size = (sample_points - 1) * voxel_size
-        offset_max = bound[:, 1] - bound[:, 0] - grid_size - 2 * margin
-        if u_offset is None:
-            u_offset = torch.rand(3)
-        if u_jitter is None:
-            u_jitter = torch.rand((1, 1, 1, 3))
-        offset = u_offset.to(offset_max) * offset_max + margin
         n = sample_points - 1
-        key = (n, str(self.device))
+        key = (n, voxel_size, margin, str(self.device))
         if getattr(self, "_lattice_key", None) != key:
+            bound = self.bound
+            grid_size = (sample_points - 1) * voxel_size
+            self._offset_max = (bound[:, 1] - bound[:, 0] - grid_size - 2 * margin).to(self.device)     # float64
             ar = torch.arange(0, n, dtype=torch.long)
             gx, gy, gz = torch.meshgrid(ar, ar, ar, indexing="ij")
             self._lattice = torch.stack([gx, gy, gz], dim=-1).to(torch.float64).to(self.device)
             self._lattice_key = key
+        if u_offset is None:
+            u_offset = torch.rand(3, device=self.device) if self.static_shapes else torch.rand(3)
+        if u_jitter is None:
+            u_jitter = torch.rand((1, 1, 1, 3), device=self.device) if self.static_shapes else torch.rand((1, 1, 1, 3))
         # reference: float64 through `volume`; (coords + jitter) * voxel + b0 + offset, then normalise by the bound
         bd = self.bound_dev
-        pts = (self._lattice + u_jitter.to(torch.float64).to(self.device)) * voxel_size + bd[:, 0] + offset.to(self.device)
+        offset = u_offset.to(self.device).to(torch.float64) * self._offset_max + margin
+        pts = (self._lattice + u_jitter.to(self.device).to(torch.float64)) * voxel_size + bd[:, 0] + offset
         pts = (pts - bd[:, 0]) / (bd[:, 1] - bd[:, 0])
         shp = pts.shape
         pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
@@ -187,7 +185,7 @@ class Mapper:
         return new_list
 
     # ------------------------------------------------------------------ slams/mapping.py:438-468
-    def set_optimizer(self, target_frames):
+    def set_optimizer(self, target_frames, capturable=False):
         net_para_list = list(self.decoder.parameters())
         net_para_list += self.fine_decoders.parameters_for(target_frames["label_dict"])
         quad_list, T_list = [], []
@@ -203,7 +201,7 @@ class Mapper:
         net_para_list = [p for p in net_para_list if p.numel() > 0]
         optimizer = torch.optim.Adam([{"params": net_para_list, "lr": 0},
                                       {"params": quad_list, "lr": 0},
-                                      {"params": T_list, "lr": 0}])
+                                      {"params": T_list, "lr": 0}], capturable=capturable)
         return optimizer, quad_list, T_list
 
     # ------------------------------------------------------------------ pixel picking (a1, a2)
@@ -250,8 +248,19 @@ class Mapper:
         return torch.cat(out)
 
     def draw_jitter(self):
-        """The two CPU draws of sample_along_rays (utils/common.py:571-574,582), forced 0.5 included."""
+        """The two draws of sample_along_rays (utils/common.py:571-574,582), forced 0.5 included.  Reference: CPU
+        generator then .to(device); with ``static_shapes`` they come from the device generator (no host work, so
+        the whole iteration can be captured in a hipGraph) and the forced 0.5 is a device-side select."""
         ns = self.n_surface_ray
+        if self.static_shapes:
+            if getattr(self, "_force_mask", None) is None or self._force_mask.numel() != ns:
+                m = torch.zeros(ns, dtype=torch.bool)
+                m[ns // 2 + 1] = True
+                self._force_mask = m.to(self.device)
+                self._half = torch.full((ns,), 0.5, device=self.device)
+            t = torch.rand(ns, device=self.device)
+            t = torch.where(self._force_mask & ~(t == 0.5).any(), self._half, t)
+            return t, torch.rand(ns, device=self.device)
         t = torch.rand(ns)
         if not torch.any(t == 0.5):
             t[ns // 2 + 1] = 0.5
@@ -296,6 +305,12 @@ class Mapper:
             back = (z > d * 1.05).float()
             trunc = (1.0 - front) * (1.0 - back) * (d > 0.0).float()        # :553-556
             code = features * trunc[..., None]
+        if self.static_shapes:
+            # no compaction (and no host sync): rays leaving the box stay in the batch with valid = 0 and are
+            # excluded from every loss mean -- same values as dropping them (slams/mapping.py:576-586) for the
+            # per_ray label layout; the reference_tiled layout (D1) depends on the post-drop N and needs the sync path
+            return {"gt_color": gt_color, "gt_depth": gt_depth, "gt_label": gt_label, "rays_o": rays_o, "rays_d": rays_d,
+                    "pts": pts, "z_vals": z, "features": code, "valid": inside}
         mask = inside.bool()
         if bool(mask.all()):                                                # the reference syncs here too (:576)
             sel = lambda t: t
@@ -341,19 +356,33 @@ class Mapper:
     # ------------------------------------------------------------------ slams/mapping.py:887-907
     def iteration_loss(self, samples, lambda_lt=10.0, smooth=True, u_offset=None, u_jitter=None, strict=False):
         pred_color, pred_depth, _, pred_logits, fine_latents, coarse_latents = self.renderer(samples, strict=strict)
-        d_loss = self.compute_depth_loss(samples["gt_depth"], pred_depth)
-        p_loss = self.compute_photometric_loss(samples["gt_color"], pred_color)
-        l_loss = self.compute_label_loss(samples["gt_label"], pred_logits)
-        lt_loss = self.compute_latent_loss(coarse_latents, fine_latents)
-        fs_loss, opacity_loss = get_opacity_loss(samples["z_vals"], samples["gt_depth"], fine_latents[..., -1],
-                                                 self.cfg["training"]["opacity_sigma"])
-        loss = self.lambda_p * p_loss + self.lambda_d * d_loss + self.lambda_l * l_loss + lambda_lt * lt_loss + \
-            self.lambda_fs * fs_loss + self.lambda_opacity * opacity_loss
-        terms = {"p_loss": p_loss, "d_loss": d_loss, "l_loss": l_loss, "lt_loss": lt_loss, "fs_loss": fs_loss,
-                 "opacity_loss": opacity_loss}
+        tr = self.cfg["training"]
+        world = self.dist.world_size if (self.dist is not None and self.dist.enabled) else 1
+        if self.fused_losses:
+            lam = (self.lambda_p, self.lambda_d, self.lambda_l, lambda_lt, self.lambda_fs, self.lambda_opacity,
+                   tr["opacity_sigma"], 0.05)          # opacity_sigma lands in `truncation`, sigma stays 0.05 (D5)
+            red = self.dist.allreduce_sums if world > 1 else None
+            loss, t = ops.mapping_losses(pred_color, pred_depth, pred_logits, fine_latents, coarse_latents,
+                                         samples["gt_color"], samples["gt_depth"], samples["gt_label"], samples["z_vals"],
+                                         lam, valid=samples.get("valid"), reduce_sums=red)
+            terms = {"p_loss": t[0], "d_loss": t[1], "l_loss": t[2], "lt_loss": t[3], "fs_loss": t[4], "opacity_loss": t[5]}
+        else:
+            if samples.get("valid") is not None or world > 1:
+                raise ValueError("the unfused loss path supports neither static_shapes nor multi-GPU")
+            d_loss = self.compute_depth_loss(samples["gt_depth"], pred_depth)
+            p_loss = self.compute_photometric_loss(samples["gt_color"], pred_color)
+            l_loss = self.compute_label_loss(samples["gt_label"], pred_logits)
+            lt_loss = self.compute_latent_loss(coarse_latents, fine_latents)
+            fs_loss, opacity_loss = get_opacity_loss(samples["z_vals"], samples["gt_depth"], fine_latents[..., -1],
+                                                     tr["opacity_sigma"])
+            loss = self.lambda_p * p_loss + self.lambda_d * d_loss + self.lambda_l * l_loss + lambda_lt * lt_loss + \
+                self.lambda_fs * fs_loss + self.lambda_opacity * opacity_loss
+            terms = {"p_loss": p_loss, "d_loss": d_loss, "l_loss": l_loss, "lt_loss": lt_loss, "fs_loss": fs_loss,
+                     "opacity_loss": opacity_loss}
         if smooth:
-            smooth_loss = self.smoothness(sample_points=self.cfg["training"]["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
-            loss = loss + self.lambda_sm * smooth_loss
+            smooth_loss = self.smoothness(sample_points=tr["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
+            # multi-GPU: every rank evaluates the SAME lattice and gradients are SUMMED, so each contributes 1/W
+            loss = loss + (self.lambda_sm / world) * smooth_loss
             terms["smooth_loss"] = smooth_loss
         return loss, terms
 

@@ -24,7 +24,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._raw, name)
-        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_last_error", "dns_abi_version"):
+        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_last_error", "dns_abi_version"):
             return fn
 
         ui = self._UNITS_ARG.get(name)
@@ -149,9 +149,10 @@ class _EncodeFn(torch.autograd.Function):
         d_table = torch.zeros_like(table) if need_t else None
         d_pe = ptr(d_out) if ctx.pe_dim else None
         d_grid = C.c_void_p(d_out.data_ptr() + 4 * ctx.pe_dim) if ctx.g_dim else None
+        ws = torch.empty(P * ctx.g_dim + 2, device=x.device, dtype=torch.float32) if need_t else None
         check(lib.dns_encode_bwd(ptr(x), ctx.b6, P, ctx.n_bins, ptr(table) if ctx.g_dim else None,
                                  C.byref(ctx.meta.c) if ctx.g_dim else None, d_pe, ld, d_grid, ld,
-                                 ptr(d_table), ptr(d_x), stream_ptr()), "dns_encode_bwd")
+                                 ptr(d_table), ptr(d_x), ptr(ws), stream_ptr()), "dns_encode_bwd")
         return d_x, d_table, None, None, None, None, None
 
 
@@ -248,7 +249,7 @@ def group_slots(slot_of_point: torch.Tensor, n_groups: int, min_count: int = 2):
     n_slots = (P + 127) // 128 * 128 + 128 * n_groups
     key = torch.where(slot_of_point < 0, torch.full_like(slot_of_point, n_groups), slot_of_point)
     order = torch.argsort(key, stable=True)
-    counts = torch.bincount(key, minlength=n_groups + 1)[:n_groups]
+    counts = torch.zeros(n_groups + 1, device=dev, dtype=torch.int64).scatter_add_(0, key, torch.ones_like(key))[:n_groups]
     padded = (counts + 127) // 128 * 128
     pad_end = torch.cumsum(padded, 0)
     pad_start = pad_end - padded
@@ -393,3 +394,72 @@ def sample_along_rays(gt_depth, far_bb, t_uniform, t_surf, t_zero):
     check(lib.dns_sample_along_rays(ptr(gt_depth), ptr(far_bb), n, ptr(t_uniform), ptr(t_surf), ptr(t_zero), nu, ns,
                                     ptr(ws), ptr(z), stream_ptr()), "dns_sample_along_rays")
     return z
+
+
+# ----------------------------------------------------------------------------- fused losses
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_color, pred_depth, pred_var, pred_logits, fine, coarse, gt_color, gt_depth, gt_label, valid, z,
+                lambdas, tracker, reduce_sums):
+        require_cuda(pred_color, pred_depth, pred_var, pred_logits, fine, coarse, gt_color, gt_depth, gt_label, valid, z)
+        c = lambda t: None if t is None else t.contiguous()
+        pred_color, pred_depth, pred_var, pred_logits = c(pred_color), c(pred_depth), c(pred_var), c(pred_logits)
+        fine, coarse, gt_color, gt_depth, gt_label, z = c(fine), c(coarse), c(gt_color), c(gt_depth), c(gt_label), c(z)
+        N = pred_depth.shape[0]
+        Cn = 0 if pred_logits is None else pred_logits.shape[-1]
+        S = 1 if z is None else z.shape[1]
+        L = 1 if fine is None else fine.shape[-1]
+        dev = pred_depth.device
+        lam = (C.c_float * 8)(*[float(v) for v in lambdas])
+        sums = torch.empty(16, device=dev)
+        out = torch.empty(16, device=dev)
+        check(lib.dns_loss_sums(lam, N, S, Cn, L, int(tracker), ptr(pred_color), ptr(pred_depth), ptr(pred_var),
+                                ptr(pred_logits), ptr(gt_color), ptr(gt_depth), ptr(gt_label), ptr(valid), ptr(fine),
+                                ptr(coarse), ptr(z), ptr(sums), stream_ptr()), "dns_loss_sums")
+        if reduce_sums is not None:
+            reduce_sums(sums)                      # multi-GPU: global numerators / counts (dns_slam_amd.dist)
+        check(lib.dns_loss_finalize(lam, N, S, Cn, L, int(tracker), ptr(sums), ptr(out), stream_ptr()), "dns_loss_finalize")
+        ctx.save_for_backward(pred_color, pred_depth, pred_var, pred_logits, fine, coarse, gt_color, gt_depth, gt_label,
+                              valid, z, out)
+        ctx.misc = (lam, N, S, Cn, L, int(tracker))
+        total = out[6]
+        terms = out[:6]
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        (pred_color, pred_depth, pred_var, pred_logits, fine, coarse, gt_color, gt_depth, gt_label, valid, z,
+         out) = ctx.saved_tensors
+        lam, N, S, Cn, L, tracker = ctx.misc
+        dev = pred_depth.device
+        g = g_total.reshape(1).contiguous().float()
+        d_color = torch.empty_like(pred_color)
+        d_depth = torch.empty_like(pred_depth)
+        d_var = torch.empty_like(pred_var) if pred_var is not None else None
+        d_logits = torch.empty_like(pred_logits) if Cn else None
+        d_fine = torch.empty_like(fine) if fine is not None else None
+        d_coarse = torch.empty_like(coarse) if coarse is not None else None
+        check(lib.dns_loss_bwd(lam, N, S, Cn, L, tracker, ptr(out), ptr(g), ptr(pred_color), ptr(pred_depth), ptr(pred_var),
+                               ptr(pred_logits), ptr(gt_color), ptr(gt_depth), ptr(gt_label), ptr(valid), ptr(fine),
+                               ptr(coarse), ptr(z), ptr(d_color), ptr(d_depth), ptr(d_var), ptr(d_logits), ptr(d_fine),
+                               ptr(d_coarse), stream_ptr()), "dns_loss_bwd")
+        return (d_color, d_depth, d_var, d_logits, d_fine, d_coarse) + (None,) * 8
+
+
+def mapping_losses(pred_color, pred_depth, pred_logits, fine, coarse, gt_color, gt_depth, gt_label, z_vals, lambdas,
+                   valid=None, reduce_sums=None):
+    """The six ray-batch loss terms of one mapping iteration, fused (slams/mapping.py:887-907 minus smoothness).
+    lambdas = (lambda_p, lambda_d, lambda_l, lambda_lt, lambda_fs, lambda_opacity, truncation, sigma).
+    -> (weighted total [scalar, differentiable], terms [6] = p, d, l, lt, fs, opacity)."""
+    return _LossFn.apply(pred_color, pred_depth, None, pred_logits, fine, coarse, gt_color, gt_depth, gt_label, valid,
+                         z_vals, lambdas, False, reduce_sums)
+
+
+def tracking_losses(pred_color, pred_depth, pred_var, pred_logits, gt_color, gt_depth, gt_label, mask, lambdas):
+    """The three masked tracking losses, fused (slams/tracking.py:85-96, 326-329). mask: bool / uint8 [N]."""
+    valid = mask.to(torch.uint8).contiguous()
+    lam = tuple(lambdas) + (0.0,) * (8 - len(lambdas))
+    lam = (lam[0], lam[1], lam[2], 0.0, 0.0, 0.0, 0.0, 1.0)
+    return _LossFn.apply(pred_color, pred_depth, pred_var, pred_logits, None, None, gt_color, gt_depth, gt_label, valid,
+                         None, lam, True, None)

@@ -127,10 +127,9 @@ class Tracker:
             optimizer.zero_grad()
             samples = self.get_target_samples(frames, features=features, prep=prep)
             pred_color, pred_depth, pred_depth_var, pred_logits = self.renderer(samples)
-            p_loss = self.compute_photometric_loss(samples["gt_color"], pred_color, samples["mask"])
-            d_loss = self.compute_depth_loss(samples["gt_depth"], pred_depth, pred_depth_var, samples["mask"])
-            l_loss = self.compute_label_loss(samples["gt_label"], pred_logits, samples["mask"])
-            loss = self.lambda_p * p_loss + self.lambda_d * d_loss + self.lambda_l * l_loss
+            loss, _terms = ops.tracking_losses(pred_color, pred_depth, pred_depth_var, pred_logits, samples["gt_color"],
+                                               samples["gt_depth"], samples["gt_label"], samples["mask"],
+                                               (self.lambda_p, self.lambda_d, self.lambda_l))
             with torch.no_grad():                       # keep-best without the host sync of :331
                 better = loss < best_loss
                 best_loss = torch.where(better, loss.detach(), best_loss)

@@ -109,11 +109,13 @@ int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_
 
 /* Backward.  x [P,3] normalised coordinates.  d_pe / d_grid may be NULL.  d_table (+=) [total_rows,F]
  * (NULL = skip), d_x [P,3] (overwritten; NULL = skip) = dL/dx of the NORMALISED coordinate; if
- * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point). */
+ * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point).  ws: 8-byte aligned scratch of
+ * dns_encode_bwd_ws_floats(P, meta) floats for the LDS-binned table scatter (NULL = per-corner atomics). */
 int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins,
                    const float* table, const DnsGridMeta* meta,
                    const float* d_pe, uint32_t ld_dpe, const float* d_grid, uint32_t ld_dgrid,
-                   float* d_table, float* d_x, void* stream);
+                   float* d_table, float* d_x, float* ws, void* stream);
+uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta);
 
 /* Debug / parity: absolute table rows of the 8 corners of every level, [P, n_levels, 8] uint32. */
 int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, uint32_t* rows, void* stream);
@@ -149,6 +151,30 @@ int dns_composite_fwd(const float* raw, const float* z, const float* logits, uin
 int dns_composite_bwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C,
                       const float* d_depth, const float* d_var, const float* d_rgb, const float* d_weights,
                       const float* d_sem, float* d_raw, float* d_logits, void* stream);
+
+/* ---- fused loss reductions --------------------------------------------------------------------
+ * Mapper: photometric / depth / label / latent losses (slams/mapping.py:110-126) + get_opacity_loss
+ * (utils/common.py:769-802) and their weighted sum (mapping.py:906-907); tracker = 1: the three masked losses of
+ * slams/tracking.py:85-96 (depth term divided by sqrt(var + 1e-10)).
+ * lambdas [host, 8 floats] = lambda_p, lambda_d, lambda_l, lambda_lt, lambda_fs, lambda_opacity, truncation, sigma.
+ * Rays: pred_color [N,3], pred_depth [N], pred_var [N] (tracker), pred_logits [N,C], gt_color [N,3], gt_depth [N],
+ * gt_label [N] int64, valid [N] uint8 (NULL = all rays count).  Points (mapper): fine, coarse [N*S, L], z [N,S].
+ * Three calls: dns_loss_sums fills sums[16] (numerators and counts; multi-GPU callers all-reduce it here),
+ * dns_loss_finalize turns it into out[16] = {p, d, l, lt, fs, op, total, -, coefficients...},
+ * dns_loss_bwd writes d(total * g_total)/d(inputs): d_color, d_depth, d_var (tracker; may be NULL), d_logits,
+ * d_fine, d_coarse (overwritten). */
+int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
+                  const float* pred_color, const float* pred_depth, const float* pred_var, const float* pred_logits,
+                  const float* gt_color, const float* gt_depth, const int64_t* gt_label, const uint8_t* valid,
+                  const float* fine, const float* coarse, const float* z, float* sums, void* stream);
+int dns_loss_finalize(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
+                      const float* sums, float* out, void* stream);
+int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
+                 const float* out, const float* g_total, const float* pred_color, const float* pred_depth,
+                 const float* pred_var, const float* pred_logits, const float* gt_color, const float* gt_depth,
+                 const int64_t* gt_label, const uint8_t* valid, const float* fine, const float* coarse, const float* z,
+                 float* d_color, float* d_depth, float* d_var, float* d_logits, float* d_fine, float* d_coarse,
+                 void* stream);
 
 #ifdef __cplusplus
 }
