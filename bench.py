@@ -105,13 +105,37 @@ def capture(step, n_warm=3):
     return g.replay
 
 
+def host_cores():
+    """CPU threads this process may actually use: min(affinity, cgroup quota) -- os.cpu_count() reports the whole node."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
     """The oracle (PyTorch CPU fp32 restatement, oracle/) timed on this host: full mapping iterations of the SAME
     workload (sample -> render -> 7 losses -> backward), as many as fit the budget (>= 1)."""
     from oracle import slam_ref as sr
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import oracle_cfg_from
-    cores = os.cpu_count() or 1
+    cores = min(host_cores(), 32)
     torch.set_num_threads(cores)
     om = sr.OracleModel(oracle_cfg_from(cfg, 8), bound, fine_classes=frames["label_dict"])
     camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])

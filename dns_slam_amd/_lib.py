@@ -34,7 +34,7 @@ SIGNATURES = {
     "dns_last_error": (C.c_char_p, []),
     "dns_grid_meta_init": (C.c_int, [C.POINTER(DnsGridMeta), _U, _U, _U, _U, C.c_double]),
     "dns_raygen_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I,
-                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                    _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_sample_along_rays": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "dns_raygen_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_encode_fwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _P, _U, _P, _U, _P]),

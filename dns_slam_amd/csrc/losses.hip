@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void loss_ray_sums_kernel(LossCfg c, const flo
 
 __device__ __forceinline__ float sigmoid10f(float x) { return 1.0f / (1.0f + expf(-10.0f * x)); }
 
-// one thread per point: latent term over L channels + free-space / opacity on the LAST channel (D5)
+// Point pass, one thread per ELEMENT of the [P, L] latent arrays (L = 33 is not a vector width: a thread-per-point
+// walk reads 132-byte rows at a 132-byte lane stride; the flat walk is fully coalesced).  The thread that owns a
+// point's LAST channel also evaluates the free-space / opacity terms of that point (D5: last channel = "occ").
 __global__ __launch_bounds__(256) void loss_point_sums_kernel(LossCfg c, const float* __restrict__ fine,
                                                               const float* __restrict__ coarse,
                                                               const float* __restrict__ z,
@@ -98,33 +100,31 @@ __global__ __launch_bounds__(256) void loss_point_sums_kernel(LossCfg c, const f
                                                               const uint8_t* __restrict__ valid,
                                                               float* __restrict__ sums) {
   __shared__ float sh[4];
-  const uint32_t P = c.N * c.S;
+  const uint64_t E = (uint64_t)c.N * c.S * c.L;
   float slt = 0.f, sfs = 0.f, sop = 0.f, nfr = 0.f, nom = 0.f;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t p = (uint32_t)(e / c.L), k = (uint32_t)(e - (uint64_t)p * c.L);
     const uint32_t n = p / c.S;
     if (!ray_valid(valid, n)) continue;
-    const float* f = fine + (size_t)p * c.L;
-    const float* co = coarse + (size_t)p * c.L;
-    float a = 0.f;
-    for (uint32_t k = 0; k < c.L; ++k) {
-      const float e = co[k] - f[k];
-      a += e * e;
+    const float f = fine[e];
+    const float d0 = coarse[e] - f;
+    slt += d0 * d0;
+    if (k + 1 == c.L) {
+      const float d = gt_depth[n], zz = z[p];
+      const float occ = sigmoid10f(f);
+      const float front = zz < (d - c.truncation) ? 1.f : 0.f;
+      const float back = zz > (d + c.truncation) ? 1.f : 0.f;
+      const float dm = d > 0.f ? 1.f : 0.f;
+      const float om = (1.f - front) * (1.f - back) * dm;
+      const float a1 = occ * front * dm;
+      sfs += a1 * a1;
+      const float r = (zz - d) / c.sigma;
+      const float pseudo = 0.5f * expf(-0.5f * r * r);
+      const float a2 = occ * om - pseudo * om;
+      sop += a2 * a2;
+      nfr += front;
+      nom += om;
     }
-    slt += a;
-    const float d = gt_depth[n], zz = z[p];
-    const float occ = sigmoid10f(f[c.L - 1]);
-    const float front = zz < (d - c.truncation) ? 1.f : 0.f;
-    const float back = zz > (d + c.truncation) ? 1.f : 0.f;
-    const float dm = d > 0.f ? 1.f : 0.f;
-    const float om = (1.f - front) * (1.f - back) * dm;
-    const float a1 = occ * front * dm;
-    sfs += a1 * a1;
-    const float r = (zz - d) / c.sigma;
-    const float pseudo = 0.5f * expf(-0.5f * r * r);
-    const float a2 = occ * om - pseudo * om;
-    sop += a2 * a2;
-    nfr += front;
-    nom += om;
   }
   float t;
   t = block_sum(slt, sh); if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + S_LT, t);
@@ -217,40 +217,34 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
                                                              const float* __restrict__ gt_depth,
                                                              const uint8_t* __restrict__ valid, float* __restrict__ d_fine,
                                                              float* __restrict__ d_coarse) {
-  const uint32_t P = c.N * c.S;
+  const uint64_t E = (uint64_t)c.N * c.S * c.L;
   const float g = g_total[0];
   const float clt = g * out[O_CLT], cfs = g * out[O_CFS], cop = g * out[O_COP];
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t p = (uint32_t)(e / c.L), k = (uint32_t)(e - (uint64_t)p * c.L);
     const uint32_t n = p / c.S;
-    const float* f = fine + (size_t)p * c.L;
-    const float* co = coarse + (size_t)p * c.L;
-    float* df = d_fine + (size_t)p * c.L;
-    float* dc = d_coarse + (size_t)p * c.L;
-    if (!ray_valid(valid, n)) {
-      for (uint32_t k = 0; k < c.L; ++k) {
-        df[k] = 0.f;
-        dc[k] = 0.f;
+    float df = 0.f, dc = 0.f;
+    if (ray_valid(valid, n)) {
+      const float f = fine[e];
+      const float d0 = coarse[e] - f;
+      dc = clt * d0;
+      df = -clt * d0;
+      if (k + 1 == c.L) {
+        const float d = gt_depth[n], zz = z[p];
+        const float occ = sigmoid10f(f);
+        const float front = zz < (d - c.truncation) ? 1.f : 0.f;
+        const float back = zz > (d + c.truncation) ? 1.f : 0.f;
+        const float dm = d > 0.f ? 1.f : 0.f;
+        const float om = (1.f - front) * (1.f - back) * dm;
+        const float r = (zz - d) / c.sigma;
+        const float pseudo = 0.5f * expf(-0.5f * r * r);
+        // d/docc of cfs/2*(occ*front*dm)^2 + cop/2*(occ*om - pseudo*om)^2, then occ' = 10 occ (1 - occ)
+        const float docc = cfs * (occ * front * dm) * (front * dm) + cop * (occ * om - pseudo * om) * om;
+        df += docc * 10.f * occ * (1.f - occ);
       }
-      continue;
     }
-    float last = 0.f;
-    for (uint32_t k = 0; k < c.L; ++k) {
-      const float e = co[k] - f[k];
-      dc[k] = clt * e;
-      const float v = -clt * e;
-      if (k + 1 == c.L) last = v; else df[k] = v;
-    }
-    const float d = gt_depth[n], zz = z[p];
-    const float occ = sigmoid10f(f[c.L - 1]);
-    const float front = zz < (d - c.truncation) ? 1.f : 0.f;
-    const float back = zz > (d + c.truncation) ? 1.f : 0.f;
-    const float dm = d > 0.f ? 1.f : 0.f;
-    const float om = (1.f - front) * (1.f - back) * dm;
-    const float r = (zz - d) / c.sigma;
-    const float pseudo = 0.5f * expf(-0.5f * r * r);
-    // d/docc of cfs/2*(occ*front*dm)^2 + cop/2*(occ*om - pseudo*om)^2, then occ' = 10 occ (1 - occ)
-    const float docc = cfs * (occ * front * dm) * (front * dm) + cop * (occ * om - pseudo * om) * om;
-    df[c.L - 1] = last + docc * 10.f * occ * (1.f - occ);
+    d_fine[e] = df;
+    d_coarse[e] = dc;
   }
 }
 
@@ -287,8 +281,9 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
   hipLaunchKernelGGL(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
                      pred_logits, gt_color, gt_depth, gt_label, valid, sums);
   if (!tracker) {
-    const uint32_t P = N * S;
-    const uint32_t blocks = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
+    const uint64_t E = (uint64_t)N * S * L;
+    // few, fat workgroups: every workgroup ends in 5 atomics on the same 5 words (same-address atomics serialise)
+    const uint32_t blocks = (uint32_t)((E + 255) / 256 < 768 ? (E + 255) / 256 : 768);
     hipLaunchKernelGGL(loss_point_sums_kernel, dim3(blocks), dim3(256), 0, st, c, fine, coarse, z, gt_depth, valid, sums);
   }
   return check_launch("dns_loss_sums");
@@ -317,8 +312,8 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
   hipLaunchKernelGGL(loss_ray_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, out, g_total, pred_color, pred_depth,
                      pred_var, pred_logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var, d_logits);
   if (!tracker) {
-    const uint32_t P = N * S;
-    const uint32_t blocks = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
+    const uint64_t E = (uint64_t)N * S * L;
+    const uint32_t blocks = (uint32_t)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
     hipLaunchKernelGGL(loss_point_bwd_kernel, dim3(blocks), dim3(256), 0, st, c, out, g_total, fine, coarse, z, gt_depth,
                        valid, d_fine, d_coarse);
   }

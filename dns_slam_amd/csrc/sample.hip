@@ -340,7 +340,7 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
                                  const float* quat, const float* trans, const double* cam, const double* bound, int H,
                                  int W, int H0, int H1, int W0, int W1, int n_frames, int n_per_frame,
                                  const float* t_uniform, const float* t_surf, const float* t_zero, int n_uniform,
-                                 int n_surface, uint32_t* depth_max_ws, float* rays_o, float* rays_d, float* gt_color,
+                                 int n_surface, uint32_t* depth_max_ws, int depth_max_given, float* rays_o, float* rays_d, float* gt_color,
                                  float* gt_depth, int64_t* gt_label, uint8_t* inside, float* z, float* pts,
                                  void* stream) {
   DNS_REQUIRE(pix_idx && color && depth && label && quat && trans && cam && bound, "dns_raygen_sample: NULL input");
@@ -352,12 +352,14 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
   const int n = n_frames * n_per_frame;
   if (n <= 0) return DNS_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(depth_max_ws, 0, sizeof(uint32_t) * n_frames, st) != hipSuccess) {
-    set_error("dns_raygen_sample: memset failed");
-    return DNS_E_LAUNCH;
-  }
   const int wwin = W1 - W0;
-  hipLaunchKernelGGL(depth_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pix_idx, depth, H, W, H0, W0, wwin, n_frames, n_per_frame, depth_max_ws);
+  if (!depth_max_given) {
+    if (hipMemsetAsync(depth_max_ws, 0, sizeof(uint32_t) * n_frames, st) != hipSuccess) {
+      set_error("dns_raygen_sample: memset failed");
+      return DNS_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(depth_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pix_idx, depth, H, W, H0, W0, wwin, n_frames, n_per_frame, depth_max_ws);
+  }
   BoundD bd;
   for (int i = 0; i < 6; ++i) bd.b[i] = bound[i];
   const Cam c = make_cam(cam);

@@ -51,6 +51,11 @@ class DistCtx:
         if self.enabled:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
 
+    def allreduce_max(self, t: torch.Tensor) -> None:
+        """In-place MAX (the per-frame max sampled depth that sample_along_rays uses, utils/common.py:581,591)."""
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     # ---- gradient exchange ------------------------------------------------------------------
     def allreduce_grads(self, params: Iterable[torch.Tensor]) -> None:
         """SUM the gradients of ``params`` over the ranks with ONE all-reduce of a flat fp32 bucket.  Each rank's loss

@@ -293,8 +293,14 @@ class Mapper:
                                                cam, self.bound, window, npf, self.t_uniform, jitter[f][0], jitter[f][1]))
             res = [torch.cat([p[i] for p in parts], 0) for i in range(8)]
         else:
+            dmax = None
+            if self.dist is not None and self.dist.enabled:
+                # batch-global max(gt_depth) of sample_along_rays (utils/common.py:581,591): over ALL ranks' rays of a frame
+                dflat = prep["depth"].reshape(K, -1)
+                dmax = torch.gather(dflat, 1, pix_idx.reshape(K, npf)).amax(dim=1).clamp_min(0.0)
+                self.dist.allreduce_max(dmax)
             res = ops.raygen_sample(quat, trans, pix_idx, prep["color"], prep["depth"], prep["label"], cam, self.bound,
-                                    window, npf, self.t_uniform, jitter[0], jitter[1])
+                                    window, npf, self.t_uniform, jitter[0], jitter[1], depth_max=dmax)
         rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = res
         N, S = z.shape
         if features is None:

@@ -326,7 +326,8 @@ def composite(raw: torch.Tensor, z_vals: torch.Tensor, logits: Optional[torch.Te
 # ----------------------------------------------------------------------------- ray generation + sampling
 class _RaygenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, quat, trans, pix_idx, color, depth, label, cam, bound, window, npf, t_uniform, t_surf, t_zero):
+    def forward(ctx, quat, trans, pix_idx, color, depth, label, cam, bound, window, npf, t_uniform, t_surf, t_zero,
+                depth_max=None):
         require_cuda(quat, trans, pix_idx, color, depth, label, t_uniform, t_surf, t_zero)
         K, H, W = depth.shape
         H0, H1, W0, W1 = window
@@ -345,12 +346,16 @@ class _RaygenFn(torch.autograd.Function):
         inside = torch.empty(n, device=dev, dtype=torch.uint8)
         z = torch.empty(n, S, device=dev)
         pts = torch.empty(n, S, 3, device=dev)
-        ws = torch.empty(K, device=dev, dtype=torch.int32)
+        if depth_max is not None:                         # per-frame max sampled depth supplied (multi-GPU: global max)
+            ws = depth_max.detach().float().contiguous().view(torch.int32)
+        else:
+            ws = torch.empty(K, device=dev, dtype=torch.int32)
         camv = (C.c_double * 4)(*[float(v) for v in cam])
         b6 = _bound6(bound)
         check(lib.dns_raygen_sample(ptr(pix_idx), ptr(color), ptr(depth), ptr(label), ptr(quat), ptr(trans), camv, b6,
                                     H, W, H0, H1, W0, W1, K, npf, ptr(t_uniform), ptr(t_surf), ptr(t_zero), nu, ns,
-                                    ptr(ws), ptr(rays_o), ptr(rays_d), ptr(gt_color), ptr(gt_depth), ptr(gt_label),
+                                    ptr(ws), 0 if depth_max is None else 1, ptr(rays_o), ptr(rays_d), ptr(gt_color),
+                                    ptr(gt_depth), ptr(gt_label),
                                     ptr(inside), ptr(z), ptr(pts), stream_ptr()), "dns_raygen_sample")
         ctx.save_for_backward(pix_idx, quat, z)
         ctx.misc = (camv, window, K, npf, S)
@@ -369,15 +374,16 @@ class _RaygenFn(torch.autograd.Function):
         check(lib.dns_raygen_bwd(ptr(pix_idx), ptr(quat), camv, H0, H1, W0, W1, K, npf, S, ptr(z), ptr(c(d_pts)),
                                  ptr(c(d_ro)), ptr(c(d_rd)), ptr(ws), ptr(d_quat), ptr(d_trans), stream_ptr()),
               "dns_raygen_bwd")
-        return (d_quat, d_trans) + (None,) * 11
+        return (d_quat, d_trans) + (None,) * 12
 
 
-def raygen_sample(quat, trans, pix_idx, color, depth, label, cam, bound, window, n_per_frame, t_uniform, t_surf, t_zero):
+def raygen_sample(quat, trans, pix_idx, color, depth, label, cam, bound, window, n_per_frame, t_uniform, t_surf, t_zero,
+                  depth_max=None):
     """K stacked frames -> (rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z).  quat [K,4], trans [K,3],
     pix_idx [K*n_per_frame] int64 window-flat indices, color [K,H,W,3], depth/label [K,H,W] fp32,
     cam=(fx,fy,cx,cy), bound [3,2] fp64, window=(H0,H1,W0,W1)."""
     return _RaygenFn.apply(quat, trans, pix_idx, color, depth, label, tuple(cam), bound, tuple(window), n_per_frame,
-                           t_uniform, t_surf, t_zero)
+                           t_uniform, t_surf, t_zero, depth_max)
 
 
 def sample_along_rays(gt_depth, far_bb, t_uniform, t_surf, t_zero):

@@ -68,14 +68,15 @@ int dns_grid_meta_init(DnsGridMeta* meta, uint32_t n_levels, uint32_t n_features
  * label [K,H,W] fp32.  quat [K,4] (w,x,y,z), trans [K,3].  cam = fx,fy,cx,cy [host].
  * bound [host] = 6 doubles b0x,b1x,b0y,b1y,b0z,b1z.  t_uniform [n_uniform] = linspace(0,1),
  * t_surf / t_zero [n_surface] the two jitter draws (t_surf already holds the forced 0.5).
- * depth_max_ws: K uint32 scratch.  Outputs: rays_o,rays_d,gt_color [n,3], gt_depth [n],
+ * depth_max_ws: K uint32 (bit patterns of the per-frame max sampled depth): scratch when depth_max_given == 0; when
+ * depth_max_given != 0 the caller has filled it (multi-GPU: the max over ALL ranks' rays of the frame).  Outputs: rays_o,rays_d,gt_color [n,3], gt_depth [n],
  * gt_label [n] int64, inside [n] uint8 (far_bb >= depth, before the +0.01), z [n, n_uniform+n_surface]
  * ascending. */
 int dns_raygen_sample(const int64_t* pix_idx, const float* color, const float* depth, const float* label,
                       const float* quat, const float* trans, const double* cam, const double* bound,
                       int H, int W, int H0, int H1, int W0, int W1, int n_frames, int n_per_frame,
                       const float* t_uniform, const float* t_surf, const float* t_zero,
-                      int n_uniform, int n_surface, uint32_t* depth_max_ws,
+                      int n_uniform, int n_surface, uint32_t* depth_max_ws, int depth_max_given,
                       float* rays_o, float* rays_d, float* gt_color, float* gt_depth, int64_t* gt_label,
                       uint8_t* inside, float* z, float* pts /* [n,S,3] = o + d*z (slams/mapping.py:531), NULL = skip */,
                       void* stream);
