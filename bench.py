@@ -37,6 +37,9 @@ WORKLOADS = {
                       "T=2^16 hash grid, 2x64 MLPs, 8 classes + per-class fine decoders, 63^3 smoothness lattice, Adam"),
     "ref": dict(rays=(332, 166), nu=32, ns=15, hash_size=16, voxel=0.02, nn=32, nl=1, smooth_pts=64,
                 desc="reference Replica defaults: 1992 rays x 47 samples, 1x32 MLPs"),
+    "cfg5": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
+                 desc="BASELINE configs[4] shape in fp32: scene0000 bound, 8192 rays x 128 samples, T=2^20 (58.7 MB table), "
+                      "2x64 MLPs (the fp16 MLP variant is not built yet)"),
 }
 
 
@@ -48,7 +51,7 @@ def algorithmic_cost(name, units, wl):
     if name == "dns_encode_bwd":
         return units * (2 * 16 * 8 * 2 * 4 + 12), 0        # read-modify-write of the same 128 table cells
     if name == "dns_composite_fwd" or name == "dns_composite_bwd":
-        return units * 64 * (4 + 1 + 8) * 4, 0             # units = rays; raw + z + logits per sample
+        return units * (wl["nu"] + wl["ns"]) * (4 + 1 + 8) * 4, 0   # units = rays; raw + z + logits per sample
     return 0, 0
 
 
@@ -56,7 +59,7 @@ def build(wl, device, seed, dist_ctx):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
-    bound, cam, frames = synthetic.make_scene(4, seed=0)
+    bound, cam, frames = synthetic.make_scene(4, seed=0, bound=synthetic.SCENE0000_BOUND if wl.get("bound") == "scene0000" else None)
     n_per_frame = sum(wl["rays"])
     cfg = synthetic.default_cfg(n_pixels=4 * n_per_frame, n_samples_ray=wl["nu"], n_surface_ray=wl["ns"], n_frames=4,
                                 hash_size=wl["hash_size"], voxel_size=wl["voxel"], n_neurons=wl["nn"],

@@ -292,7 +292,7 @@ __device__ __forceinline__ void store_acc_rows(float* __restrict__ dst, const f3
 }
 
 template <int NN, int NL>
-__global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const float* __restrict__ x, uint32_t ldx,
+__global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restrict__ x, uint32_t ldx,
                                                            const float* __restrict__ dy, uint32_t lddy,
                                                            const float* __restrict__ params, MlpShape sh,
                                                            float* __restrict__ dx, uint32_t lddx,
@@ -303,7 +303,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const float* __restri
   constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = BwdLds<NN, NL>;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // 8 waves share one set of LDS weight images (they cap the CU at one workgroup): waves 0-3 take one 128-slot
+  // tile, waves 4-7 the next one when it belongs to the same weight set -- two waves per SIMD hide each other's
+  // LDS / MFMA latencies.
+  const uint32_t lane = threadIdx.x & 63u, wave8 = threadIdx.x >> 6;
+  const uint32_t wave = wave8 & 3u, wsel = wave8 >> 2;
   const uint32_t khalf = sh.n_in / 2;
   const uint32_t ko2 = L::ko2(sh.n_out);
   const uint32_t in_tiles = L::in_pad(sh.n_in) / 32u;
@@ -315,8 +319,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const float* __restri
   float* wsH2 = ws + (size_t)2 * n_slots * NN;
   float* wsD2 = ws + (size_t)3 * n_slots * NN;
   int cur_group = -2;
-  for (uint32_t bt = bt0; bt < bt1; ++bt) {
-    const int grp = tile_group ? tile_group[bt] : 0;
+  for (uint32_t btb = bt0; btb < bt1;) {
+    const int grp = tile_group ? tile_group[btb] : 0;
+    const uint32_t nb = (btb + 1 < bt1 && (tile_group ? tile_group[btb + 1] : 0) == grp) ? 2u : 1u;
+    const uint32_t bt = btb + wsel;
+    btb += nb;
     if (grp != cur_group) {
       __syncthreads();
       if (grp >= 0) {
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(const float* __restri
       cur_group = grp;
       __syncthreads();
     }
+    if (wsel >= nb) continue;                      // no second tile of this weight set: waves 4-7 sit this one out
     const uint32_t slot = bt * 128u + wave * 32u + (lane & 31u);
     const uint32_t h = lane >> 5;
     int row = -1;
@@ -466,12 +474,16 @@ struct GemmTnArgs {
   uint32_t tiles_per_block;
 };
 
-// Stage 64 rows x Wp columns (Wp = 32..128, multiple of 32) of a row-major matrix into LDS.  4 threads per row,
-// each owning Wp/4 consecutive columns; every global load of the thread is issued before the first LDS store so
-// the (up to 8) 16-byte loads overlap instead of paying one memory latency each.
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, uint32_t Wp, const float* __restrict__ src,
-                                           uint32_t ld, const int32_t* __restrict__ index, uint32_t W, uint32_t p0,
-                                           uint32_t n_slots) {
+// Staging of 64 rows x Wp columns (Wp = 32..128, multiple of 32) of a row-major matrix into LDS, split in two
+// halves so the global loads of sub-tile k+1 fly while the MFMAs of sub-tile k run: stage_load issues every
+// 16-byte load of the thread (4 threads per row, Wp/4 consecutive columns each) into registers, stage_store
+// writes them to LDS after the barrier that retires the previous sub-tile.
+struct StageRegs {
+  float4 v[8];
+};
+
+__device__ __forceinline__ void stage_load(StageRegs& rg, uint32_t Wp, const float* __restrict__ src, uint32_t ld,
+                                           const int32_t* __restrict__ index, uint32_t W, uint32_t p0, uint32_t n_slots) {
   const uint32_t r = threadIdx.x >> 2, q = threadIdx.x & 3u;
   const uint32_t cw = Wp >> 2;               // columns per thread: 8, 16, 24 or 32
   const uint32_t c0 = q * cw;
@@ -480,35 +492,41 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, uint32_t Wp,
   if (slot < n_slots) row = index ? index[slot] : (int)slot;
   const float* sp = src + (size_t)(row >= 0 ? row : 0) * ld;
   const bool vec = ((ld & 3u) == 0) && ((((uintptr_t)src) & 15u) == 0);
-  float4 v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rg.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t c = c0 + 4 * j;
     if ((uint32_t)(4 * j) < cw && row >= 0) {
       if (vec && c + 3 < W) {
-        v[j] = *reinterpret_cast<const float4*>(sp + c);
+        rg.v[j] = *reinterpret_cast<const float4*>(sp + c);
       } else {
-        if (c < W) v[j].x = sp[c];
-        if (c + 1 < W) v[j].y = sp[c + 1];
-        if (c + 2 < W) v[j].z = sp[c + 2];
-        if (c + 3 < W) v[j].w = sp[c + 3];
+        if (c < W) rg.v[j].x = sp[c];
+        if (c + 1 < W) rg.v[j].y = sp[c + 1];
+        if (c + 2 < W) rg.v[j].z = sp[c + 2];
+        if (c + 3 < W) rg.v[j].w = sp[c + 3];
       }
     }
   }
+}
+
+__device__ __forceinline__ void stage_store(const StageRegs& rg, float* __restrict__ dst, uint32_t Wp) {
+  const uint32_t r = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  const uint32_t cw = Wp >> 2;
+  const uint32_t c0 = q * cw;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if ((uint32_t)(4 * j) < cw) *reinterpret_cast<float4*>(dst + r * Wp + c0 + 4 * j) = v[j];
+    if ((uint32_t)(4 * j) < cw) *reinterpret_cast<float4*>(dst + r * Wp + c0 + 4 * j) = rg.v[j];
 }
 
 struct GemmTnBatch {
   GemmTnArgs g[3];
 };
 
-// LDS staging: the workgroup loads a 64-slot sub-tile of A [64 x M] and B [64 x N] once (coalesced, through the
-// optional slot->row index) and all waves read their MFMA operands from it -- lane (i,h) of step s reads
-// row 2s+h, column tile*32+i: two 128-byte row segments per ds_read_b32, conflict-free for any row stride.
-// blockIdx.y selects one of up to three GEMMs (dW_in, dW_hidden, dW_out of one network) sharing the launch.
+// Weight gradients C[M x N] += sum_slots A[slot][m] * B[slot][n] (K dimension = points), per parameter group.
+// The workgroup stages a 64-slot sub-tile of A [64 x M] and B [64 x N] through LDS (coalesced, through the optional
+// slot->row index) and all waves read their MFMA operands from it -- lane (i,h) of step s reads row 2s+h, column
+// tile*32+i: two 128-byte row segments per ds_read_b32, conflict-free for any row stride.  Each wave owns up to 2
+// of the <= 8 output tiles; blockIdx.y selects one of up to three GEMMs (dW_in, dW_hidden, dW_out) of one network.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnBatch batch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GemmTnArgs& g = batch.g[blockIdx.y];
@@ -545,33 +563,58 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnBatch batch) {
       acc[t] = zero16();
     }
   };
-  for (uint32_t bt = bt0; bt < bt1; ++bt) {
-    const int grp = g.tile_group ? g.tile_group[bt] : 0;
+  // sub-tile sequence of this workgroup: (bt, sub) pairs, skipping tiles of empty groups
+  auto group_of = [&](uint32_t bt) -> int { return g.tile_group ? g.tile_group[bt] : 0; };
+  auto next_live = [&](uint32_t& bt, uint32_t& sub) -> bool {   // advance to the next sub-tile that exists
+    while (bt < bt1) {
+      if (group_of(bt) >= 0 && bt * 128u + sub * 64u < g.n_slots) return true;
+      ++bt;
+      sub = 0;
+    }
+    return false;
+  };
+  uint32_t bt = bt0, sub = 0;
+  StageRegs ra, rb;
+  bool have = next_live(bt, sub);
+  if (have) {
+    stage_load(ra, Mp, g.A, g.lda, g.a_index, M, bt * 128u + sub * 64u, g.n_slots);
+    stage_load(rb, Np, g.B, g.ldb, g.b_index, N, bt * 128u + sub * 64u, g.n_slots);
+  }
+  while (have) {
+    const int grp = group_of(bt);
     if (grp != cur_group) {
       flush(cur_group);
       cur_group = grp;
     }
-    if (grp < 0) continue;
-    for (uint32_t sub = 0; sub < 2; ++sub) {
-      const uint32_t p0 = bt * 128u + sub * 64u;
-      if (p0 >= g.n_slots) break;
-      __syncthreads();
-      // stage A and B sub-tiles (zero beyond the matrix / for padding slots); all loads of a thread in flight
-      stage_rows(la, Mp, g.A, g.lda, g.a_index, M, p0, g.n_slots);
-      stage_rows(lb, Np, g.B, g.ldb, g.b_index, N, p0, g.n_slots);
-      __syncthreads();
+    __syncthreads();                         // previous sub-tile's MFMA reads are done
+    stage_store(ra, la, Mp);
+    stage_store(rb, lb, Np);
+    __syncthreads();
+    // request the next sub-tile before computing on this one
+    uint32_t nbt = bt, nsub = sub + 1;
+    if (nsub == 2) {
+      nsub = 0;
+      ++nbt;
+    }
+    const bool more = next_live(nbt, nsub);
+    if (more) {
+      stage_load(ra, Mp, g.A, g.lda, g.a_index, M, nbt * 128u + nsub * 64u, g.n_slots);
+      stage_load(rb, Np, g.B, g.ldb, g.b_index, N, nbt * 128u + nsub * 64u, g.n_slots);
+    }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (tile_id[t] < ntiles) {
-          const uint32_t mt = tile_id[t] / NT, nt = tile_id[t] % NT;
-          const float* pa = la + h * Mp + mt * 32 + i;
-          const float* pb = lb + h * Np + nt * 32 + i;
+    for (int t = 0; t < 2; ++t) {
+      if (tile_id[t] < ntiles) {
+        const uint32_t mt = tile_id[t] / NT, nt = tile_id[t] % NT;
+        const float* pa = la + h * Mp + mt * 32 + i;
+        const float* pb = lb + h * Np + nt * 32 + i;
 #pragma unroll 8
-          for (uint32_t st = 0; st < 32u; ++st)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * st * Mp], pb[2 * st * Np], acc[t], 0, 0, 0);
-        }
+        for (uint32_t st = 0; st < 32u; ++st)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * st * Mp], pb[2 * st * Np], acc[t], 0, 0, 0);
       }
     }
+    bt = nbt;
+    sub = nsub;
+    have = more;
   }
   flush(cur_group);
 }
@@ -650,7 +693,7 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
     const size_t lds_bytes = (size_t)BwdLds<NN, NL>::total(n_in, n_out, d_x != nullptr) * sizeof(float);            \
     hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                         (int)lds_bytes);                                                                            \
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, dy, lddy,     \
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy,     \
                        params, sh, d_x, lddx, ws, n_slots, row_index, tile_group, param_stride, tpb);               \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_BWD(32, 1)

@@ -47,7 +47,7 @@ def camera(H=480, W=640, fx=500.0, fy=500.0):
     return {"H": H, "W": W, "fx": fx, "fy": fy, "cx": (W - 1) / 2.0, "cy": (H - 1) / 2.0}
 
 
-def make_pose(theta: float, center=(3.0, 1.2, 0.0), radius=1.0, jitter: torch.Tensor = None) -> torch.Tensor:
+def make_pose(theta: float, center=(3.0, 1.2, 0.0), radius=1.0, jitter: torch.Tensor = None) -> torch.Tensor:  # noqa: E501
     """c2w of a camera on a horizontal circle looking outward (camera looks along -z, y up; world z up)."""
     look = torch.tensor([math.cos(theta), math.sin(theta), 0.0], dtype=torch.float64)
     if jitter is not None:
@@ -100,7 +100,8 @@ def make_scene(n_frames=4, cam=None, bound=None, seed=0):
     colors, depths, labels, poses = [], [], [], []
     for f in range(n_frames):
         jit = torch.randn(3, generator=g, dtype=torch.float64)
-        c2w = make_pose(2 * math.pi * f / n_frames + 0.3, jitter=jit)
+        centre = tuple(float(v) for v in (bound_t[:, 0] + bound_t[:, 1]) / 2)          # camera circle around the room centre
+        c2w = make_pose(2 * math.pi * f / n_frames + 0.3, center=centre, radius=min(1.0, float((bound_t[:, 1] - bound_t[:, 0]).min()) / 8), jitter=jit)
         c, d, l = render_frame(c2w, cam, room, seed * 100 + f)
         colors.append(c), depths.append(d), labels.append(l), poses.append(c2w)
     label_dict = sorted({int(v) for l in labels for v in torch.unique(l).tolist()})
