@@ -170,6 +170,31 @@ __device__ __forceinline__ void relu(f32x16 (&a)[NT]) {
 
 __device__ __forceinline__ uint32_t param_off_hidden(uint32_t nn, uint32_t n_in) { return nn * n_in; }
 
+template <int NT>
+__device__ __forceinline__ void store_acc_rows(float* __restrict__ dst, const f32x16 (&a)[NT], uint32_t h) {
+  // dst = row base of a [NN]-wide slot row; 4 contiguous floats per (tile, quad)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+      *reinterpret_cast<float4*>(dst + t * 32 + 8 * q + 4 * h) = v;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_acc_rows(const float* __restrict__ src, f32x16 (&a)[NT], uint32_t h, bool ok) {
+  // inverse of store_acc_rows: a slot row of [NN] floats -> accumulator layout
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(src + t * 32 + 8 * q + 4 * h);
+      a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w;
+    }
+}
+
 // LDS layout helpers (floats)
 template <int NN, int NL>
 struct FwdLds {
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ y, uint32_t ldy, uint32_t n_slots,
                                                       const int32_t* __restrict__ row_index,
                                                       const int32_t* __restrict__ tile_group, uint32_t param_stride,
-                                                      uint32_t tiles_per_block) {
+                                                      uint32_t tiles_per_block, float* __restrict__ h_save) {
   constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = FwdLds<NN, NL>;
@@ -223,10 +248,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ 
     f32x16 a0[NT];
     layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, a0);
     relu<NT>(a0);
+    if (h_save && slot < n_slots) store_acc_rows<NT>(h_save + (size_t)slot * NN, a0, h);   // kept for the backward
     f32x16 a1[NT];
     if (NL == 2) {
       layer_chain<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, NT, a1);
       relu<NT>(a1);
+      if (h_save && slot < n_slots) store_acc_rows<NT>(h_save + (size_t)(n_slots + slot) * NN, a1, h);
     }
     const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
     float* yrow = y + (size_t)(valid ? row : 0) * ldy;
@@ -265,13 +292,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ 
 // Backward, data path: recompute hidden activations, dH_l = W^T dH_{l+1} (.) relu', dX = W_in^T dH_1.
 // Writes H_l and dH_l (slot-major [n_slots, NN]) to the workspace for the weight-gradient GEMMs.
 // ws layout: [H_1 | dH_1 | H_2 | dH_2] each n_slots*NN floats.
-template <int NN, int NL>
+// SAVED = the forward kept its hidden activations (h_saved): no recompute, so the forward images W_in / W_h are
+// not staged (LDS 100 KB -> ~57 KB) and 144 of the 338 MFMAs per tile (2x64, 80 in) disappear.
+template <int NN, int NL, bool SAVED>
 struct BwdLds {
   static __host__ __device__ uint32_t in_pad(uint32_t n_in) { return (n_in + 31u) / 32u * 32u; }
   static __host__ __device__ uint32_t ko2(uint32_t n_out) { return (n_out + 1u) / 2u; }
   static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
-  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return NN * n_in; }
-  static __host__ __device__ uint32_t img_outT(uint32_t n_in) { return img_h(n_in) + (NL - 1) * NN * NN; }
+  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return SAVED ? 0 : NN * n_in; }
+  static __host__ __device__ uint32_t img_outT(uint32_t n_in) { return SAVED ? 0 : img_h(n_in) + (NL - 1) * NN * NN; }
   static __host__ __device__ uint32_t img_hT(uint32_t n_in, uint32_t n_out) { return img_outT(n_in) + NN * 2 * ko2(n_out); }
   static __host__ __device__ uint32_t img_inT(uint32_t n_in, uint32_t n_out) { return img_hT(n_in, n_out) + (NL - 1) * NN * NN; }
   static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, bool need_dx) {
@@ -279,19 +308,7 @@ struct BwdLds {
   }
 };
 
-template <int NT>
-__device__ __forceinline__ void store_acc_rows(float* __restrict__ dst, const f32x16 (&a)[NT], uint32_t h) {
-  // dst = row base of a [NN]-wide slot row; 4 contiguous floats per (tile, quad)
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 v = make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
-      *reinterpret_cast<float4*>(dst + t * 32 + 8 * q + 4 * h) = v;
-    }
-}
-
-template <int NN, int NL>
+template <int NN, int NL, bool SAVED>
 __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restrict__ x, uint32_t ldx,
                                                            const float* __restrict__ dy, uint32_t lddy,
                                                            const float* __restrict__ params, MlpShape sh,
@@ -299,10 +316,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
                                                            float* __restrict__ ws, uint32_t n_slots,
                                                            const int32_t* __restrict__ row_index,
                                                            const int32_t* __restrict__ tile_group,
-                                                           uint32_t param_stride, uint32_t tiles_per_block) {
+                                                           uint32_t param_stride, uint32_t tiles_per_block,
+                                                           const float* __restrict__ h_saved) {
   constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using L = BwdLds<NN, NL>;
+  using L = BwdLds<NN, NL, SAVED>;
   // 8 waves share one set of LDS weight images (they cap the CU at one workgroup): waves 0-3 take one 128-slot
   // tile, waves 4-7 the next one when it belongs to the same weight set -- two waves per SIMD hide each other's
   // LDS / MFMA latencies.
@@ -314,10 +332,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   const uint32_t bt0 = blockIdx.x * tiles_per_block;
   const uint32_t bt1 = min(bt0 + tiles_per_block, n_btiles);
-  float* wsH1 = ws;
-  float* wsD1 = ws + (size_t)n_slots * NN;
-  float* wsH2 = ws + (size_t)2 * n_slots * NN;
-  float* wsD2 = ws + (size_t)3 * n_slots * NN;
+  // workspace: recompute path [H1 | dH1 | H2 | dH2]; saved path [dH1 | dH2] (H stays in h_saved)
+  float* wsH1 = SAVED ? nullptr : ws;
+  float* wsD1 = SAVED ? ws : ws + (size_t)n_slots * NN;
+  float* wsH2 = SAVED ? nullptr : ws + (size_t)2 * n_slots * NN;
+  float* wsD2 = SAVED ? ws + (size_t)n_slots * NN : ws + (size_t)3 * n_slots * NN;
   int cur_group = -2;
   for (uint32_t btb = bt0; btb < bt1;) {
     const int grp = tile_group ? tile_group[btb] : 0;
@@ -330,9 +349,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
         const float* pw = params + (size_t)grp * param_stride;
         const float* wh = pw + NN * sh.n_in;
         const float* wout = wh + (NL - 1) * NN * NN;
-        build_image(lds + L::img_in(sh.n_in), pw, NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
+        if (!SAVED) build_image(lds + L::img_in(sh.n_in), pw, NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
         if (NL == 2) {
-          build_image(lds + L::img_h(sh.n_in), wh, NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+          if (!SAVED) build_image(lds + L::img_h(sh.n_in), wh, NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
           build_image(lds + L::img_hT(sh.n_in, sh.n_out), wh, NN, NN, true, NT, NN / 2, K_CHAIN, 0, NN);
         }
         // A = W_out^T: rows = hidden (NN), k over outputs in split halves of ko2
@@ -354,22 +373,27 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
         f32x16 z[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) z[t] = zero16();
-        store_acc_rows<NT>(wsH1 + (size_t)slot * NN, z, h);
+        if (!SAVED) store_acc_rows<NT>(wsH1 + (size_t)slot * NN, z, h);
         store_acc_rows<NT>(wsD1 + (size_t)slot * NN, z, h);
         if (NL == 2) {
-          store_acc_rows<NT>(wsH2 + (size_t)slot * NN, z, h);
+          if (!SAVED) store_acc_rows<NT>(wsH2 + (size_t)slot * NN, z, h);
           store_acc_rows<NT>(wsD2 + (size_t)slot * NN, z, h);
         }
       }
       continue;
     }
-    const float* xrow = x + (size_t)(valid ? row : 0) * ldx + h * khalf;
     f32x16 h1[NT], h2[NT];
-    layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, h1);
-    relu<NT>(h1);
-    if (NL == 2) {
-      layer_chain<NT, NT>(h1, lds + L::img_h(sh.n_in), lane, NT, h2);
-      relu<NT>(h2);
+    if (SAVED) {
+      load_acc_rows<NT>(h_saved + (size_t)slot * NN, h1, h, slot < n_slots);
+      if (NL == 2) load_acc_rows<NT>(h_saved + (size_t)(n_slots + slot) * NN, h2, h, slot < n_slots);
+    } else {
+      const float* xrow = x + (size_t)(valid ? row : 0) * ldx + h * khalf;
+      layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, h1);
+      relu<NT>(h1);
+      if (NL == 2) {
+        layer_chain<NT, NT>(h1, lds + L::img_h(sh.n_in), lane, NT, h2);
+        relu<NT>(h2);
+      }
     }
     // dH_last = W_out^T dY
     f32x16 dl[NT];
@@ -410,10 +434,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
     }
     const f32x16(&dfirst)[NT] = (NL == 2) ? d1 : dl;
     if (slot < n_slots) {
-      store_acc_rows<NT>(wsH1 + (size_t)slot * NN, h1, h);
+      if (!SAVED) store_acc_rows<NT>(wsH1 + (size_t)slot * NN, h1, h);
       store_acc_rows<NT>(wsD1 + (size_t)slot * NN, dfirst, h);
       if (NL == 2) {
-        store_acc_rows<NT>(wsH2 + (size_t)slot * NN, h2, h);
+        if (!SAVED) store_acc_rows<NT>(wsH2 + (size_t)slot * NN, h2, h);
         store_acc_rows<NT>(wsD2 + (size_t)slot * NN, dl, h);
       }
     }
@@ -643,9 +667,11 @@ extern "C" uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, 
 
 extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
                            uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
-                           const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream) {
+                           const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, float* h_save,
+                           void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
+  DNS_REQUIRE(!h_save || (((uintptr_t)h_save) % 16) == 0, "dns_mlp_fwd: h_save must be 16-byte aligned");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
@@ -660,7 +686,7 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
   {                                                                                                                \
     const size_t lds_bytes = (size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) * sizeof(float);                    \
     hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, params, sh, y, ldy, \
-                       n_slots, row_index, tile_group, param_stride, tpb);                                         \
+                       n_slots, row_index, tile_group, param_stride, tpb, h_save);                                 \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
@@ -673,7 +699,7 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
 extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
                            uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* d_x,
                            uint32_t lddx, float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
-                           const int32_t* tile_group, uint32_t param_stride, void* stream) {
+                           const int32_t* tile_group, uint32_t param_stride, const float* h_saved, void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params && ws, "dns_mlp_bwd: NULL argument");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
@@ -688,28 +714,34 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
   const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t NNr = n_neurons;
-#define LAUNCH_BWD(NN, NL)                                                                                          \
+#define LAUNCH_BWD2(NN, NL, SV)                                                                                     \
   {                                                                                                                 \
-    const size_t lds_bytes = (size_t)BwdLds<NN, NL>::total(n_in, n_out, d_x != nullptr) * sizeof(float);            \
-    hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                        (int)lds_bytes);                                                                            \
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy,     \
-                       params, sh, d_x, lddx, ws, n_slots, row_index, tile_group, param_stride, tpb);               \
+    const size_t lds_bytes = (size_t)BwdLds<NN, NL, SV>::total(n_in, n_out, d_x != nullptr) * sizeof(float);        \
+    (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds_bytes);                                                                      \
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy, \
+                       params, sh, d_x, lddx, ws, n_slots, row_index, tile_group, param_stride, tpb, h_saved);      \
+  }
+#define LAUNCH_BWD(NN, NL)            \
+  {                                   \
+    if (h_saved) LAUNCH_BWD2(NN, NL, true) \
+    else LAUNCH_BWD2(NN, NL, false)   \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_BWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_BWD(32, 2)
   else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_BWD(64, 1)
   else LAUNCH_BWD(64, 2)
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD2
   int rc = check_launch("dns_mlp_bwd(data)");
   if (rc != DNS_OK) return rc;
   if (!d_params) return DNS_OK;
   // weight gradients: dW_in = dH1^T X ; dW_h = dH2^T H1 ; dW_out = dY^T H_last
   const size_t SN = (size_t)n_slots * NNr;
-  float* wsH1 = ws;
-  float* wsD1 = ws + SN;
-  float* wsH2 = ws + 2 * SN;
-  float* wsD2 = ws + 3 * SN;
+  const float* wsH1 = h_saved ? h_saved : ws;
+  const float* wsD1 = h_saved ? ws : ws + SN;
+  const float* wsH2 = h_saved ? h_saved + SN : ws + 2 * SN;
+  const float* wsD2 = h_saved ? ws + SN : ws + 3 * SN;
   GemmTnBatch batch;
   int ng = 0;
   auto add = [&](const float* A, uint32_t lda, const int32_t* ai, uint32_t M, const float* B, uint32_t ldb,

@@ -191,6 +191,11 @@ def _row_major_2d(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+# True: the forward keeps the hidden activations (512 B/point at 2x64) and the backward skips the recompute;
+# False: nothing is kept and dns_mlp_bwd recomputes them from x (less memory, ~1.7x more MFMA work in the backward).
+MLP_SAVE_HIDDEN = True
+
+
 class _MlpFn(torch.autograd.Function):
     """y = MLP(x; params).  ``params`` is [G, count] (G weight sets, G=1 for a plain network)."""
 
@@ -208,15 +213,18 @@ class _MlpFn(torch.autograd.Function):
         else:
             y = torch.zeros(P, n_out, device=x.device, dtype=torch.float32)
         stride = params.shape[-1] if params.dim() == 2 else 0
+        # keep the hidden activations when a backward will follow: it then skips the forward recompute
+        keep = MLP_SAVE_HIDDEN and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        h_save = torch.empty(nl * n_slots * nn, device=x.device, dtype=torch.float32) if keep else None
         check(lib.dns_mlp_fwd(ptr(x), x.stride(0), ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, n_slots,
-                              ptr(row_index), ptr(tile_group), stride, stream_ptr()), "dns_mlp_fwd")
-        ctx.save_for_backward(x, params, row_index, tile_group)
+                              ptr(row_index), ptr(tile_group), stride, ptr(h_save), stream_ptr()), "dns_mlp_fwd")
+        ctx.save_for_backward(x, params, row_index, tile_group, h_save)
         ctx.shape, ctx.n_slots, ctx.stride = shape, n_slots, stride
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, params, row_index, tile_group = ctx.saved_tensors
+        x, params, row_index, tile_group, h_save = ctx.saved_tensors
         n_in, n_out, nn, nl = ctx.shape
         dy = dy.contiguous()
         P = x.shape[0]
@@ -229,7 +237,7 @@ class _MlpFn(torch.autograd.Function):
         ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(ctx.n_slots, nn, nl)), device=x.device, dtype=torch.float32)
         check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(d_x), n_in,
                               ptr(d_p), ptr(ws), ctx.n_slots, ptr(row_index), ptr(tile_group), ctx.stride,
-                              stream_ptr()), "dns_mlp_bwd")
+                              ptr(h_save), stream_ptr()), "dns_mlp_bwd")
         return d_x, d_p, None, None, None, None
 
 

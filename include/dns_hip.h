@@ -131,15 +131,19 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * fine decoders of slams/mapping.py:590-601 without gathering activations. */
 int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
-                const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream);
+                const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
+                float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: hidden activations kept for dns_mlp_bwd */,
+                void* stream);
 
-/* Backward.  Recomputes the hidden activations from x.  d_x [rows, lddx] written for valid slots (NULL =
+/* Backward.  Hidden activations come from h_saved (what dns_mlp_fwd wrote) or, if NULL, are recomputed from x.
+ * d_x [rows, lddx] written for valid slots (NULL =
  * skip); d_params (+=) same layout as params (+ group*param_stride), NULL = skip.  ws: 16-byte aligned
  * float workspace of dns_mlp_bwd_ws_floats(n_slots, n_neurons, n_hidden_layers) elements. */
 int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
                 uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
                 float* d_x, uint32_t lddx, float* d_params, float* ws, uint32_t n_slots,
-                const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, void* stream);
+                const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, const float* h_saved,
+                void* stream);
 uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers);
 
 /* ---- occupancy compositing (raw2nerf_color, utils/common.py:506-537, + the logit composite of

@@ -105,9 +105,10 @@ SHAPES = [(80, 33, 32, 1), (112, 3, 32, 1), (112, 40, 32, 1), (112, 8, 32, 1), (
 
 
 @pytest.mark.parametrize("n_in,n_out,nn,nl", SHAPES)
-@pytest.mark.parametrize("P", [1000, 129])
-def test_mlp_forward_backward(n_in, n_out, nn, nl, P):
+@pytest.mark.parametrize("P,save_hidden", [(1000, True), (129, True), (777, False)])
+def test_mlp_forward_backward(n_in, n_out, nn, nl, P, save_hidden, monkeypatch):
     ops = _ops()
+    monkeypatch.setattr(ops, "MLP_SAVE_HIDDEN", save_hidden)     # both backward variants: saved activations / recompute
     g = torch.Generator().manual_seed(n_in * 7 + n_out * 3 + nn + nl)
     params = tr.mlp_init(n_in, n_out, nn, nl, g)
     assert params.numel() == ops.mlp_param_count(n_in, n_out, nn, nl)
