@@ -207,6 +207,10 @@ def main():
             graphed = True
         except Exception as e:                               # keep the benchmark alive: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
             run = step
     for i in range(args.warmup):
         tw = time.perf_counter()
@@ -268,7 +272,11 @@ def main():
         "kernel_breakdown": breakdown,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, cfg, bound, cam, frames)
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl, cfg, bound, cam, frames)
+        except Exception as e:                               # never lose the GPU line to a host-side problem
+            out["cpu_baseline"] = {"value": None, "unit": "ray-samples/s", "cores": host_cores(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
     print(json.dumps(out))
 
 

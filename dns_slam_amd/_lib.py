@@ -42,7 +42,7 @@ SIGNATURES = {
     "dns_encode_bwd_ws_floats": (C.c_uint64, [_U, C.POINTER(DnsGridMeta)]),
     "dns_hashgrid_indices": (C.c_int, [_P, _U, C.POINTER(DnsGridMeta), _P, _P]),
     "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P, _P]),
-    "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P, _P]),
+    "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P, _I, _P]),
     "dns_mlp_bwd_ws_floats": (C.c_uint64, [_U, _U, _U]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),

@@ -18,6 +18,7 @@
 //
 // Roofline: exact-fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s); these kernels are MFMA-bound for
 // n_in >= 80 (x traffic 320-448 B/point vs 14-45 kFLOP/point).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace dns {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
                                                            const int32_t* __restrict__ row_index,
                                                            const int32_t* __restrict__ tile_group,
                                                            uint32_t param_stride, uint32_t tiles_per_block,
-                                                           const float* __restrict__ h_saved) {
+                                                           const float* __restrict__ h_saved, int accumulate_dx) {
   constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = BwdLds<NN, NL, SAVED>;
@@ -458,15 +459,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
                 const uint32_t c0 = (it0 + t) * 32 + 8 * q + 4 * h;
                 if (c0 + 3 < sh.n_in) {
                   if ((lddx & 3u) == 0) {
-                    *reinterpret_cast<float4*>(dxrow + c0) = make_float4(o[t][4 * q], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]);
+                    float4 v = make_float4(o[t][4 * q], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]);
+                    if (accumulate_dx) {                 // a second network sharing the same input adds its gradient
+                      const float4 u = *reinterpret_cast<const float4*>(dxrow + c0);
+                      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    }
+                    *reinterpret_cast<float4*>(dxrow + c0) = v;
                   } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dxrow[c0 + e] = o[t][4 * q + e];
+                    for (int e = 0; e < 4; ++e) dxrow[c0 + e] = o[t][4 * q + e] + (accumulate_dx ? dxrow[c0 + e] : 0.f);
                   }
                 } else {
 #pragma unroll
                   for (int e = 0; e < 4; ++e)
-                    if (c0 + e < sh.n_in) dxrow[c0 + e] = o[t][4 * q + e];
+                    if (c0 + e < sh.n_in) dxrow[c0 + e] = o[t][4 * q + e] + (accumulate_dx ? dxrow[c0 + e] : 0.f);
                 }
               }
             }
@@ -699,7 +705,8 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
 extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
                            uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* d_x,
                            uint32_t lddx, float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
-                           const int32_t* tile_group, uint32_t param_stride, const float* h_saved, void* stream) {
+                           const int32_t* tile_group, uint32_t param_stride, const float* h_saved, int accumulate_dx,
+                           void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params && ws, "dns_mlp_bwd: NULL argument");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
@@ -720,7 +727,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
     (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds_bytes);                                                                      \
     hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy, \
-                       params, sh, d_x, lddx, ws, n_slots, row_index, tile_group, param_stride, tpb, h_saved);      \
+                       params, sh, d_x, lddx, ws, n_slots, row_index, tile_group, param_stride, tpb, h_saved,       \
+                       accumulate_dx);                                                                              \
   }
 #define LAUNCH_BWD(NN, NL)            \
   {                                   \
@@ -764,6 +772,16 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
   const uint32_t max_cols = ((n_in + 31u) / 32u) * 32u + NNr > 2 * NNr ? ((n_in + 31u) / 32u) * 32u + NNr : 2 * NNr;
   const uint32_t out_cols = ((n_out + 31u) / 32u) * 32u + NNr;
   const size_t gemm_lds = (size_t)64 * (max_cols > out_cols ? max_cols : out_cols) * sizeof(float);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks, ng), dim3(256), gemm_lds, st, batch);
+  // Few, fat workgroups: every workgroup ends by adding its accumulators into the SAME small dW (28 KB), and same-address
+  // float atomics serialise (MI355X_MICROARCH: one row from every workgroup = 14x slower) -- the flush, not the MFMAs,
+  // dominated at 512 workgroups per GEMM.  ~2 workgroups per CU over the batched GEMMs; DNS_GEMM_BLOCKS overrides.
+  static const char* gb_env = getenv("DNS_GEMM_BLOCKS");
+  uint32_t gblocks = gb_env ? (uint32_t)atoi(gb_env) : 512u / (uint32_t)ng;
+  if (gblocks < 1) gblocks = 1;
+  uint32_t gtpb = (n_btiles + gblocks - 1) / gblocks;
+  if (gtpb < 1) gtpb = 1;
+  gblocks = (n_btiles + gtpb - 1) / gtpb;
+  for (int k = 0; k < 3; ++k) batch.g[k].tiles_per_block = gtpb;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
   return check_launch("dns_mlp_bwd(weights)");
 }

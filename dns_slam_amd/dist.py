@@ -7,7 +7,8 @@ north_star's addition.  Exactness w.r.t. one GPU rendering the union batch: the 
 numerators / counts of the rank's rays; ``allreduce_sums`` makes them global BEFORE they are normalised, so every
 masked mean (depth over d > 0, rays inside the box) uses the global denominator and the fs/opacity branch flag
 (utils/common.py:794) is evaluated on the global counts.  Each rank then back-propagates local numerators over
-global denominators and the gradients are SUMMED; the smoothness lattice, identical on every rank, is weighted 1/W.
+global denominators and the gradients are SUMMED; the smoothness term (each rank draws its own random lattice unless
+the caller passes the same offsets) is weighted 1/W, i.e. the ranks' lattices are averaged.
 Bucket: all gradients are flattened into one fp32 buffer -- 6.8 MB (T=2^16) .. 59 MB (T=2^20) + <1 MB of MLPs
 + 7 floats per frame -- so the collective is one large message; xGMI is point-to-point (7 links x ~153 GB/s), a
 ring all-reduce of M bytes moves 2*(7/8)*M over each link: 6.8 MB -> ~80 us, 59 MB -> ~0.7 ms.

@@ -387,7 +387,7 @@ class Mapper:
                      "opacity_loss": opacity_loss}
         if smooth:
             smooth_loss = self.smoothness(sample_points=tr["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
-            # multi-GPU: every rank evaluates the SAME lattice and gradients are SUMMED, so each contributes 1/W
+            # multi-GPU: gradients are SUMMED over ranks, so each rank's lattice contributes 1/W (average of W lattices)
             loss = loss + (self.lambda_sm / world) * smooth_loss
             terms["smooth_loss"] = smooth_loss
         return loss, terms

@@ -237,7 +237,7 @@ class _MlpFn(torch.autograd.Function):
         ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(ctx.n_slots, nn, nl)), device=x.device, dtype=torch.float32)
         check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(d_x), n_in,
                               ptr(d_p), ptr(ws), ctx.n_slots, ptr(row_index), ptr(tile_group), ctx.stride,
-                              ptr(h_save), stream_ptr()), "dns_mlp_bwd")
+                              ptr(h_save), 0, stream_ptr()), "dns_mlp_bwd")
         return d_x, d_p, None, None, None, None
 
 
@@ -477,3 +477,4 @@ def tracking_losses(pred_color, pred_depth, pred_var, pred_logits, gt_color, gt_
     lam = (lam[0], lam[1], lam[2], 0.0, 0.0, 0.0, 0.0, 1.0)
     return _LossFn.apply(pred_color, pred_depth, pred_var, pred_logits, None, None, gt_color, gt_depth, gt_label, valid,
                          None, lam, True, None)
+

@@ -143,7 +143,7 @@ int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, co
                 uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
                 float* d_x, uint32_t lddx, float* d_params, float* ws, uint32_t n_slots,
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, const float* h_saved,
-                void* stream);
+                int accumulate_dx /* != 0: d_x += (a second network reading the same input) */, void* stream);
 uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers);
 
 /* ---- occupancy compositing (raw2nerf_color, utils/common.py:506-537, + the logit composite of

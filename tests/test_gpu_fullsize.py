@@ -1,0 +1,93 @@
+"""GPU, BASELINE.json full sizes (configs[1]: 4096 rays x 64 samples, T=2^16, 2x64 MLPs; configs[4] shape: 8192 x 128,
+T=2^20): size-independent properties of the HIP path, plus one full-size comparison against the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(workload):
+    import bench
+    from dns_slam_amd import dist as dd
+    wl = bench.WORKLOADS[workload]
+    cfg, bound, cam, frames, mapper, step = bench.build(wl, DEV, seed=7, dist_ctx=dd.DistCtx())
+    return wl, cfg, bound, cam, frames, mapper
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg5"])
+def test_fullsize_properties(workload):
+    from dns_slam_amd import ops
+    wl, cfg, bound, cam, frames, mapper = _build(workload)
+    _, ql, Tl = mapper.set_optimizer(frames)
+    prep = mapper.prepare_frames(frames)
+    s = mapper.get_target_samples(frames, ql, Tl, prep=prep)
+    N, S = s["z_vals"].shape
+    assert (N, S) == (4 * sum(wl["rays"]), wl["nu"] + wl["ns"])
+    z = s["z_vals"]
+    assert bool((z[:, 1:] >= z[:, :-1]).all()), "z sorted ascending per ray"
+    d = s["gt_depth"]
+    hit = d > 0
+    # one sample sits exactly at the measured depth (forced t = 0.5 -> 0.95 d/2 + 1.05 d/2, utils/common.py:572-574)
+    exact = (0.95 * d * 0.5 + 1.05 * d * 0.5)[:, None]
+    assert bool(((z == exact).any(-1) | ~hit).all())
+    assert bool(torch.equal(s["pts"], s["rays_o"][:, None, :] + s["rays_d"][:, None, :] * z[:, :, None]))
+    # hash rows in range, per level
+    dec = mapper.decoder
+    x = ((s["pts"].reshape(-1, 3).double() - mapper.bound_dev[:, 0]) / (mapper.bound_dev[:, 1] - mapper.bound_dev[:, 0])).float()
+    meta = dec.pe_fn.grid_fn.meta
+    rows = ops.hashgrid_rows(x[:65536].contiguous(), meta)
+    for l, lv in enumerate(meta.levels()):
+        assert int(rows[:, l].min()) >= lv["offset"] and int(rows[:, l].max()) < lv["offset"] + lv["size"]
+    # renderer: weights are a partition of unity, colours in [0,1], gradients finite; shard-and-sum == unsharded
+    pc, pd, pv, pl, fine, coarse = mapper.renderer(s, strict=False)
+    assert float(pc.min()) >= 0.0 and float(pc.max()) <= 1.0
+    assert bool((pd >= z[:, 0] - 1e-5).all() and (pd <= z[:, -1] + 1e-5).all()), "depth is a convex combination of z"
+    assert bool((pv >= -1e-6).all())
+    loss, _ = mapper.iteration_loss(s, smooth=False)
+    table = dec.pe_fn.grid_fn.params
+    g_all, = torch.autograd.grad(loss, table, retain_graph=False)
+    assert bool(torch.isfinite(g_all).all()) and float(g_all.abs().max()) > 0
+    # linearity of the scatter in the upstream gradient: grad(2 * loss) == 2 * grad(loss) bit for bit (fixed point sums)
+    loss2, _ = mapper.iteration_loss(s, smooth=False)
+    g2, = torch.autograd.grad(2.0 * loss2, table)
+    assert float((g2 - 2.0 * g_all).abs().max()) <= 2e-6 * float(g_all.abs().max())
+
+
+def test_cfg2_fullsize_matches_oracle():
+    """One full-size iteration (262 144 points) against the CPU oracle: loss terms and the table / coarse gradients."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import slam_ref as sr
+    from util import assert_close, oracle_from_product, randomise_
+    wl, cfg, bound, cam, frames, mapper = _build("cfg2")
+    dec = mapper.decoder
+    randomise_(dec, 3)
+    with torch.no_grad():
+        dec.pe_fn.grid_fn.params.mul_(2000.0)
+    randomise_([mapper.fine_decoders.pool], 4)
+    mapper.is_BA = False
+    _, ql, Tl = mapper.set_optimizer(frames)
+    prep = mapper.prepare_frames(frames)
+    torch.manual_seed(11)
+    pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+    s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
+    loss, terms = mapper.iteration_loss(s, smooth=False)
+    loss.backward()
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    npf = pix.numel() // 4
+    fr = []
+    for f in range(4):
+        img5 = torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
+        fr.append(sr.frame_samples(img5, ql[f].detach().cpu(), Tl[f].detach().cpu(), camt, bound, pix.cpu()[f * npf:(f + 1) * npf],
+                                   jit[0].cpu(), jit[1].cpu(), wl["nu"], wl["ns"]))
+    so = sr.mapper_target_samples(fr)
+    lo, to, _ = sr.mapping_loss(om, so, sr.LossCfg())
+    lo.backward()
+    for kp, ko in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"), ("opacity_loss", "op")):
+        a, b = float(terms[kp]), float(to[ko])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), (kp, a, b)
+    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what="d table (full size)")
+    n = 64 * 80 + 64 * 64 + 33 * 64
+    assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:n], om.coarse.grad[:n], what="d coarse (full size)")
