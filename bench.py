@@ -72,9 +72,9 @@ def build(wl, device, seed, dist_ctx):
     mapper.is_BA = True
     mapper.static_shapes = True                              # sync-free iteration: capturable in a hipGraph
     mapper.set_decoder(frames)
-    optimizer, quad_list, T_list = mapper.set_optimizer(frames, capturable=True)
+    optimizer, quad_list, T_list = mapper.set_optimizer(frames, fused=True)     # csrc/adam.hip: one launch, step count on device
     for grp, lr in zip(optimizer.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):
-        grp["lr"] = torch.tensor(lr, device=device)          # capturable Adam wants tensor lrs on the device
+        grp["lr"] = lr
     prep = mapper.prepare_frames(frames)
     torch.manual_seed(seed)                                  # per-rank ray draws
     torch.cuda.manual_seed(seed)

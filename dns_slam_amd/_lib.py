@@ -24,6 +24,11 @@ class DnsGridMeta(C.Structure):
     ]
 
 
+class DnsAdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_uint64),
+                ("lr", C.c_float)]
+
+
 _P = C.c_void_p
 _U = C.c_uint32
 _I = C.c_int
@@ -48,6 +53,10 @@ SIGNATURES = {
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _P, _P]),
+    "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _P, _P]),
+    "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _P, _P, _P]),
+    "dns_group_slots": (C.c_int, [_P, _U, _U, _U, _U, _P, _P, _P, _P]),
+    "dns_adam_step": (C.c_int, [C.POINTER(DnsAdamTensor), _U, C.c_float, C.c_float, C.c_float, _P, _P]),
     "dns_composite_fwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P]),
     "dns_composite_bwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -1,0 +1,177 @@
+// Small fused helpers of the mapping iteration.
+//
+// (1) Total-variation smoothness of the coarse occupancy on an n^3 lattice (reference slams/mapping.py:151-157):
+//     loss = (sum (occ[i+1]-occ[i])^2 over x, y, z) / sample_points^3, occ = coarse[:, 0].  The reference spends a
+//     dozen launches (three slices, three pows, three sums) on it; here one reduction kernel and one gradient kernel.
+// (2) Grouping of points by weight-set id for the grouped MLP (the per-class dispatch of Mapper.fine_fn,
+//     slams/mapping.py:590-601, which loops over classes with two host syncs each): a counting sort into 128-slot
+//     tiles -- histogram, one-workgroup scan (padded tile offsets + tile -> group map), scatter -- instead of
+//     ~25 torch launches (argsort, cumsum, searchsorted, ...).
+#include "common.hpp"
+
+namespace dns {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void tv_fwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t n, float inv_norm,
+                                                     float* __restrict__ out) {
+  __shared__ float sh[4];
+  const uint32_t total = n * n * n;
+  float acc = 0.f;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
+    const float v = lat[(size_t)e * ld];
+    if (i + 1 < n) { const float d = lat[(size_t)(e + n * n) * ld] - v; acc += d * d; }
+    if (j + 1 < n) { const float d = lat[(size_t)(e + n) * ld] - v; acc += d * d; }
+    if (k + 1 < n) { const float d = lat[(size_t)(e + 1) * ld] - v; acc += d * d; }
+  }
+  acc = wave_sum_f(acc);
+  if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (sh[0] + sh[1] + sh[2] + sh[3]) * inv_norm);
+}
+
+// d_lat [n^3, ld]: column 0 = d loss / d occ, the other columns zero (the gradient of coarse[:, 0:1] padded back)
+__global__ __launch_bounds__(256) void tv_bwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t n, float inv_norm,
+                                                     const float* __restrict__ g, float* __restrict__ d_lat) {
+  const uint32_t total = n * n * n;
+  const float c = 2.0f * inv_norm * g[0];
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
+    const float v = lat[(size_t)e * ld];
+    float a = 0.f;
+    if (i + 1 < n) a -= lat[(size_t)(e + n * n) * ld] - v;
+    if (i > 0) a += v - lat[(size_t)(e - n * n) * ld];
+    if (j + 1 < n) a -= lat[(size_t)(e + n) * ld] - v;
+    if (j > 0) a += v - lat[(size_t)(e - n) * ld];
+    if (k + 1 < n) a -= lat[(size_t)(e + 1) * ld] - v;
+    if (k > 0) a += v - lat[(size_t)(e - 1) * ld];
+    float* row = d_lat + (size_t)e * ld;
+    row[0] = c * a;
+    for (uint32_t q = 1; q < ld; ++q) row[q] = 0.f;
+  }
+}
+
+// ---- grouping ---------------------------------------------------------------------------------------------------
+constexpr uint32_t GROUP_MAX = 256;
+
+__global__ __launch_bounds__(256) void group_hist_kernel(const int64_t* __restrict__ slot, uint32_t P, uint32_t G,
+                                                         uint32_t* __restrict__ counts) {
+  __shared__ uint32_t h[GROUP_MAX];
+  for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int64_t s = slot[p];
+    if (s >= 0 && s < (int64_t)G) atomicAdd(&h[(uint32_t)s], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < G; i += blockDim.x)
+    if (h[i]) atomicAdd(counts + i, h[i]);
+}
+
+// one workgroup: padded start of every group (multiples of 128), tile -> group map, cursors = padded starts
+__global__ __launch_bounds__(256) void group_scan_kernel(const uint32_t* __restrict__ counts, uint32_t G, uint32_t min_count,
+                                                         uint32_t n_tiles, uint32_t* __restrict__ cursor,
+                                                         int32_t* __restrict__ tile_group) {
+  __shared__ uint32_t start[GROUP_MAX + 1];
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+      start[g] = o;
+      o += (counts[g] + 127u) / 128u * 128u;
+    }
+    start[G] = o;
+  }
+  __syncthreads();
+  for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) cursor[g] = start[g];
+  for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    const uint32_t pos = t * 128u;
+    int grp = -1;
+    if (pos < start[G]) {
+      uint32_t lo = 0, hi = G;                     // last g with start[g] <= pos
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (start[mid] <= pos) lo = mid; else hi = mid;
+      }
+      if (counts[lo] >= min_count) grp = (int)lo;  // Mapper.fine_fn: a class needs more than one point (mapping.py:597)
+    }
+    tile_group[t] = grp;
+  }
+}
+
+__global__ __launch_bounds__(256) void group_scatter_kernel(const int64_t* __restrict__ slot, uint32_t P, uint32_t G,
+                                                            uint32_t* __restrict__ cursor, int32_t* __restrict__ row_index) {
+  // workgroup-aggregated cursors: LDS integer atomics rank the points of the workgroup inside each group, one global
+  // atomic per (workgroup, group) reserves the range
+  __shared__ uint32_t cnt[GROUP_MAX];
+  __shared__ uint32_t base[GROUP_MAX];
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  int64_t s = -1;
+  uint32_t rank = 0;
+  if (p < P) {
+    s = slot[p];
+    if (s >= 0 && s < (int64_t)G) rank = atomicAdd(&cnt[(uint32_t)s], 1u); else s = -1;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) base[i] = cnt[i] ? atomicAdd(cursor + i, cnt[i]) : 0u;
+  __syncthreads();
+  if (s >= 0) row_index[base[(uint32_t)s] + rank] = (int32_t)p;
+}
+
+}  // namespace dns
+
+using namespace dns;
+
+extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, float* out, void* stream) {
+  DNS_REQUIRE(lat && out && n >= 1 && ld >= 1, "dns_tv_fwd: bad argument");
+  DNS_REQUIRE((uint64_t)n * n * n < (1ull << 31), "dns_tv_fwd: lattice too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) {
+    set_error("dns_tv_fwd: memset failed");
+    return DNS_E_LAUNCH;
+  }
+  const uint32_t total = n * n * n;
+  const uint32_t blocks = (total + 255) / 256 < 512 ? (total + 255) / 256 : 512;
+  const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
+  hipLaunchKernelGGL(tv_fwd_kernel, dim3(blocks), dim3(256), 0, st, lat, ld, n, inv, out);
+  return check_launch("dns_tv_fwd");
+}
+
+extern "C" int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, const float* g, float* d_lat,
+                          void* stream) {
+  DNS_REQUIRE(lat && g && d_lat && n >= 1 && ld >= 1, "dns_tv_bwd: bad argument");
+  const uint32_t total = n * n * n;
+  const uint32_t blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+  const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
+  hipLaunchKernelGGL(tv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lat, ld, n, inv, g, d_lat);
+  return check_launch("dns_tv_bwd");
+}
+
+extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t min_count,
+                               uint32_t n_slots, uint32_t* ws, int32_t* row_index, int32_t* tile_group, void* stream) {
+  DNS_REQUIRE(slot_of_point && ws && row_index && tile_group, "dns_group_slots: NULL argument");
+  DNS_REQUIRE(n_groups >= 1 && n_groups <= GROUP_MAX, "dns_group_slots: n_groups %u out of range [1,%u]", n_groups, GROUP_MAX);
+  DNS_REQUIRE(n_slots % 128u == 0 && (uint64_t)n_slots >= (uint64_t)P + 127ull * n_groups,
+              "dns_group_slots: n_slots %u too small for %u points in %u groups", n_slots, P, n_groups);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* counts = ws;
+  uint32_t* cursor = ws + GROUP_MAX;
+  if (hipMemsetAsync(counts, 0, sizeof(uint32_t) * GROUP_MAX, st) != hipSuccess ||
+      hipMemsetAsync(row_index, 0xFF, sizeof(int32_t) * n_slots, st) != hipSuccess) {   // -1 = padding slot
+    set_error("dns_group_slots: memset failed");
+    return DNS_E_LAUNCH;
+  }
+  if (P) {
+    const uint32_t hb = (P + 255) / 256 < 512 ? (P + 255) / 256 : 512;
+    hipLaunchKernelGGL(group_hist_kernel, dim3(hb), dim3(256), 0, st, slot_of_point, P, n_groups, counts);
+  }
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, st, counts, n_groups, min_count, n_slots / 128u, cursor, tile_group);
+  if (P) hipLaunchKernelGGL(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index);
+  return check_launch("dns_group_slots");
+}

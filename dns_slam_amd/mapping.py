@@ -157,6 +157,8 @@ class Mapper:
         shp = pts.shape
         pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
         coarse = self.decoder.coarse_fn(pe, features=grid_pts)
+        if self.fused_losses:
+            return ops.tv_smoothness(coarse, n, sample_points)        # :151-157 in one reduction kernel
         occ = coarse[:, 0:1].reshape(*shp[:3], 1)          # intended shape of :152
         tv_x = torch.pow(occ[1:, ...] - occ[:-1, ...], 2).sum()
         tv_y = torch.pow(occ[:, 1:, ...] - occ[:, :-1, ...], 2).sum()
@@ -185,7 +187,7 @@ class Mapper:
         return new_list
 
     # ------------------------------------------------------------------ slams/mapping.py:438-468
-    def set_optimizer(self, target_frames, capturable=False):
+    def set_optimizer(self, target_frames, capturable=False, fused=False):
         net_para_list = list(self.decoder.parameters())
         net_para_list += self.fine_decoders.parameters_for(target_frames["label_dict"])
         quad_list, T_list = [], []
@@ -199,6 +201,11 @@ class Mapper:
             quad_list.append(quad)
             T_list.append(T)
         net_para_list = [p for p in net_para_list if p.numel() > 0]
+        if fused:
+            from .optim import FusedAdam
+            optimizer = FusedAdam([{"params": net_para_list, "lr": 0}, {"params": quad_list, "lr": 0},
+                                   {"params": T_list, "lr": 0}])
+            return optimizer, quad_list, T_list
         optimizer = torch.optim.Adam([{"params": net_para_list, "lr": 0},
                                       {"params": quad_list, "lr": 0},
                                       {"params": T_list, "lr": 0}], capturable=capturable)

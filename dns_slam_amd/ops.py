@@ -248,34 +248,22 @@ def mlp(x: torch.Tensor, params: torch.Tensor, n_in: int, n_out: int, n_neurons:
 
 
 def group_slots(slot_of_point: torch.Tensor, n_groups: int, min_count: int = 2):
-    """Device-side (sync-free) layout for the grouped MLP: points sorted by weight-set id and padded to 128-slot
-    tiles.  ``slot_of_point`` [P] int64 in [0, n_groups) (negative = no network).  Returns (row_index int32
-    [n_slots], tile_group int32 [n_slots/128], n_slots).  Groups with fewer than ``min_count`` points are skipped,
-    as ``Mapper.fine_fn`` does (slams/mapping.py:597: ``if index.sum() > 1``)."""
+    """Device-side (sync-free) layout for the grouped MLP: points counting-sorted by weight-set id into 128-slot tiles
+    (dns_group_slots).  ``slot_of_point`` [P] int64 in [0, n_groups) (negative = no network).  Returns (row_index
+    int32 [n_slots], tile_group int32 [n_slots/128], n_slots).  Groups with fewer than ``min_count`` points are
+    skipped, as ``Mapper.fine_fn`` does (slams/mapping.py:597: ``if index.sum() > 1``)."""
+    require_cuda(slot_of_point)
+    slot_of_point = slot_of_point.contiguous()
+    if slot_of_point.dtype != torch.int64:
+        slot_of_point = slot_of_point.to(torch.int64)
     P = slot_of_point.shape[0]
     dev = slot_of_point.device
     n_slots = (P + 127) // 128 * 128 + 128 * n_groups
-    key = torch.where(slot_of_point < 0, torch.full_like(slot_of_point, n_groups), slot_of_point)
-    order = torch.argsort(key, stable=True)
-    counts = torch.zeros(n_groups + 1, device=dev, dtype=torch.int64).scatter_add_(0, key, torch.ones_like(key))[:n_groups]
-    padded = (counts + 127) // 128 * 128
-    pad_end = torch.cumsum(padded, 0)
-    pad_start = pad_end - padded
-    cnt_start = torch.cumsum(counts, 0) - counts
-    skey = key[order]
-    valid = skey < n_groups
-    g = skey.clamp(max=n_groups - 1)
-    rank = torch.arange(P, device=dev) - cnt_start[g]
-    pos = pad_start[g] + rank
-    row_index = torch.full((n_slots,), -1, device=dev, dtype=torch.int32)
-    pos = torch.where(valid, pos, torch.full_like(pos, n_slots - 1))   # invalid points land on a padding slot
-    row_index[pos] = torch.where(valid, order, torch.full_like(order, -1)).to(torch.int32)
-    tiles = torch.arange(n_slots // 128, device=dev) * 128
-    tg = torch.searchsorted(pad_end, tiles, right=True)
-    live = (tg < n_groups)
-    tgc = tg.clamp(max=n_groups - 1)
-    live = live & (counts[tgc] >= min_count)
-    tile_group = torch.where(live, tgc, torch.full_like(tgc, -1)).to(torch.int32)
+    row_index = torch.empty(n_slots, device=dev, dtype=torch.int32)
+    tile_group = torch.empty(n_slots // 128, device=dev, dtype=torch.int32)
+    ws = torch.empty(512, device=dev, dtype=torch.int32)
+    check(lib.dns_group_slots(ptr(slot_of_point), P, n_groups, min_count, n_slots, ptr(ws), ptr(row_index), ptr(tile_group),
+                              stream_ptr()), "dns_group_slots")
     return row_index, tile_group, n_slots
 
 
@@ -478,3 +466,31 @@ def tracking_losses(pred_color, pred_depth, pred_var, pred_logits, gt_color, gt_
     return _LossFn.apply(pred_color, pred_depth, pred_var, pred_logits, None, None, gt_color, gt_depth, gt_label, valid,
                          None, lam, True, None)
 
+
+
+# ----------------------------------------------------------------------------- smoothness (TV)
+class _TvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lat, n, sample_points):
+        require_cuda(lat)
+        lat = lat.contiguous().float()
+        out = torch.empty(1, device=lat.device)
+        check(lib.dns_tv_fwd(ptr(lat), lat.shape[1], n, sample_points, ptr(out), stream_ptr()), "dns_tv_fwd")
+        ctx.save_for_backward(lat)
+        ctx.misc = (n, sample_points)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lat, = ctx.saved_tensors
+        n, sp = ctx.misc
+        d = torch.empty_like(lat)
+        check(lib.dns_tv_bwd(ptr(lat), lat.shape[1], n, sp, ptr(g.reshape(1).contiguous().float()), ptr(d), stream_ptr()),
+              "dns_tv_bwd")
+        return d, None, None
+
+
+def tv_smoothness(latents: torch.Tensor, n: int, sample_points: int) -> torch.Tensor:
+    """Total variation of latents[:, 0] on an n^3 lattice / sample_points^3 (slams/mapping.py:151-157).
+    latents [n^3, L] = the coarse decoder's output on the lattice points (x-major)."""
+    return _TvFn.apply(latents, n, sample_points)

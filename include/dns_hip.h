@@ -181,6 +181,38 @@ int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint3
                  float* d_color, float* d_depth, float* d_var, float* d_logits, float* d_fine, float* d_coarse,
                  void* stream);
 
+/* ---- fused Adam --------------------------------------------------------------------------------
+ * torch.optim.Adam.step with default betas / eps, no weight decay, no amsgrad (reference slams/mapping.py:464,910,
+ * slams/tracking.py:120-124,339) over up to 32 parameter tensors in one launch.  tensors [host]: per tensor the
+ * parameter, its gradient (NULL = skip), first / second moment buffers, element count and learning rate.
+ * state: 3 device floats {step count, 1-beta1^t, 1-beta2^t}; zero it when the optimiser is created ("fresh moments
+ * every optimize() call", slams/mapping.py:464); each call advances the count on the device. */
+typedef struct DnsAdamTensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  uint64_t n;
+  float lr;
+} DnsAdamTensor;
+int dns_adam_step(const DnsAdamTensor* tensors, uint32_t n_tensors, float beta1, float beta2, float eps,
+                  float* state, void* stream);
+
+/* ---- small fused helpers of the mapping iteration ----------------------------------------------
+ * Total-variation smoothness of coarse[:, 0] on an n^3 lattice, divided by sample_points^3
+ * (slams/mapping.py:151-157).  lat [n^3, ld] (the coarse latents, occupancy in column 0).  out: 1 float.
+ * Backward: d_lat [n^3, ld] = g[0] * d loss / d lat (column 0; the other columns are zeroed). */
+int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, float* out, void* stream);
+int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, const float* g, float* d_lat,
+               void* stream);
+
+/* Counting sort of P points by weight-set id into 128-slot tiles for dns_mlp_fwd/bwd (the per-class dispatch of
+ * Mapper.fine_fn, slams/mapping.py:590-601).  slot_of_point [P] int64 (negative = no network).  Outputs row_index
+ * [n_slots] (-1 = padding), tile_group [n_slots/128] (-1 = skip; groups with fewer than min_count points are
+ * skipped, mapping.py:597).  n_slots: multiple of 128, >= P + 127 * n_groups.  ws: 512 uint32 of scratch. */
+int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t min_count, uint32_t n_slots,
+                    uint32_t* ws, int32_t* row_index, int32_t* tile_group, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

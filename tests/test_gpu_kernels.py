@@ -330,3 +330,64 @@ def test_raygen_pose_gradient():
     loss.backward()
     assert_close(qp.grad.cpu(), qo.grad, what="d quat")
     assert_close(Tp.grad.cpu(), To.grad, what="d T")
+
+
+# ----------------------------------------------------------------------------------------- fused Adam / TV / grouping
+def test_fused_adam_matches_torch_adam():
+    """csrc/adam.hip vs torch.optim.Adam (reference slams/mapping.py:464): 25 steps, three lr groups, a frozen tensor."""
+    from dns_slam_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1706624,), (64, 80), (33, 64), (4,), (3,)]
+    p_ref = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    p_fus = [p.detach().clone().requires_grad_(True) for p in p_ref]
+    frozen_r, frozen_f = torch.ones(5, device=DEV), torch.ones(5, device=DEV)
+    groups = lambda ps, fr: [{"params": ps[:3], "lr": 5e-3}, {"params": [ps[3], fr], "lr": 5e-4}, {"params": [ps[4]], "lr": 1e-3}]
+    o_ref = torch.optim.Adam(groups(p_ref, frozen_r))
+    o_fus = FusedAdam(groups(p_fus, frozen_f))
+    for it in range(25):
+        for a, b in zip(p_ref, p_fus):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (10.0 ** ((it % 5) - 3))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o_ref.step()
+        o_fus.step()
+    for a, b in zip(p_ref, p_fus):
+        assert_close(b.detach().cpu(), a.detach().cpu(), rtol=1e-6, what="FusedAdam parameter")
+    assert torch.equal(frozen_f, torch.ones(5, device=DEV))
+
+
+@pytest.mark.parametrize("n,ld", [(11, 33), (63, 33), (5, 1)])
+def test_tv_smoothness_matches_torch(n, ld):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    lat = torch.randn(n ** 3, ld, generator=g).to(DEV).requires_grad_(True)
+    out = ops.tv_smoothness(lat, n, n + 1)
+    out.backward(torch.tensor(0.7, device=DEV))
+    lt = lat.detach().clone().requires_grad_(True)
+    occ = lt[:, 0:1].reshape(n, n, n, 1)
+    ref = (torch.pow(occ[1:] - occ[:-1], 2).sum() + torch.pow(occ[:, 1:] - occ[:, :-1], 2).sum()
+           + torch.pow(occ[:, :, 1:] - occ[:, :, :-1], 2).sum()) / ((n + 1) ** 3)
+    ref.backward(torch.tensor(0.7, device=DEV))
+    assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert_close(lat.grad.cpu(), lt.grad.cpu(), rtol=1e-5, what="TV gradient")
+
+
+def test_group_slots_layout():
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    P, G = 20000, 7
+    slot = torch.randint(-1, G - 1, (P,), generator=g)
+    slot[123] = G - 1                                       # a group with a single point -> skipped (min_count 2)
+    ri, tg, n_slots = ops.group_slots(slot.to(DEV), G, 2)
+    ri, tg = ri.cpu().long(), tg.cpu().long()
+    assert n_slots % 128 == 0 and ri.numel() == n_slots and tg.numel() == n_slots // 128
+    placed = ri[ri >= 0]
+    assert torch.equal(torch.sort(placed)[0], torch.nonzero(slot >= 0).reshape(-1))      # every routed point exactly once
+    for t in range(n_slots // 128):
+        rows = ri[t * 128:(t + 1) * 128]
+        rows = rows[rows >= 0]
+        if rows.numel():
+            grp = torch.unique(slot[rows])
+            assert grp.numel() == 1                          # one weight set per 128-slot tile
+            assert int(tg[t]) == (int(grp) if int((slot == int(grp)).sum()) >= 2 else -1)
+        else:
+            assert int(tg[t]) == -1 or int((slot == int(tg[t])).sum()) >= 2
