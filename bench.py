@@ -271,6 +271,23 @@ def main():
         "roofline": roofline,
         "kernel_breakdown": breakdown,
     }
+    # secondary line: forward-only full-image render of one 640x480 frame (frame_vis path), rays/s
+    try:
+        mapper.static_shapes = False
+        torch.cuda.synchronize()
+        rf = lambda: mapper.render_frame(frames["gt_color"][0], frames["gt_depth"][0], frames["gt_label"][0],
+                                         frames["est_c2w"][0], n_pts_batch=65536)
+        rf()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            rf()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 3
+        out["render_forward"] = {"rays_per_s": cam["H"] * cam["W"] / dt, "ray_samples_per_s": cam["H"] * cam["W"] * S / dt,
+                                 "ms_per_frame": dt * 1e3, "what": "full 640x480 frame, forward only, 65536-ray chunks"}
+    except Exception as e:
+        out["render_forward"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, cfg, bound, cam, frames)

@@ -772,11 +772,10 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
   const uint32_t max_cols = ((n_in + 31u) / 32u) * 32u + NNr > 2 * NNr ? ((n_in + 31u) / 32u) * 32u + NNr : 2 * NNr;
   const uint32_t out_cols = ((n_out + 31u) / 32u) * 32u + NNr;
   const size_t gemm_lds = (size_t)64 * (max_cols > out_cols ? max_cols : out_cols) * sizeof(float);
-  // Few, fat workgroups: every workgroup ends by adding its accumulators into the SAME small dW (28 KB), and same-address
-  // float atomics serialise (MI355X_MICROARCH: one row from every workgroup = 14x slower) -- the flush, not the MFMAs,
-  // dominated at 512 workgroups per GEMM.  ~2 workgroups per CU over the batched GEMMs; DNS_GEMM_BLOCKS overrides.
+  // Workgroups per GEMM: measured flat between 256 and 1024 (latency-bound staging, not the final atomic flush,
+  // sets the time; fewer than 256 starves the CUs).  DNS_GEMM_BLOCKS overrides.
   static const char* gb_env = getenv("DNS_GEMM_BLOCKS");
-  uint32_t gblocks = gb_env ? (uint32_t)atoi(gb_env) : 512u / (uint32_t)ng;
+  uint32_t gblocks = gb_env ? (uint32_t)atoi(gb_env) : 512u;
   if (gblocks < 1) gblocks = 1;
   uint32_t gtpb = (n_btiles + gblocks - 1) / gblocks;
   if (gtpb < 1) gtpb = 1;

@@ -366,6 +366,36 @@ class Mapper:
         pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)
         return pred_color, pred_depth, pred_depth_var, pred_logits, fine_latents, coarse_latents
 
+    # ------------------------------------------------------------------ slams/mapping.py:638-724 (without the plotting)
+    @torch.no_grad()
+    def render_frame(self, cur_gt_color, cur_gt_depth, cur_gt_label, cur_c2w, features=None, n_pts_batch=None, jitter=None):
+        """Full-image re-rendering of ``frame_vis``: all H*W rays of the frame (get_all_rays :540, box clip, ONE
+        sample_along_rays over the whole image :661), then the renderer in chunks of ``n_pts_batch`` rays (:675-694;
+        the reference's 1000 by default -- NB the tiled label layout (D1) makes the result depend on the chunk size).
+        Returns (pred_color [H,W,3], pred_depth [H,W], pred_label [H,W] = argmax of the composited logits)."""
+        H, W = self.H, self.W
+        n_pts_batch = n_pts_batch or self.cfg["mapping"].get("n_pts_batch", 1000)
+        dev = self.device
+        quat = get_quad_from_c2w(cur_c2w).to(dev)[None]
+        trans = cur_c2w[:3, 3].to(dev).float()[None]
+        f = lambda t: t.to(dev).float().contiguous()[None]
+        if jitter is None:
+            jitter = self.draw_jitter()
+        pix = torch.arange(H * W, device=dev)
+        rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = ops.raygen_sample(
+            quat, trans, pix, f(cur_gt_color), f(cur_gt_depth), f(cur_gt_label), (self.fx, self.fy, self.cx, self.cy),
+            self.bound, (0, H, 0, W), H * W, self.t_uniform, jitter[0], jitter[1])
+        S = z.shape[1]
+        colors, depths, labels = [], [], []
+        for start in range(0, H * W, n_pts_batch):
+            end = min(start + n_pts_batch, H * W)
+            code = torch.zeros(end - start, S, self.hidden_dim, device=dev) if features is None else features[start:end]
+            samples = {"rays_o": rays_o[start:end], "rays_d": rays_d[start:end], "gt_label": gt_label[start:end],
+                       "pts": pts[start:end], "z_vals": z[start:end], "features": code}
+            color, depth, _, logits, _, _ = self.renderer(samples, strict=False)
+            colors.append(color), depths.append(depth), labels.append(torch.argmax(logits, dim=-1))
+        return torch.cat(colors).reshape(H, W, 3), torch.cat(depths).reshape(H, W), torch.cat(labels).reshape(H, W)
+
     # ------------------------------------------------------------------ slams/mapping.py:887-907
     def iteration_loss(self, samples, lambda_lt=10.0, smooth=True, u_offset=None, u_jitter=None, strict=False):
         pred_color, pred_depth, _, pred_logits, fine_latents, coarse_latents = self.renderer(samples, strict=strict)

@@ -338,3 +338,39 @@ def test_graph_capture_of_full_iteration():
     assert all(l == l for l in losses)                      # finite
     assert len(set(losses)) > 20                            # fresh rays every replay (graph-safe RNG), not a frozen batch
     assert sum(losses[-5:]) < sum(losses[:5])
+
+
+def test_render_frame_matches_oracle_chunks():
+    """Full-image render (frame_vis, slams/mapping.py:638-724): whole-image sampling + chunked renderer vs the oracle."""
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    cam = synthetic.camera(H=24, W=32, fx=24.0, fy=24.0)
+    bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=3)
+    cfg = synthetic.default_cfg(n_pixels=200, hash_size=14, voxel_size=0.08, smooth_pts=10)
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    mapper = Mapper(cfg, dec, bound, cam, device=DEV)
+    mapper.set_decoder(frames)
+    randomise_(dec, 5)
+    with torch.no_grad():
+        dec.pe_fn.grid_fn.params.mul_(2000.0)
+    randomise_([mapper.fine_decoders.pool], 6)
+    torch.manual_seed(1)
+    jit = mapper.draw_jitter()
+    c2w = frames["est_c2w"][2]
+    col, dep, lab = mapper.render_frame(frames["gt_color"][2], frames["gt_depth"][2], frames["gt_label"][2], c2w,
+                                        n_pts_batch=200, jitter=jit)
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    from dns_slam_amd.common import get_quad_from_c2w
+    img5 = torch.cat((frames["gt_color"][2], frames["gt_depth"][2][..., None], frames["gt_label"][2][..., None]), -1)
+    so = sr.frame_samples(img5, get_quad_from_c2w(c2w), c2w[:3, 3].clone(), (24, 32, 24.0, 24.0, cam["cx"], cam["cy"]), bound,
+                          torch.arange(24 * 32), jit[0].cpu(), jit[1].cpu(), 32, 15)
+    cols, deps, labs = [], [], []
+    for st in range(0, 24 * 32, 200):
+        chunk = {k: so[k][st:st + 200] for k in ("pts", "z_vals", "gt_label", "features")}
+        rgb, depth, _, logits, _, _ = sr.mapper_renderer(om, chunk)
+        cols.append(rgb.detach()), deps.append(depth.detach()), labs.append(torch.argmax(logits, -1))
+    assert_close(col.cpu().reshape(-1, 3), torch.cat(cols), what="render_frame colour")
+    assert_close(dep.cpu().reshape(-1), torch.cat(deps), what="render_frame depth")
+    agree = (lab.cpu().reshape(-1) == torch.cat(labs)).float().mean()
+    assert float(agree) > 0.995          # argmax may flip where two logits tie to 1e-4
