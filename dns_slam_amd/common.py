@@ -102,3 +102,29 @@ def sample_along_rays(gt_depth, n_samples, n_surface, far_bb, device=None, jitte
         jitter = (t, torch.rand(n_surface))
     tu = torch.linspace(0.0, 1.0, steps=n_samples, device=dev) if n_samples > 0 else None
     return ops.sample_along_rays(gt_depth, far_bb, tu, jitter[0].to(dev), jitter[1].to(dev))
+
+
+_NHWC_CACHE = {}
+
+
+def features_channels_last(features):
+    """[R,C,h,w] stem features -> contiguous [R,h,w,C], cached per tensor (the reference up-samples the SAME maps in
+    every feature_matching call of an optimize(); the re-layout is done once)."""
+    key = (features.data_ptr(), features._version, tuple(features.shape))
+    hit = _NHWC_CACHE.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    nhwc = features.detach().permute(0, 2, 3, 1).contiguous().float()
+    _NHWC_CACHE["k"] = (key, nhwc)
+    return nhwc
+
+
+def feature_matching(H, W, K, pts_, refer_w2c, features, merge_fn):
+    """utils/common.py:645-679, same signature: project ``pts_`` [P,3] into the R reference frames, look the code up in the
+    [R,C,h,w] stem feature maps (bilinear-at-rounded-pixel, fused in csrc/feature.hip instead of F.interpolate to full
+    resolution), zero it where the projection is invalid, and merge the R views with ``merge_fn(pts - o, o, code)``."""
+    code, _mask = ops.feature_gather(pts_, refer_w2c, K, features_channels_last(features), H, W)
+    refer_c2w = torch.inverse(refer_w2c)
+    refer_o = refer_c2w[:, :3, 3]
+    refer_p = pts_[None, :, :] - refer_o[:, None, :]
+    return merge_fn(refer_p, refer_o, code)

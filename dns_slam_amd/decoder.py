@@ -88,9 +88,8 @@ class Merge(nn.Module):
 
     def forward(self, p, o, features=None):
         n_refer, n_points, C = features.shape
-        bound = self.bound.to(p.device)
-        p = (p - bound[:, 0]) / (bound[:, 1] - bound[:, 0])
-        pe = self.pe_fn(p.flatten(0, 1).float())
+        # (p - b0)/(b1 - b0) in fp64 (the RELATIVE vector normalised with the scene bound) fused with OneBlob
+        pe = ops.encode(p.flatten(0, 1), None, None, self.bound, self.pe_fn.n_bins, True, False)
         latents = self.decoder(torch.cat((pe, features.flatten(0, 1)), -1))
         return torch.mean(latents.reshape(n_refer, n_points, -1), 0)
 

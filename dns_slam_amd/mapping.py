@@ -24,7 +24,7 @@ from torch import nn
 
 from . import ops
 from . import tcnn_shim as tcnn
-from .common import get_opacity_loss, get_quad_from_c2w, get_rotation_from_quad
+from .common import feature_matching, get_opacity_loss, get_quad_from_c2w, get_rotation_from_quad
 from .decoder import fused_cat
 
 
@@ -313,6 +313,9 @@ class Mapper:
         if features is None:
             code = torch.zeros(N, S, self.hidden_dim, device=self.device)
         else:
+            if features.dim() == 5:
+                # stem feature maps [n_target, n_refer, C, h, w] + refer_frames: the 2-D branch of :533-551
+                features = self.match_features(target_frames, quad_list, T_list, refer_frames, features, pts, npf)
             d = gt_depth[:, None]
             front = (z < d * 0.95).float()
             back = (z > d * 1.05).float()
@@ -331,6 +334,36 @@ class Mapper:
             sel = lambda t: t[mask]
         return {"gt_color": sel(gt_color), "gt_depth": sel(gt_depth), "gt_label": sel(gt_label),
                 "rays_o": sel(rays_o), "rays_d": sel(rays_d), "pts": sel(pts), "z_vals": sel(z), "features": sel(code)}
+
+    # ------------------------------------------------------------------ slams/mapping.py:533-551
+    def match_features(self, target_frames, quad_list, T_list, refer_frames, features, pts, npf):
+        """Per target frame: choose each reference frame's pose (-1 = the frame itself, a frame that is also a target
+        = its pose under optimisation, else the stored keyframe pose; all detached, :534-545), project the frame's points
+        and merge the looked-up image codes (feature_matching + Decoder.merge).  -> code [N, S, hidden_dim]."""
+        K = torch.tensor([[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]])
+        bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self.device)
+        target_idx = list(target_frames["kf_idx"])
+        S = pts.shape[1]
+        out = []
+        for i in range(self.n_target_frame):
+            def pose_of(k):
+                R = get_rotation_from_quad(quad_list[k])
+                return torch.cat([torch.cat((R, T_list[k][:, None]), -1), bottom], dim=0).clone().detach()
+            refer_idx = list(refer_frames["kf_idx"][i])
+            w2c = []
+            for refer_id in refer_idx:
+                if refer_id == -1:
+                    c2w = pose_of(i)
+                elif refer_id in target_idx:
+                    c2w = pose_of(target_idx.index(refer_id))
+                else:
+                    c2w = refer_frames["est_c2w"][i][refer_idx.index(refer_id)].clone().detach().to(self.device).float()
+                w2c.append(torch.inverse(c2w))
+            w2c = torch.stack(w2c, 0)
+            p_i = pts[i * npf:(i + 1) * npf].flatten(0, 1)
+            code = feature_matching(self.H, self.W, K, p_i, w2c, features[i], self.decoder.merge)
+            out.append(code.reshape(npf, S, -1))
+        return torch.cat(out, 0)
 
     # ------------------------------------------------------------------ slams/mapping.py:590-601
     def fine_fn(self, pes, classes=None, features=None, strict=True):

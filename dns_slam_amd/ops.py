@@ -43,7 +43,7 @@ class _TimedLib:
     # argument index holding the number of units (points / slots / rays) a launch processes
     _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 9, "dns_mlp_bwd": 13,
                   "dns_composite_fwd": 3, "dns_composite_bwd": 3, "dns_raygen_sample": (14, 15), "dns_raygen_bwd": (7, 8),
-                  "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2}
+                  "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5)}
 
     def arm(self):
         self.records = []
@@ -494,3 +494,20 @@ def tv_smoothness(latents: torch.Tensor, n: int, sample_points: int) -> torch.Te
     """Total variation of latents[:, 0] on an n^3 lattice / sample_points^3 (slams/mapping.py:151-157).
     latents [n^3, L] = the coarse decoder's output on the lattice points (x-major)."""
     return _TvFn.apply(latents, n, sample_points)
+
+
+# ----------------------------------------------------------------------------- 2-D feature lookup
+def feature_gather(pts: torch.Tensor, refer_w2c: torch.Tensor, K, feat_nhwc: torch.Tensor, H: int, W: int):
+    """pts [P,3], refer_w2c [R,4,4], K 3x3 (host values), feat_nhwc [R,h,w,C] -> (code [R,P,C], mask [R,P] bool).
+    No gradient (frozen stem features, rounded pixel)."""
+    require_cuda(pts, refer_w2c, feat_nhwc)
+    pts = pts.detach().contiguous().float()
+    w2c = refer_w2c.detach().contiguous().float()
+    R, h, w, Cc = feat_nhwc.shape
+    P = pts.shape[0]
+    Kh = (C.c_float * 9)(*[float(v) for v in torch.as_tensor(K).reshape(-1).tolist()])
+    code = torch.empty(R, P, Cc, device=pts.device)
+    mask = torch.empty(R, P, device=pts.device, dtype=torch.uint8)
+    check(lib.dns_feature_gather(ptr(pts), ptr(w2c), Kh, ptr(feat_nhwc), R, P, Cc, h, w, H, W, ptr(code), ptr(mask),
+                                 stream_ptr()), "dns_feature_gather")
+    return code, mask.bool()

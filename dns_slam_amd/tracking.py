@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .common import get_quad_from_c2w, get_rotation_from_quad
+from .common import feature_matching, get_quad_from_c2w, get_rotation_from_quad
 
 
 class Tracker:
@@ -91,6 +91,12 @@ class Tracker:
         if features is None:
             code = torch.zeros(N, S, self.hidden_dim, device=self.device)
         else:
+            if features.dim() == 5:
+                # stem maps [1, n_refer, C, h, w] + refer_frames['est_w2c'] [n_refer,4,4]: slams/tracking.py:162-165
+                K = torch.tensor([[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]])
+                w2c = refer_frames["est_w2c"].clone().detach()
+                features = feature_matching(self.H, self.W, K, pts.flatten(0, 1), w2c, features[0],
+                                            self.decoder.merge).reshape(N, S, -1)
             d = gt_depth[:, None]
             trunc = (1.0 - (z < d * 0.95).float()) * (1.0 - (z > d * 1.05).float()) * (d > 0.0).float()
             code = features * trunc[..., None]

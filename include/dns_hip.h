@@ -213,6 +213,13 @@ int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points
 int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t min_count, uint32_t n_slots,
                     uint32_t* ws, int32_t* row_index, int32_t* tile_group, void* stream);
 
+/* ---- 2-D feature lookup (feature_matching / feature_searching, utils/common.py:632-673) --------
+ * pts [P,3] world points, w2c [R,16] row-major world->camera of the R reference frames, K [host, 9 floats] intrinsics,
+ * feat [R,h,w,C] stem feature maps, CHANNELS LAST.  code [R,P,C] = the bilinear (align_corners) value of the map at
+ * the rounded projected full-resolution pixel, zero where the projection is invalid; mask [R,P] uint8 (NULL = skip). */
+int dns_feature_gather(const float* pts, const float* w2c, const float* K, const float* feat, uint32_t R, uint32_t P,
+                       uint32_t C, int h, int w, int H, int W, float* code, uint8_t* mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,7 +171,40 @@ def golden_opacity():
     np.savez_compressed(os.path.join(OUT, "get_opacity_loss.npz"), **out)
 
 
+def golden_feature_matching():
+    """feature_matching (utils/common.py:645-679) with a recording merge_fn: returns [mean_r(code) | mean_r(refer_p)]."""
+    out = {}
+    for ci, (H, W, h, w, Cc, R, P, seed) in enumerate([(12, 16, 6, 8, 4, 2, 300, 0), (24, 32, 12, 16, 8, 3, 500, 1)]):
+        g = torch.Generator().manual_seed(400 + seed)
+        feats = torch.randn(R, Cc, h, w, generator=g)
+        fx = fy = float(W)
+        K = torch.tensor([[fx, 0.0, (W - 1) / 2.0], [0.0, fy, (H - 1) / 2.0], [0.0, 0.0, 1.0]])
+        w2c = []
+        for r in range(R):
+            Rm, T = rand_pose(410 + 10 * seed + r)
+            c2w = torch.eye(4)
+            c2w[:3, :3] = Rm
+            c2w[:3, 3] = T * 0.3
+            w2c.append(torch.inverse(c2w))
+        w2c = torch.stack(w2c, 0)
+        pts = torch.randn(P, 3, generator=g) * 2.0
+        rec = {}
+
+        def merge_fn(refer_p, refer_o, code_pts):
+            rec["refer_o"] = refer_o.clone()
+            return torch.cat((code_pts.mean(0), refer_p.mean(0)), -1)
+
+        res = C.feature_matching(H, W, K, pts, w2c, feats, merge_fn)
+        p = f"c{ci}_"
+        out.update({p + "dims": np.array([H, W, h, w, Cc, R, P]), p + "K": K.numpy(), p + "w2c": w2c.numpy(),
+                    p + "features": feats.numpy(), p + "pts": pts.numpy(), p + "out": res.numpy(),
+                    p + "refer_o": rec["refer_o"].numpy()})
+    out["n_cases"] = np.array(2)
+    np.savez_compressed(os.path.join(OUT, "feature_matching.npz"), **out)
+
+
 if __name__ == "__main__":
+    golden_feature_matching()
     golden_get_samples()
     golden_by_class()
     golden_all_rays()

@@ -1,0 +1,140 @@
+"""GPU parity of the 2-D feature branch: feature_matching against the IMPORTED reference's golden
+outputs, Decoder.merge against the oracle (values + gradients), and the Mapper's per-frame reference-pose logic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import feature_ref as fr
+from oracle import render_math as rm
+from oracle import slam_ref as sr
+from util import assert_close, oracle_from_product, randomise_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_feature_matching_golden(golden_dir):
+    from dns_slam_amd.common import feature_matching
+    g = np.load(os.path.join(golden_dir, "feature_matching.npz"))
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        H, W, h, w, Cc, R, P = [int(v) for v in g[p + "dims"]]
+        rec = {}
+
+        def merge_fn(refer_p, refer_o, code_pts):
+            rec["o"] = refer_o
+            return torch.cat((code_pts.mean(0), refer_p.mean(0)), -1)
+
+        out = feature_matching(H, W, _t(g[p + "K"]), _t(g[p + "pts"]).to(DEV), _t(g[p + "w2c"]).to(DEV),
+                               _t(g[p + "features"]).to(DEV), merge_fn).cpu()
+        ref = _t(g[p + "out"])
+        # a projected coordinate within float rounding of x.5 may round to the neighbouring pixel: allow a few rows
+        bad = ((out - ref).abs() > 1e-5 * ref.abs().max()).any(-1)
+        assert float(bad.float().mean()) <= 0.01, f"case {ci}: {int(bad.sum())} of {P} points differ"
+        assert_close(rec["o"].cpu(), _t(g[p + "refer_o"]), rtol=1e-6, what="refer_o")
+
+
+def test_feature_gather_vs_oracle_large():
+    """Replica-like shapes: [3, 64, 120, 160] maps looked up at 240 x 320 resolution, 20 000 points."""
+    from dns_slam_amd.common import feature_matching
+    g = torch.Generator().manual_seed(0)
+    R, C, h, w, H, W, P = 3, 64, 120, 160, 240, 320, 20000
+    feats = torch.randn(R, C, h, w, generator=g)
+    K = torch.tensor([[200.0, 0, (W - 1) / 2], [0, 200.0, (H - 1) / 2], [0, 0, 1.0]])
+    w2c = torch.eye(4).repeat(R, 1, 1)
+    w2c[:, :3, 3] = torch.randn(R, 3, generator=g) * 0.2
+    pts = torch.randn(P, 3, generator=g) * torch.tensor([1.5, 1.0, 1.0]) + torch.tensor([0.0, 0.0, -3.0])
+    ident = lambda p_, o_, c_: c_
+    code_o = fr.feature_matching(H, W, K, pts, w2c, feats, ident)
+    code_p = feature_matching(H, W, K, pts.to(DEV), w2c.to(DEV), feats.to(DEV), ident).cpu()
+    bad = ((code_o - code_p).abs() > 1e-5).any(-1)
+    assert float(bad.float().mean()) < 0.002
+    assert float((code_o.abs().sum(-1) > 0).float().mean()) > 0.3          # the test does hit valid pixels
+
+
+def test_merge_module_matches_oracle():
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    bound = synthetic.load_bound(synthetic.ROOM0_BOUND)
+    cfg = synthetic.default_cfg(hash_size=12, voxel_size=0.2)
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    randomise_(dec, 2)
+    g = torch.Generator().manual_seed(1)
+    R, P = 3, 700
+    p = (torch.randn(R, P, 3, generator=g) * 2.0)
+    o = torch.randn(R, 3, generator=g)
+    code = torch.randn(R, P, 64, generator=g)
+    gy = torch.randn(P, 32, generator=g)
+    pp = p.to(DEV).requires_grad_(True)
+    y = dec.merge(pp, o.to(DEV), code.to(DEV))
+    (y * gy.to(DEV)).sum().backward()
+    params = dec.merge.decoder.params.detach().cpu().clone().requires_grad_(True)
+    po = p.clone().requires_grad_(True)
+    yo = fr.merge_forward(params, bound, po, o, code)
+    (yo * gy).sum().backward()
+    assert_close(y.cpu(), yo, what="merge fwd")
+    assert_close(dec.merge.decoder.params.grad.cpu()[:112 * 32 + 32 * 32], params.grad[:112 * 32 + 32 * 32], what="merge dparams")
+    bad = ((pp.grad.cpu() - po.grad).abs() > 1e-4 * po.grad.abs().max()).any(-1)
+    assert float(bad.float().mean()) < 0.002
+
+
+def test_mapper_feature_branch_matches_oracle():
+    """get_target_samples with stem feature maps + refer_frames (slams/mapping.py:533-557) vs the oracle composition."""
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.encoder import ResNet
+    from dns_slam_amd.mapping import Mapper
+    cam = synthetic.camera(H=60, W=80, fx=60.0, fy=60.0)
+    bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=0)
+    cfg = synthetic.default_cfg(n_pixels=240, hash_size=14, voxel_size=0.08, smooth_pts=10)
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    randomise_(dec, 4)
+    mapper = Mapper(cfg, dec, bound, cam, device=DEV)
+    mapper.set_decoder(frames)
+    mapper.is_BA = True
+    _, ql, Tl = mapper.set_optimizer(frames)
+    frames = dict(frames)
+    frames["kf_idx"] = [0, 10, 20, 30]
+    # per target frame two references: an older keyframe that is also a target (or a foreign one) and itself (-1)
+    refer = {"kf_idx": [[99, -1], [0, -1], [10, -1], [20, -1]],
+             "gt_color": torch.stack([torch.stack([frames["gt_color"][max(i - 1, 0)], frames["gt_color"][i]]) for i in range(4)]),
+             "est_c2w": torch.stack([torch.stack([frames["est_c2w"][max(i - 1, 0)], frames["est_c2w"][i]]) for i in range(4)])}
+    stem = ResNet(seed=3).to(DEV)
+    feats = stem(refer["gt_color"].to(DEV))
+    assert feats.shape == (4, 2, 64, 30, 40)
+    torch.manual_seed(9)
+    prep = mapper.prepare_frames(frames)
+    pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+    s = mapper.get_target_samples(frames, ql, Tl, refer_frames=refer, features=feats, prep=prep, pix_idx=pix, jitter=jit)
+    # oracle
+    sd = stem.conv_blocks.state_dict()
+    fo = fr.stem_forward(refer["gt_color"], sd["conv1.weight"].cpu(), sd["bn1.weight"].cpu(), sd["bn1.bias"].cpu(),
+                         sd["bn1.running_mean"].cpu(), sd["bn1.running_var"].cpu())
+    assert_close(feats.cpu(), fo, rtol=1e-4, what="stem features")
+    K = torch.tensor([[cam["fx"], 0.0, cam["cx"]], [0.0, cam["fy"], cam["cy"]], [0.0, 0.0, 1.0]])
+    params = dec.merge.decoder.params.detach().cpu()
+    npf = pix.numel() // 4
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]])
+    pose = lambda k: torch.cat([torch.cat((rm.rotation_from_quad(ql[k].detach().cpu()), Tl[k].detach().cpu()[:, None]), -1), bottom], 0)
+    codes = []
+    for i in range(4):
+        img5 = torch.cat((frames["gt_color"][i], frames["gt_depth"][i][..., None], frames["gt_label"][i][..., None]), -1)
+        fs = sr.frame_samples(img5, ql[i].detach().cpu(), Tl[i].detach().cpu(), camt, bound, pix.cpu()[i * npf:(i + 1) * npf],
+                              jit[0].cpu(), jit[1].cpu(), 32, 15)
+        first = refer["est_c2w"][i][0] if i == 0 else pose(i - 1)         # 99 is foreign -> stored pose; else a target's pose
+        w2c = torch.stack([torch.inverse(first), torch.inverse(pose(i))])
+        merge = lambda p_, o_, c_: fr.merge_forward(params, bound, p_, o_, c_)
+        code = fr.feature_matching(cam["H"], cam["W"], K, fs["pts"].flatten(0, 1), w2c, fo[i], merge).reshape(npf, 47, -1)
+        codes.append(code * rm.truncation_mask(fs["z_vals"], fs["gt_depth"])[..., None])
+    code_o = torch.cat(codes, 0)
+    got = s["features"].cpu()
+    bad = ((got - code_o).abs() > 1e-4 * code_o.abs().max()).flatten(1).any(-1)
+    assert float(bad.float().mean()) < 0.01, f"{int(bad.sum())} rays differ"
+    assert float((code_o.abs().sum(-1) > 0).float().mean()) > 0.05

@@ -114,3 +114,21 @@ def test_opacity_loss(golden_dir):
             torch.testing.assert_close(occ.grad, _t(g[p + "grad_occ"]), rtol=1e-6, atol=1e-9)
         else:
             assert not fs.requires_grad      # the zero-branch returns constants (common.py:799-800)
+
+
+def test_feature_matching_golden(golden_dir):
+    """2-D feature branch (utils/common.py:645-679) against the imported reference with a recording merge_fn."""
+    from oracle import feature_ref as fr
+    g = _load(golden_dir, "feature_matching.npz")
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        H, W, h, w, Cc, R, P = [int(v) for v in g[p + "dims"]]
+        rec = {}
+
+        def merge_fn(refer_p, refer_o, code_pts):
+            rec["o"] = refer_o
+            return torch.cat((code_pts.mean(0), refer_p.mean(0)), -1)
+
+        out = fr.feature_matching(H, W, _t(g[p + "K"]), _t(g[p + "pts"]), _t(g[p + "w2c"]), _t(g[p + "features"]), merge_fn)
+        assert torch.equal(out, _t(g[p + "out"]))
+        assert torch.equal(rec["o"], _t(g[p + "refer_o"]))
