@@ -46,6 +46,16 @@ class FineDecoderPool(nn.Module):
     def keys(self):
         return self.slot.keys()
 
+    def __getitem__(self, class_id):
+        """``fine_decoders[class_id]`` as the reference uses it (slams/mapping.py:600,1139): a Network whose flat
+        ``params`` shares the pool row's storage (evaluation / inspection; training goes through the pool)."""
+        net = tcnn.Network(self.n_in, self.n_out, self.net_cfg)
+        net.params = nn.Parameter(self.pool.data[self.slot[int(class_id)]], requires_grad=False)
+        return net
+
+    def items(self):
+        return [(c, self[c]) for c in self.slot]
+
     def __contains__(self, k):
         return int(k) in self.slot
 
