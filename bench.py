@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-step progress on stderr")
+    ap.add_argument("--no-render-forward", action="store_true", help="skip the secondary full-image render line")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -262,6 +263,15 @@ def main():
             ach = fl / (ms / 1e3) / 1e12
             roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / calls}
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/), if present
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = pmc["entry_points"].get(name)
+            if ent and pmc.get("workload") == args.workload:
+                roofline["traffic"] = ent["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = pmc["source"]
+        except Exception:
+            pass
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -273,6 +283,8 @@ def main():
     }
     # secondary line: forward-only full-image render of one 640x480 frame (frame_vis path), rays/s
     try:
+        if args.no_render_forward:
+            raise RuntimeError("skipped (--no-render-forward)")
         mapper.static_shapes = False
         torch.cuda.synchronize()
         rf = lambda: mapper.render_frame(frames["gt_color"][0], frames["gt_depth"][0], frames["gt_label"][0],
@@ -306,7 +318,7 @@ def mlp_flops(name, kernel_times, wl, n_points, steps):
     per_step_fwd = 2 * (n_points * (2 * macs(80, 33) + macs(112, 3) + macs(112, 8)) + lattice * macs(80, 33))
     if name == "dns_mlp_fwd":
         return per_step_fwd * steps
-    return 3 * per_step_fwd * steps        # recompute + data grads + weight grads
+    return 2 * per_step_fwd * steps        # data gradients + weight gradients (hidden activations are kept, no recompute)
 
 
 if __name__ == "__main__":

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(256) void loss_point_sums_kernel(LossCfg c, const f
                                                               const uint8_t* __restrict__ valid,
                                                               float* __restrict__ sums) {
   __shared__ float sh[4];
-  const uint64_t E = (uint64_t)c.N * c.S * c.L;
+  const uint32_t E = c.N * c.S * c.L;               // < 2^32 (checked on the host): 32-bit divides, not 64-bit
   float slt = 0.f, sfs = 0.f, sop = 0.f, nfr = 0.f, nom = 0.f;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t p = (uint32_t)(e / c.L), k = (uint32_t)(e - (uint64_t)p * c.L);
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    const uint32_t p = e / c.L, k = e - p * c.L;
     const uint32_t n = p / c.S;
     if (!ray_valid(valid, n)) continue;
     const float f = fine[e];
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
                                                              const float* __restrict__ gt_depth,
                                                              const uint8_t* __restrict__ valid, float* __restrict__ d_fine,
                                                              float* __restrict__ d_coarse) {
-  const uint64_t E = (uint64_t)c.N * c.S * c.L;
+  const uint32_t E = c.N * c.S * c.L;
   const float g = g_total[0];
   const float clt = g * out[O_CLT], cfs = g * out[O_CFS], cop = g * out[O_COP];
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t p = (uint32_t)(e / c.L), k = (uint32_t)(e - (uint64_t)p * c.L);
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    const uint32_t p = e / c.L, k = e - p * c.L;
     const uint32_t n = p / c.S;
     float df = 0.f, dc = 0.f;
     if (ray_valid(valid, n)) {
@@ -277,6 +277,7 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
   DNS_REQUIRE(C == 0 || (pred_logits && gt_label), "dns_loss_sums: C > 0 needs logits and labels");
   DNS_REQUIRE(!tracker || pred_var, "dns_loss_sums: tracker mode needs pred_var");
   DNS_REQUIRE(tracker || (fine && coarse && z && L >= 1 && S >= 1), "dns_loss_sums: mapper mode needs fine, coarse, z");
+  DNS_REQUIRE(tracker || (uint64_t)N * S * L < (1ull << 32) - (1ull << 22), "dns_loss_sums: N*S*L must stay below 2^32");
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
   hipLaunchKernelGGL(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
                      pred_logits, gt_color, gt_depth, gt_label, valid, sums);

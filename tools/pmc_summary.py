@@ -1,0 +1,65 @@
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/pmc_traffic.json + a text table.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-timing
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py ... (same)
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg2 r01
+
+Units / corrections (MI355X_MICROARCH.md, HBM): counters are KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
+coalesced (16 B/lane) streaming read -> doubled for the streaming kernels (MLP, losses, compositing, transpose, Adam);
+8-byte gather kernels (encode_*, hashgrid_bwd_binned) are uncalibrated and left RAW (a lower bound).  WRITE_SIZE is exact."""
+import collections, csv, glob, json, os, sys
+
+fetch_dir, write_dir, workload, tag = sys.argv[1:5]
+ENTRY = {  # C-ABI entry point -> kernels it launches
+    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_data_kernel", "gemm_tn_kernel"],
+    "dns_encode_fwd": ["encode_fwd_kernel"], "dns_encode_bwd": ["encode_bwd_kernel", "dgrid_transpose_kernel", "hashgrid_bwd_binned_kernel"],
+    "dns_composite_fwd": ["composite_fwd_kernel"], "dns_composite_bwd": ["composite_bwd_kernel"],
+    "dns_loss_sums": ["loss_ray_sums_kernel", "loss_point_sums_kernel"], "dns_loss_bwd": ["loss_ray_bwd_kernel", "loss_point_bwd_kernel"],
+    "dns_raygen_sample": ["depth_max_kernel", "raygen_sample_kernel"], "dns_raygen_bwd": ["raygen_bwd_reduce_kernel", "raygen_bwd_pose_kernel"],
+    "dns_adam_step": ["adam_tick_kernel", "adam_step_kernel"], "dns_tv_fwd": ["tv_fwd_kernel"], "dns_tv_bwd": ["tv_bwd_kernel"],
+    "dns_group_slots": ["group_hist_kernel", "group_scan_kernel", "group_scatter_kernel"],
+}
+GATHER = ("encode_fwd_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel")
+
+
+def load(d):
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if "dns::" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dns::", "").split("<")[0]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"]) * 1024.0
+    return agg
+
+
+fe, wr = load(fetch_dir), load(write_dir)
+kern = {}
+for k in sorted(set(fe) | set(wr)):
+    n = max(fe.get(k, [0])[0], wr.get(k, [0])[0]) or 1
+    raw_f = fe.get(k, [0, 0.0])[1] / n
+    f = raw_f if k in GATHER else 2.0 * raw_f
+    w = wr.get(k, [0, 0.0])[1] / n
+    kern[k] = {"launches": n, "fetch_raw_bytes": raw_f, "fetch_bytes": f, "write_bytes": w, "fetch_corrected": k not in GATHER}
+entries = {}
+for e, ks in ENTRY.items():
+    present = [k for k in ks if k in kern]
+    if not present:
+        continue
+    calls = max(kern[k]["launches"] for k in present)
+    tot = sum((kern[k]["fetch_bytes"] + kern[k]["write_bytes"]) * kern[k]["launches"] for k in present) / calls
+    entries[e] = {"hbm_bytes_per_launch": tot, "kernels": present}
+out = {"workload": workload, "source": f"profiles/{tag}_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                      "FETCH doubled for streaming kernels, raw for 8-byte gather kernels)",
+       "kernels": kern, "entry_points": entries}
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+with open(f"profiles/{tag}_pmc_traffic.txt", "w") as fh:
+    fh.write(__doc__ + "\n")
+    fh.write(f"{'kernel':34s} {'launches':>8s} {'FETCH raw MB':>13s} {'FETCH used MB':>14s} {'WRITE MB':>10s}\n")
+    for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]['fetch_bytes'] + kv[1]['write_bytes'])):
+        fh.write(f"{k:34s} {v['launches']:8d} {v['fetch_raw_bytes'] / 1e6:13.2f} {v['fetch_bytes'] / 1e6:14.2f} {v['write_bytes'] / 1e6:10.2f}\n")
+    fh.write("\nper C-ABI entry point (bytes per call):\n")
+    for e, v in sorted(entries.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        fh.write(f"{e:22s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB   ({', '.join(v['kernels'])})\n")
+print(open(f"profiles/{tag}_pmc_traffic.txt").read())
