@@ -300,6 +300,27 @@ def main():
                                  "ms_per_frame": dt * 1e3, "what": "full 640x480 frame, forward only, 65536-ray chunks"}
     except Exception as e:
         out["render_forward"] = {"error": f"{type(e).__name__}: {e}"}
+    # secondary line: the tracking optimise step (slams/tracking.py:313-340), 500 rays, coarse-only render, pose-only Adam
+    try:
+        if args.no_render_forward:
+            raise RuntimeError("skipped (--no-render-forward)")
+        from dns_slam_amd.tracking import Tracker
+        tcfg = dict(cfg)
+        tracker = Tracker(tcfg, mapper.decoder, bound, cam, device=device)
+        cur = {"gt_color": frames["gt_color"][1], "gt_depth": frames["gt_depth"][1], "gt_label": frames["gt_label"][1]}
+        n_it = tcfg["tracking"]["n_iters"]
+        res = {}
+        for mode in ("eager", "graph"):
+            tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, fused=True, graph=(mode == "graph"))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, fused=True, graph=(mode == "graph"))
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t1) * 1e3 / n_it
+        out["tracking"] = {"ms_per_iter_eager": res["eager"], "ms_per_iter_graph_incl_capture": res["graph"],
+                           "rays": tcfg["tracking"]["n_pixels"], "samples_per_ray": S, "iters_per_frame": n_it}
+    except Exception as e:
+        out["tracking"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, cfg, bound, cam, frames)

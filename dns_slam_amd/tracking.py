@@ -10,6 +10,8 @@ The process loop (``run`` :229: data loading, mapper synchronisation, logging) i
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -33,6 +35,7 @@ class Tracker:
         self.hidden_dim = decoder.hidden_dim
         self.pe_dim = decoder.pe_dim
         self.border = 20
+        self.static_shapes = False        # True: device-side jitter draws, no host work per iteration (hipGraph-capturable)
         self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
 
     # slams/tracking.py:85-96 -- masked means written as weighted sums (no boolean-mask gather / host sync)
@@ -50,13 +53,16 @@ class Tracker:
         return (ce * w).sum() / w.sum()
 
     # slams/tracking.py:108-126
-    def set_optimizer(self, c2w, idx=None):
+    def set_optimizer(self, c2w, idx=None, fused=False):
         lr = self.cam_lr
         quad = get_quad_from_c2w(c2w).clone().detach().to(self.device).requires_grad_(True)
         T = c2w[:3, 3].clone().detach().to(self.device).float().requires_grad_(True)
         lrT = lr * 0.2 if self.seperate_LR else lr
-        optimizer = torch.optim.Adam([{"params": [T], "lr": lrT}, {"params": [quad], "lr": lr}])
-        return optimizer, quad, T
+        groups = [{"params": [T], "lr": lrT}, {"params": [quad], "lr": lr}]
+        if fused:
+            from .optim import FusedAdam
+            return FusedAdam(groups), quad, T
+        return torch.optim.Adam(groups), quad, T
 
     def draw_pixels(self):
         b = self.border
@@ -64,6 +70,15 @@ class Tracker:
 
     def draw_jitter(self):
         ns = self.n_surface_ray
+        if self.static_shapes:
+            if getattr(self, "_force_mask", None) is None or self._force_mask.numel() != ns:
+                m = torch.zeros(ns, dtype=torch.bool)
+                m[ns // 2 + 1] = True
+                self._force_mask = m.to(self.device)
+                self._half = torch.full((ns,), 0.5, device=self.device)
+            t = torch.rand(ns, device=self.device)
+            t = torch.where(self._force_mask & ~(t == 0.5).any(), self._half, t)
+            return t, torch.rand(ns, device=self.device)
         t = torch.rand(ns)
         if not torch.any(t == 0.5):
             t[ns // 2 + 1] = 0.5
@@ -119,11 +134,33 @@ class Tracker:
         pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)
         return pred_color, pred_depth, pred_depth_var, pred_logits
 
+    @contextlib.contextmanager
+    def frozen_scene(self):
+        """Tracking optimises the pose only (slams/tracking.py:120-124).  The reference still lets autograd compute the
+        gradients of the (deep-copied) scene parameters and throws them away; here the scene is frozen for the duration of
+        the loop, which skips every weight-gradient GEMM and the hash-grid scatter without changing the pose gradients."""
+        params = [p for p in self.decoder.parameters() if p.requires_grad]
+        for p in params:
+            p.requires_grad_(False)
+        try:
+            yield
+        finally:
+            for p in params:
+                p.requires_grad_(True)
+
     # slams/tracking.py:313-340
-    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None):
-        """Optimise (quat, T) of one frame against the frozen scene; returns the best-loss camera tensor [7]."""
+    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None, fused=False, graph=False):
+        """Optimise (quat, T) of one frame against the frozen scene; returns the best-loss camera tensor [7].
+        ``graph=True`` captures ONE iteration (sampling, render, losses, backward, fused Adam, keep-best) into a hipGraph
+        and replays it n_iters times: tracking is 30-50 tiny latency-bound iterations per frame."""
         n_iters = self.n_iters if n_iters is None else n_iters
-        optimizer, quad, T = self.set_optimizer(est_c2w)
+        with self.frozen_scene():
+            if graph:
+                return self._track_frame_graphed(cur_frames, est_c2w, n_iters, features)
+            return self._track_frame_eager(cur_frames, est_c2w, n_iters, features, fused)
+
+    def _track_frame_eager(self, cur_frames, est_c2w, n_iters, features, fused):
+        optimizer, quad, T = self.set_optimizer(est_c2w, fused=fused)
         frames = dict(cur_frames)
         frames["est_quad"], frames["est_T"] = quad, T
         prep = self.prepare_frame(cur_frames)
@@ -143,3 +180,46 @@ class Tracker:
             loss.backward()
             optimizer.step()
         return best_cam, best_loss
+
+    def _track_frame_graphed(self, cur_frames, est_c2w, n_iters, features):
+        self.static_shapes = True
+        optimizer, quad, T = self.set_optimizer(est_c2w, fused=True)
+        frames = dict(cur_frames)
+        frames["est_quad"], frames["est_T"] = quad, T
+        prep = self.prepare_frame(cur_frames)
+        state = {"best_loss": torch.full((), float("inf"), device=self.device),
+                 "best_cam": torch.cat((quad, T), 0).detach().clone()}
+
+        def one_iter():
+            optimizer.zero_grad(set_to_none=True)
+            samples = self.get_target_samples(frames, features=features, prep=prep)
+            pc, pd, pv, pl = self.renderer(samples)
+            loss, _ = ops.tracking_losses(pc, pd, pv, pl, samples["gt_color"], samples["gt_depth"], samples["gt_label"],
+                                          samples["mask"], (self.lambda_p, self.lambda_d, self.lambda_l))
+            with torch.no_grad():
+                better = loss < state["best_loss"]
+                state["best_loss"].copy_(torch.where(better, loss.detach(), state["best_loss"]))
+                state["best_cam"].copy_(torch.where(better, torch.cat((quad, T), 0).detach(), state["best_cam"]))
+            loss.backward()
+            optimizer.step()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        saved = (quad.detach().clone(), T.detach().clone())
+        with torch.cuda.stream(side):
+            for _ in range(2):                           # warm-up (allocator, lazy kernel attributes), then rewind
+                one_iter()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            quad.copy_(saved[0]); T.copy_(saved[1])
+            for m, v in optimizer.state.values():
+                m.zero_(); v.zero_()
+            optimizer._dev_state.zero_()
+            state["best_loss"].fill_(float("inf"))
+            state["best_cam"].copy_(torch.cat((quad, T), 0))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_iter()
+        for _ in range(n_iters - 1):
+            g.replay()
+        return state["best_cam"], state["best_loss"]
