@@ -472,12 +472,73 @@ class Mapper:
             terms["smooth_loss"] = smooth_loss
         return loss, terms
 
+    # ------------------------------------------------------------------ slams/mapping.py:764-836
+    def decoder_init(self, decoder_idx, gt_color, gt_depth, gt_label, gt_c2w, cur_c2w, n_iters=100, n_rays=300,
+                     features=None, smooth=True):
+        """Warm-up of freshly added per-class decoders on the current frame: ``n_iters`` Adam steps (lr = training.lr) on
+        (decoder + fine decoders) with ``n_rays`` rays drawn class-balanced over ``decoder_idx`` only
+        (get_samples_by_uniq_class, utils/common.py:364-403: first class takes the remainder, a 1-pixel class is
+        repeated, an absent class is skipped), fixed pose, losses = depth + colour + label + smoothness + fs/opacity
+        (no latent term, :823-824)."""
+        dev = self.device
+        color = gt_color.to(dev).float().contiguous()[None]
+        depth = gt_depth.to(dev).float().contiguous()[None]
+        label = gt_label.to(dev).float().contiguous()[None]
+        lab = label[0].reshape(-1)
+        order = torch.argsort(lab, stable=True)
+        classes, cnt = torch.unique_consecutive(lab[order], return_counts=True)
+        st = torch.cumsum(cnt, 0) - cnt
+        cls_host = classes.tolist()                                       # one sync per decoder_init call
+        n_class = len(decoder_idx)
+        n_k = n_rays // n_class
+        starts, counts = [], []
+        for i, c in enumerate(decoder_idx):
+            m = n_rays - n_k * (n_class - 1) if i == 0 else n_k
+            if float(c) in cls_host:
+                j = cls_host.index(float(c))
+                starts.append(st[j].expand(m))
+                counts.append(cnt[j].expand(m))
+        starts, counts = torch.cat(starts), torch.cat(counts)
+        quat = get_quad_from_c2w(cur_c2w).to(dev)[None]
+        trans = cur_c2w[:3, 3].to(dev).float()[None]
+        from .optim import FusedAdam
+        params = [p for p in list(self.decoder.parameters()) + [self.fine_decoders.pool] if p.numel() > 0]
+        optimizer = FusedAdam([{"params": params, "lr": self.lr}])
+        tr = self.cfg["training"]
+        lam = (self.lambda_p, self.lambda_d, self.lambda_l, 0.0, self.lambda_fs, self.lambda_opacity, tr["opacity_sigma"], 0.05)
+        loss = None
+        for _ in range(n_iters):
+            optimizer.zero_grad()
+            u = torch.rand(starts.numel(), device=dev, dtype=torch.float64)
+            pix = order[starts + torch.minimum((u * counts).to(torch.int64), counts - 1)]
+            jit = self.draw_jitter()
+            rays_o, rays_d, pts, gc, gd, gl, inside, z = ops.raygen_sample(
+                quat, trans, pix, color, depth, label, (self.fx, self.fy, self.cx, self.cy), self.bound,
+                (0, self.H, 0, self.W), pix.numel(), self.t_uniform, jit[0], jit[1])
+            code = torch.zeros(z.shape[0], z.shape[1], self.hidden_dim, device=dev) if features is None else features
+            samples = {"pts": pts, "z_vals": z, "gt_label": gl, "features": code, "rays_d": rays_d}
+            pc, pd, _, pl, fine, coarse = self.renderer(samples, strict=True)
+            loss, _t = ops.mapping_losses(pc, pd, pl, fine, coarse, gc, gd, gl, z, lam)
+            if smooth:
+                loss = loss + self.lambda_sm * self.smoothness(sample_points=tr["smooth_pts"])
+            loss.backward()
+            optimizer.step()
+        return loss
+
     # ------------------------------------------------------------------ slams/mapping.py:839-949
     def optimize(self, n_iters, cur_idx, target_frames, features=None, smooth=True):
         """Iteration driver.  ``target_frames`` is what ``set_target_refer_frames`` (:329, host-side keyframe
         bookkeeping, out of scope) returns: gt_color/gt_depth/gt_label per frame, est_c2w, label_dict."""
         self.is_BA = cur_idx >= self.start_optimize_idx
         new_decoder_idx = self.set_decoder(target_frames)
+        if len(new_decoder_idx) > 0 and cur_idx > 50:                   # :857-868 (first_frame_optimized is the caller's state)
+            cur_class = set(torch.unique(target_frames["gt_label"][-1]).tolist())
+            warm = [c for c in new_decoder_idx if float(c) in cur_class]
+            new_decoder_idx = warm
+            if warm:
+                self.decoder_init(warm, target_frames["gt_color"][-1], target_frames["gt_depth"][-1],
+                                  target_frames["gt_label"][-1], target_frames.get("gt_c2w", target_frames["est_c2w"])[-1],
+                                  target_frames["est_c2w"][-1], smooth=smooth)
         optimizer, quad_list, T_list = self.set_optimizer(target_frames)
         optimizer.param_groups[0]["lr"] = self.lr
         optimizer.param_groups[1]["lr"] = self.BA_cam_lr * self.is_BA
@@ -495,7 +556,12 @@ class Mapper:
             loss.backward()
             optimizer.step()
         bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self.device)
-        R = get_rotation_from_quad(quad_list[-1].detach())
-        cur_c2w = torch.cat([torch.cat((R, T_list[-1].detach()[:, None]), -1), bottom], dim=0)
+        pose = lambda k: torch.cat([torch.cat((get_rotation_from_quad(quad_list[k].detach()), T_list[k].detach()[:, None]), -1),
+                                    bottom], dim=0)
+        if self.is_BA:                                                  # :914-926: refined keyframe poses go back to the caller
+            for i in range(1, self.n_target_frame - 1):
+                target_frames["est_c2w"][i] = pose(i).to(target_frames["est_c2w"][i].device)
+        cur_c2w = pose(self.n_target_frame - 1)
+        target_frames["est_c2w"][-1] = cur_c2w.clone().to(target_frames["est_c2w"][-1].device)
         self.last_quad_list, self.last_T_list = quad_list, T_list
         return cur_c2w, terms

@@ -407,3 +407,33 @@ def test_tracker_track_frame_eager_and_graphed_reduce_pose_error():
         err0 = float((c2w[:3, 3] - frames["est_c2w"][2][:3, 3]).norm())
         err1 = float((cam7[4:].cpu() - frames["est_c2w"][2][:3, 3]).norm())
         assert err1 < err0 * 1.5                 # does not diverge (40 tiny-lr steps move the pose by <= 0.04)
+
+
+def test_optimize_driver_and_decoder_init():
+    """Mapper.optimize (slams/mapping.py:839-949) end to end incl. the decoder warm-up (:764-836) for classes that appear
+    after frame 50: the warm-up only draws rays of the new classes, the driver returns a valid pose and writes the
+    refined keyframe poses back."""
+    cfg, bound, cam, frames, dec, mapper = _setup(n_pixels=400)
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    m = Mapper(cfg, dec, bound, cam, device=DEV)
+    fr = dict(frames)
+    fr["est_c2w"] = frames["est_c2w"].clone()
+    fr["label_dict"] = [0, 1, 2, 3]
+    torch.manual_seed(0)
+    c2w0, terms0 = m.optimize(6, 20, fr, smooth=True)                   # no warm-up before frame 50
+    assert set(m.fine_decoders.keys()) == {0, 1, 2, 3}
+    fr["label_dict"] = sorted(frames["label_dict"])                      # classes 4..7 appear
+    pool_before = m.fine_decoders.pool.detach().clone()
+    c2w1, terms1 = m.optimize(6, 60, fr, smooth=True)                   # > 50: decoder_init runs for the new classes
+    assert set(m.fine_decoders.keys()) == set(frames["label_dict"])
+    for c in (4, 5, 6, 7):
+        s_ = m.fine_decoders.slot[c]
+        assert float((m.fine_decoders.pool[s_] - pool_before[s_]).abs().max()) > 0       # warmed up / trained
+    assert c2w1.shape == (4, 4) and bool(torch.isfinite(c2w1).all())
+    R = c2w1[:3, :3]
+    assert torch.allclose(R @ R.t(), torch.eye(3, device=DEV), atol=1e-4)
+    assert all(float(v) == float(v) for v in terms1.values())
+    assert not torch.equal(fr["est_c2w"][1], frames["est_c2w"][1])      # BA pose write-back (idx >= start_optimize_idx)
+    assert torch.equal(fr["est_c2w"][0], frames["est_c2w"][0])          # the oldest frame stays fixed (:457)
