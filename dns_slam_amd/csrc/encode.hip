@@ -281,6 +281,8 @@ struct BinPlan {
   uint32_t chunk_rows;                    // rows per chunk
   uint32_t strided_dense;                 // dense levels: one contiguous run of points per thread
   uint32_t job_prefix[DNS_MAX_LEVELS + 1];  // prefix sum over levels of chunks[l] * slices[l]
+  uint32_t group_prefix[DNS_MAX_LEVELS + 1];  // prefix sum over levels of slices[l]: a group = one (level, slice)
+  uint32_t xcd_major;                     // 1: blockIdx -> (xcd = b % 8, q = b / 8), a group's chunks adjacent in q
   uint32_t chunks[DNS_MAX_LEVELS];
   uint32_t slices[DNS_MAX_LEVELS];
 };
@@ -340,12 +342,36 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
   (void)frexpf(mx, &ex);                         // mx < 2^ex
   const float scale = ldexpf(1.0f, 40 - ex);     // |w*g| * scale < 2^40; 2^22 contributions stay below 2^62
   const double inv_scale = (double)ldexpf(1.0f, ex - 40);
-  // job -> (level, chunk, slice)
-  uint32_t l = 0;
-  while (l + 1 < plan.n_levels && blockIdx.x >= plan.job_prefix[l + 1]) ++l;
-  const uint32_t rem = blockIdx.x - plan.job_prefix[l];
+  // job -> (level, chunk, slice).  All chunks of one (level, slice) group sweep the SAME points, so they should share
+  // an L2: workgroups are dealt round-robin over the 8 XCDs (xcd = blockIdx % 8), hence group g goes to XCD g % 8 and
+  // its chunks sit at consecutive q = blockIdx / 8 -- they start together on that XCD's 32 CUs and 7 of 8 point reads
+  // hit L2 instead of each XCD pulling the slice from HBM on its own.
+  uint32_t l = 0, chunk, slice;
+  if (plan.xcd_major) {
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint32_t q = blockIdx.x >> 3;
+    bool found = false;
+    for (l = 0; l < plan.n_levels; ++l) {
+      const uint32_t g_lo = plan.group_prefix[l], g_hi = plan.group_prefix[l + 1];
+      const uint32_t first = g_lo + ((xcd + 8u - (g_lo & 7u)) & 7u);          // first group of this level on this XCD
+      const uint32_t cnt = first < g_hi ? (g_hi - first + 7u) / 8u : 0u;
+      const uint32_t nj = cnt * plan.chunks[l];
+      if (q < nj) {
+        slice = first + 8u * (q / plan.chunks[l]) - g_lo;
+        chunk = q % plan.chunks[l];
+        found = true;
+        break;
+      }
+      q -= nj;
+    }
+    if (!found) return;                          // padding workgroup of the XCD-major grid (uniform exit)
+  } else {
+    while (l + 1 < plan.n_levels && blockIdx.x >= plan.job_prefix[l + 1]) ++l;
+    const uint32_t rem = blockIdx.x - plan.job_prefix[l];
+    chunk = rem / plan.slices[l];
+    slice = rem % plan.slices[l];
+  }
   const uint32_t ns = plan.slices[l];
-  const uint32_t chunk = rem / ns, slice = rem % ns;
   const uint32_t base = chunk * plan.chunk_rows;
   const uint32_t size = lv.size[l];
   const uint32_t rows = min(plan.chunk_rows, size - base);
@@ -391,24 +417,40 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
         xn[2] = xin[(size_t)pn * 3 + 2];
       }
     }
-    if (!live || (gg.x == 0.f && gg.y == 0.f)) continue;
-    const float g0 = gg.x * scale, g1 = gg.y * scale;                    // exact: power-of-two scale
-    float f[3];
-    uint32_t g[3];
+    const bool work = live && !(gg.x == 0.f && gg.y == 0.f);
+    const float gs0 = gg.x * scale, gs1 = gg.y * scale;                  // exact: power-of-two scale
+    float fsave[3];
+    uint32_t gsave[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
       const float fl = floorf(pos);
-      g[a] = (uint32_t)(int)fl;
-      f[a] = pos - fl;
+      gsave[a] = (uint32_t)(int)fl;
+      fsave[a] = pos - fl;
     }
+    uint32_t hit_mask = 0;
+    const uint32_t* g = gsave;
+    const uint32_t rows_eff = work ? rows : 0u;                          // idle lanes never hit
+    // Only ~1/8 of the corners of a hashed level land in this chunk.  Issuing the two ds_add_u64 under each corner's own
+    // branch costs 16 LDS atomic instructions per step with ~8 live lanes each (the LDS atomic pipe is paid per
+    // instruction, not per lane); instead: a branch-free pass builds the lane's 8-bit hit mask, then the wave pops one
+    // hit per lane per round -- max-hits-per-lane rounds (3-4) of two denser atomics.
+    uint32_t hits = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const uint32_t local = grid_row(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, size, hashed) - base;
-      if (local < rows) {
-        const float w = ((c & 1) ? f[0] : 1.0f - f[0]) * ((c & 2) ? f[1] : 1.0f - f[1]) * ((c & 4) ? f[2] : 1.0f - f[2]);
-        atomicAdd(bins + 2 * local, (unsigned long long)__float2ll_rn(w * g0));
-        atomicAdd(bins + 2 * local + 1, (unsigned long long)__float2ll_rn(w * g1));
+      hits |= (local < rows_eff ? 1u : 0u) << c;
+    }
+    hit_mask = hits;
+    while (__any(hit_mask != 0)) {
+      if (hit_mask) {
+        const uint32_t c = (uint32_t)__ffs((int)hit_mask) - 1u;
+        hit_mask &= hit_mask - 1u;
+        const uint32_t local = grid_row(gsave[0] + (c & 1u), gsave[1] + ((c >> 1) & 1u), gsave[2] + ((c >> 2) & 1u), res, size, hashed) - base;
+        const float w = ((c & 1u) ? fsave[0] : 1.0f - fsave[0]) * ((c & 2u) ? fsave[1] : 1.0f - fsave[1]) *
+                        ((c & 4u) ? fsave[2] : 1.0f - fsave[2]);
+        atomicAdd(bins + 2 * local, (unsigned long long)__float2ll_rn(w * gs0));
+        atomicAdd(bins + 2 * local + 1, (unsigned long long)__float2ll_rn(w * gs1));
       }
     }
   }
@@ -515,7 +557,11 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     static const char* ns_env = getenv("DNS_SCATTER_SLICES");
     BinPlan plan;
     plan.n_levels = lv.n_levels;
-    plan.chunk_rows = 8192;
+    static const char* rows_env = getenv("DNS_SCATTER_ROWS");
+    plan.chunk_rows = rows_env ? (uint32_t)atoi(rows_env) : 8192u;
+    DNS_REQUIRE(plan.chunk_rows >= 256 && plan.chunk_rows <= 8192, "DNS_SCATTER_ROWS must be in [256, 8192]");
+    static const char* order_env = getenv("DNS_SCATTER_ORDER");
+    plan.xcd_major = (order_env && order_env[0] == 'l') ? 0u : 1u;
     static const char* walk = getenv("DNS_SCATTER_WALK");
     plan.strided_dense = (walk && walk[0] == 'c') ? 0u : 1u;
     uint32_t total_chunks = 0, chunk_of[DNS_MAX_LEVELS];
@@ -527,7 +573,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     if (ns < 1) ns = 1;
     const uint32_t max_ns = (P + 1023) / 1024;                 // at least ~one point per thread
     if (ns > max_ns) ns = max_ns ? max_ns : 1;
-    uint32_t jobs = 0;
+    uint32_t jobs = 0, groups = 0;
+    uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t l = 0; l < lv.n_levels; ++l) {
       plan.chunks[l] = chunk_of[l];
       // dense (coarse) levels: every corner of every point lands in the chunk -> ~4x the work per point
@@ -535,13 +582,24 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       if (nsl > max_ns) nsl = max_ns ? max_ns : 1;
       plan.slices[l] = nsl;
       plan.job_prefix[l] = jobs;
+      plan.group_prefix[l] = groups;
+      for (uint32_t g = groups; g < groups + nsl; ++g) per_xcd[g & 7u] += chunk_of[l];
       jobs += chunk_of[l] * nsl;
+      groups += nsl;
     }
-    for (uint32_t l = lv.n_levels; l <= DNS_MAX_LEVELS; ++l) plan.job_prefix[l] = jobs;
+    for (uint32_t l = lv.n_levels; l <= DNS_MAX_LEVELS; ++l) {
+      plan.job_prefix[l] = jobs;
+      plan.group_prefix[l] = groups;
+    }
+    if (plan.xcd_major) {
+      uint32_t mx = 0;
+      for (int i = 0; i < 8; ++i) mx = per_xcd[i] > mx ? per_xcd[i] : mx;
+      jobs = 8u * mx;                                          // padded: workgroups past an XCD's last job exit at once
+    }
     const size_t lds_bytes = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      (void)hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 2 * (int)sizeof(unsigned long long));
       attr_set = true;
     }
     uint32_t* gmax = (uint32_t*)(ws + (size_t)P * lv.n_levels * 2);

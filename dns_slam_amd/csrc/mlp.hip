@@ -650,6 +650,219 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnBatch batch) {
   flush(cur_group);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradients, direct-operand form (default).  v_mfma_f32_16x16x4_f32 takes A[16 x 4] with lane l holding
+// A[i = l&15][k = l>>4] and B[4 x 16] with lane l holding B[k = l>>4][j = l&15]; the K axis is the point axis.  A wave
+// that reads one float4 per lane from a row-major [points x 64] matrix -- lane l: point p0 + (l>>4), channels
+// 4*(l&15) .. +3, i.e. 1 KB contiguous per load -- holds in component c of that float4 exactly the A (or B) operand
+// of the 16-channel subset S_c = {4i + c}.  So operands go from global memory straight into the MFMA with no LDS
+// staging, no transposes and no barriers: acc[ca][cb] += mfma(a.comp[ca], b.comp[cb]) accumulates dW[4i+ca][4j+cb]
+// over the wave's points, 16 MFMAs per (64 x 64) block of dW per 4 points.
+//
+// Work split: a "unit" is one <= 64 x <= 64 block of one weight matrix (dW_in splits in two column halves when
+// n_in > 64, so a network has up to 4 units: dW_in lo/hi, dW_hidden, dW_out -- 16 MFMAs per step each, i.e. balanced).
+// ONE launch per network; wave w of every workgroup owns unit w and sweeps all slots of the workgroup's tiles, so the
+// four SIMDs of a CU run the four units side by side, the per-launch fixed cost (ramp, prologue, flush) is paid once
+// instead of once per matrix, and no cross-wave reduction exists.  Loads are issued D steps ahead; the flush goes
+// through a wave-private LDS transpose so that each atomic instruction covers 256 contiguous bytes of one dW row.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t GEMM_MAX_TPB = 64;        // 128-slot tiles per workgroup (their weight-set ids are staged in LDS)
+
+struct GemmUnit {
+  const float* A;          // [slots or rows x lda], M <= 64 channels -> rows of dW
+  const float* B;          // [slots or rows x ldb], N <= 64 channels (pre-offset to the unit's first column)
+  const int32_t* a_index;  // optional slot -> row (-1 = padding)
+  const int32_t* b_index;
+  float* C;                // dW block origin (+ group * c_stride)
+  uint32_t lda, ldb, ldc, M, N;
+  uint32_t kind;           // bit 0: a_index, bit 1: b_index, bit 2: A rows are float4-addressable
+};
+
+struct GemmRoles {
+  GemmUnit u[4];
+  const int32_t* tile_group;  // per 128 slots (NULL: one weight set)
+  uint32_t n_units, n_slots, tiles_per_block, c_stride, strided;
+};
+
+// The loop body is branch-free around its loads on purpose: every load is unconditional on a clamped address (and
+// the A operand zeroed at use when the point is not real), so the compiler's vmcnt bookkeeping keeps D steps of data
+// loads plus the NEXT round's index loads in flight instead of draining the queue at a conditional.
+template <bool AIDX, bool BIDX, bool AVEC>
+__device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slots, uint32_t bt0, uint32_t tstride, uint32_t ntl,
+                                              const int* __restrict__ grp_lds, float* __restrict__ wlds, uint32_t c_stride) {
+  constexpr int D = 8;                       // load steps (1 KB per operand each) in flight
+  const uint32_t lane = threadIdx.x & 63u;
+  const float* __restrict__ A = u.A;
+  const float* __restrict__ B = u.B;
+  const int32_t* __restrict__ ai = u.a_index;
+  const int32_t* __restrict__ bi = u.b_index;
+  const uint32_t lda = u.lda, ldb = u.ldb, M = u.M, N = u.N;
+  const uint32_t nsteps = ntl * 32u;         // 32 steps of 4 points per 128-slot tile
+  const uint32_t k = lane >> 4, c4 = 4u * (lane & 15u);
+  // Columns past M / N are CLAMPED, not zeroed: D[i][j] depends on A row i and B column j only, so whatever such a lane
+  // reads lands in output rows >= M / columns >= N, which the flush never writes.  Invalid POINTS (K axis: padding
+  // slots, dead tiles, the ragged tail) read row 0 and have their A operand zeroed at use.
+  uint32_t a_col[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a_col[e] = AVEC ? (c4 < M ? c4 : 0u) : min(c4 + e, M - 1u);
+  const uint32_t b_col = c4 < N ? c4 : 0u;   // N % 4 == 0 (host-checked)
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[D], rb[D];
+  int ia[D], ib[D];                          // slot -> row of the step whose data is requested next round
+  bool rv[D];                                // this lane's point of the step is real
+  auto slot_ok = [&](uint32_t q, uint32_t& slot) -> bool {
+    slot = (bt0 + (q >> 5) * tstride) * 128u + (q & 31u) * 4u + k;
+    const bool live = q < nsteps && grp_lds[min(q >> 5, ntl - 1u)] >= 0;    // uniform
+    return live && slot < n_slots;
+  };
+  auto issue_idx = [&](int& xa, int& xb, uint32_t q) {
+    if (!AIDX && !BIDX) return;
+    uint32_t slot;
+    const bool ok = slot_ok(q, slot);
+    const uint32_t sl = ok ? slot : 0u;      // slot 0 exists
+    if (AIDX) xa = ai[sl];
+    if (BIDX) xb = bi[sl];
+  };
+  auto issue_data = [&](float4& a, float4& b, bool& valid, int xa, int xb, uint32_t q) {
+    uint32_t slot;
+    bool ok = slot_ok(q, slot);
+    if (AIDX) ok = ok && xa >= 0;
+    if (BIDX) ok = ok && xb >= 0;
+    valid = ok;
+    const uint32_t arow = ok ? (AIDX ? (uint32_t)xa : slot) : 0u;
+    const uint32_t brow = ok ? (BIDX ? (uint32_t)xb : slot) : 0u;
+    const float* pa = A + (size_t)arow * lda;
+    const float* pb = B + (size_t)brow * ldb;
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    if (AVEC) {
+      const nt4 t = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(pa + a_col[0]));   // read once: stream
+      a = make_float4(t[0], t[1], t[2], t[3]);
+    } else {
+      a.x = pa[a_col[0]]; a.y = pa[a_col[1]]; a.z = pa[a_col[2]]; a.w = pa[a_col[3]];
+    }
+    const nt4 t = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(pb + b_col));
+    b = make_float4(t[0], t[1], t[2], t[3]);
+  };
+  auto flush = [&](int grp) {
+    if (grp < 0) return;
+    // wave-private LDS transpose: D tile (ca, cb), lane (i>>2)*16 + j, register i&3 holds dW[4i+ca][4j+cb]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        reinterpret_cast<float4*>(wlds)[(a * 4 + b) * 64 + lane] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    __builtin_amdgcn_wave_barrier();
+    float* C = u.C + (size_t)grp * c_stride;
+    const uint32_t col = lane, cb = col & 3u, j = col >> 2;
+    for (uint32_t row = 0; row < M; ++row) {
+      const uint32_t ca = row & 3u, i = row >> 2;
+      const float v = wlds[(((ca * 4u + cb) * 64u + (i >> 2) * 16u + j) * 4u) + (i & 3u)];
+      if (col < N && v != 0.f) atomicAdd(C + (size_t)row * u.ldc + col, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // prologue: indices of steps 0..D-1, then their data + the indices of steps D..2D-1
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    ia[d] = 0;
+    ib[d] = 0;
+    issue_idx(ia[d], ib[d], (uint32_t)d);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    issue_data(ra[d], rb[d], rv[d], ia[d], ib[d], (uint32_t)d);
+    issue_idx(ia[d], ib[d], (uint32_t)(d + D));
+    asm volatile("" ::: "memory");
+  }
+  int cur = -2;
+  for (uint32_t q0 = 0; q0 < nsteps; q0 += D) {
+    if ((q0 & 31u) == 0) {
+      const int grp = grp_lds[q0 >> 5];
+      if (grp >= 0 && grp != cur) {
+        flush(cur);
+        cur = grp;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const uint32_t q = q0 + d;
+      const bool va = rv[d];
+      const float av[4] = {va ? ra[d].x : 0.f, va ? ra[d].y : 0.f, va ? ra[d].z : 0.f, va ? ra[d].w : 0.f};
+      const float bv[4] = {rb[d].x, rb[d].y, rb[d].z, rb[d].w};
+      issue_data(ra[d], rb[d], rv[d], ia[d], ib[d], q + D);
+      issue_idx(ia[d], ib[d], q + 2 * D);
+      asm volatile("" ::: "memory");         // keep the loads in program order: vmcnt waits are positional
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  flush(cur);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_roles_kernel(GemmRoles r) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* grp_lds = reinterpret_cast<int*>(lds);
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n_btiles = (r.n_slots + 127u) / 128u;
+  // One weight set: tiles are dealt round-robin (tile = blockIdx + t * gridDim), so that at any moment the whole grid
+  // reads one dense window of each matrix (DRAM pages are consumed by neighbouring workgroups together).  Grouped
+  // launches keep contiguous tile ranges instead: a workgroup then meets few weight sets and flushes rarely.
+  const bool strided = r.strided != 0;
+  const uint32_t bt0 = strided ? blockIdx.x : blockIdx.x * r.tiles_per_block;
+  const uint32_t tstride = strided ? gridDim.x : 1u;
+  if (bt0 >= n_btiles) return;               // uniform per workgroup
+  const uint32_t ntl = strided ? (n_btiles - bt0 + tstride - 1u) / tstride : min(r.tiles_per_block, n_btiles - bt0);
+  for (uint32_t t = threadIdx.x; t < ntl; t += blockDim.x) grp_lds[t] = r.tile_group ? r.tile_group[bt0 + t * tstride] : 0;
+  __syncthreads();                           // the only workgroup barrier: waves are independent from here on
+  const GemmUnit& u = r.u[wave];             // blockDim.x = 64 * n_units
+  float* wlds = lds + GEMM_MAX_TPB + wave * 4096u;
+  switch (u.kind) {
+    case 4: gemm_unit_run<false, false, true>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
+    case 6: gemm_unit_run<false, true, true>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
+    case 5: gemm_unit_run<true, false, true>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
+    case 0: gemm_unit_run<false, false, false>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
+    case 1: gemm_unit_run<true, false, false>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
+    default: break;                          // host never launches other kinds
+  }
+}
+
+// Builds the unit list of one network's <= 3 weight-gradient GEMMs; returns false when some operand does not fit the
+// direct form (the caller then uses the LDS-staged kernel).
+static bool make_roles(const GemmTnArgs* g, int ng, GemmRoles& r) {
+  r.n_units = 0;
+  for (int k = 0; k < ng; ++k) {
+    const GemmTnArgs& a = g[k];
+    if (a.M > 64u || a.N > 128u || (a.N & 3u) || (a.ldb & 3u) || (((uintptr_t)a.B) & 15u)) return false;
+    const bool avec = (a.M & 3u) == 0 && (a.lda & 3u) == 0 && ((((uintptr_t)a.A) & 15u) == 0);
+    const uint32_t kind = (a.a_index ? 1u : 0u) | (a.b_index ? 2u : 0u) | (avec ? 4u : 0u);
+    if (!(kind == 4u || kind == 6u || kind == 5u || kind == 0u || kind == 1u)) return false;
+    for (uint32_t c0 = 0; c0 < a.N; c0 += 64u) {
+      if (r.n_units == 4u) return false;
+      GemmUnit& u = r.u[r.n_units++];
+      u.A = a.A; u.B = a.B + c0; u.a_index = a.a_index; u.b_index = a.b_index; u.C = a.C + c0;
+      u.lda = a.lda; u.ldb = a.ldb; u.ldc = a.ldc; u.M = a.M; u.N = (a.N - c0 < 64u) ? a.N - c0 : 64u;
+      u.kind = kind;
+    }
+  }
+  for (uint32_t k = r.n_units; k < 4u; ++k) r.u[k] = r.u[0];
+  r.tile_group = g[0].tile_group;
+  r.n_slots = g[0].n_slots;
+  r.c_stride = g[0].c_stride;
+  return r.n_units > 0;
+}
+
 static bool shape_ok(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
   return (nn == 32 || nn == 64) && (nl == 1 || nl == 2) && n_in >= 8 && n_in <= 128 && (n_in % 8) == 0 && n_out >= 1 &&
          n_out <= 64;
@@ -798,7 +1011,29 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
     if (gtpb < 1) gtpb = 1;
     gblocks = (n_btiles + gtpb - 1) / gtpb;
     for (int k = 0; k < 3; ++k) batch.g[k].tiles_per_block = gtpb;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
+    static const char* gemm_env = getenv("DNS_GEMM");
+    if (gemm_env && gemm_env[0] == 's') {     // LDS-staged 32x32x2 form, kept for A/B measurement
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
+    } else {
+      GemmRoles roles;
+      if (make_roles(batch.g, ng, roles)) {
+        // two workgroups per CU by default (each wave = one unit on its own SIMD); tiles per workgroup bounded by the
+        // LDS weight-set table
+        uint32_t nb = gb_env ? (uint32_t)atoi(gb_env) : 512u;   // 2 workgroups per CU: measured 275 vs 285 us at 256
+        if (nb > n_btiles) nb = n_btiles;
+        const uint32_t nb_min = (n_btiles + GEMM_MAX_TPB - 1) / GEMM_MAX_TPB;
+        if (nb < nb_min) nb = nb_min;
+        if (nb < 1) nb = 1;
+        roles.tiles_per_block = (n_btiles + nb - 1) / nb;
+        nb = (n_btiles + roles.tiles_per_block - 1) / roles.tiles_per_block;
+        static const char* order_env = getenv("DNS_GEMM_ORDER");     // 'c' contiguous / 's' strided, for A/B
+        roles.strided = order_env ? (order_env[0] == 's') : (roles.tile_group == nullptr);
+        const size_t roles_lds = (GEMM_MAX_TPB + (size_t)roles.n_units * 4096) * sizeof(float);
+        hipLaunchKernelGGL(gemm_roles_kernel, dim3(nb), dim3(64 * roles.n_units), roles_lds, st, roles);
+      } else {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
+      }
+    }
   }
   return check_launch("dns_mlp_bwd(weights)");
 }

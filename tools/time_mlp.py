@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dns_slam_amd import ops
-P = 262144
+P = int(os.environ.get("DNS_P", 262144))
 n_in, n_out, nn, nl = [int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (112, 8, 64, 2))]
 dev = "cuda"
 x = torch.randn(P, n_in, device=dev, requires_grad=True)
