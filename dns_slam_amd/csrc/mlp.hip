@@ -23,35 +23,105 @@
 
 namespace dns {
 
+#ifdef DNS_TRACE
+// developer instrumentation (tools/mlp_trace.py builds a separate library with -DDNS_TRACE): issue-time stamps of one
+// wave of two workgroups, 100 MHz wall clock
+__device__ unsigned long long dns_trace_buf[2][64];
+#define DNS_STAMP(i)                                                                                         \
+  do {                                                                                                       \
+    const uint32_t i_ = (i);                                                                                 \
+    if ((threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == 300) && i_ < 64)                             \
+      dns_trace_buf[blockIdx.x ? 1 : 0][i_] = wall_clock64();                                                \
+  } while (0)
+#else
+#define DNS_STAMP(i) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t acc_row(uint32_t r, uint32_t h) { return (r & 3u) + 8u * (r >> 2) + 4u * h; }
 
-enum KMap { K_SPLIT = 0, K_CHAIN = 1 };
-
+// Images are built by walking M in MEMORY order (aligned float4s, the quad e of the matrix starts at float 4e): every
+// workgroup re-reads the weights, so this walk is a large part of a launch's fixed cost.  It is split in two so that a
+// kernel can put the loads of ALL its matrices in flight first (image_load), zero the image area and pass the barrier
+// while they fly, and only then scatter (image_scatter) through the inverse of the k map: one memory latency per
+// weight set instead of one per matrix (a gather in image order cost ~50 dependent L2 round trips per thread).
+// Requires C % 4 == 0 (true for every layer: n_in % 8 == 0, hidden width 32 / 64) and R * C / 4 <= MAXQ * blockDim.
+enum KMap { K_SPLIT = 0, K_CHAIN = 1, K_PAIR = 2 };
 // A-operand image: img[(rt*nsteps + s)*64 + lane] = Meff[rt*32 + (lane&31)][kmap(s, lane>>5)]
 // Meff[i][k] = transpose ? M[k][i] : M[i][k];  M is row-major [R x C] (logical rows/cols of M).
-// K_SPLIT: k = h*khalf + s (s < khalf);  K_CHAIN: k = (s/16)*32 + acc_row(s%16, h).
-__device__ void build_image(float* __restrict__ img, const float* __restrict__ M, uint32_t R, uint32_t C, bool transpose,
-                            uint32_t row_tiles, uint32_t nsteps, int kmap, uint32_t khalf, uint32_t klimit) {
-  const uint32_t total = row_tiles * nsteps * 64u;
-  for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-    const uint32_t lane = e & 63u;
-    const uint32_t s = (e >> 6) % nsteps;
-    const uint32_t rt = (e >> 6) / nsteps;
-    const uint32_t i = rt * 32u + (lane & 31u);
-    const uint32_t h = lane >> 5;
-    const uint32_t k = (kmap == K_SPLIT) ? (h * khalf + s) : ((s >> 4) * 32u + acc_row(s & 15u, h));
-    float v = 0.f;
-    if (k < klimit) {
-      if (!transpose) {
-        if (i < R && k < C) v = M[(size_t)i * C + k];
+// K_SPLIT: k = h*khalf + s (s < khalf);  K_CHAIN: k = (s/16)*32 + acc_row(s%16, h);  K_PAIR: k = 2s + h.
+template <int MAXQ>
+struct ImgQuads {
+  float4 v[MAXQ];
+};
+
+template <int MAXQ>
+__device__ __forceinline__ void image_load(ImgQuads<MAXQ>& q, const float* __restrict__ M, uint32_t R, uint32_t C) {
+  const uint32_t nq = R * (C >> 2);
+  const bool vec = (((uintptr_t)M) & 15u) == 0;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    const uint32_t e = threadIdx.x + j * blockDim.x;
+    q.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < nq) {
+      const float* src = M + (size_t)e * 4u;
+      if (vec) {
+        q.v[j] = *reinterpret_cast<const float4*>(src);
       } else {
-        if (k < R && i < C) v = M[(size_t)k * C + i];
+        q.v[j] = make_float4(src[0], src[1], src[2], src[3]);
       }
     }
-    img[e] = v;
   }
+}
+
+template <int MAXQ>
+__device__ __forceinline__ void image_scatter(const ImgQuads<MAXQ>& q, float* __restrict__ img, uint32_t R, uint32_t C,
+                                              bool transpose, uint32_t row_tiles, uint32_t nsteps, int kmap, uint32_t khalf,
+                                              uint32_t klimit) {
+  auto step_of = [&](uint32_t k, uint32_t& st, uint32_t& h) -> bool {   // inverse of kmap; false: k has no slot
+    if (k >= klimit) return false;
+    if (kmap == K_SPLIT) {
+      h = k >= khalf ? 1u : 0u;
+      st = k - h * khalf;
+    } else if (kmap == K_PAIR) {
+      h = k & 1u;
+      st = k >> 1;
+    } else {
+      const uint32_t r32 = k & 31u;
+      h = (r32 >> 2) & 1u;
+      st = (k >> 5) * 16u + ((r32 & 3u) | ((r32 >> 3) << 2));
+    }
+    return st < nsteps;
+  };
+  const uint32_t qpr = C >> 2;                       // quads per row of M
+  const uint32_t nq = R * qpr;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    const uint32_t e = threadIdx.x + j * blockDim.x;
+    if (e >= nq) continue;
+    const uint32_t rr = e / qpr, cc = (e - rr * qpr) * 4u;
+    const float4 v = q.v[j];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (!transpose) {                                // Meff[i = rr][k = cc + c]
+      const uint32_t rt = rr >> 5;
+      if (rt >= row_tiles) continue;
+#pragma unroll
+      for (uint32_t c = 0; c < 4u; ++c) {
+        uint32_t st, h;
+        if (step_of(cc + c, st, h)) img[(rt * nsteps + st) * 64u + (rr & 31u) + 32u * h] = vv[c];
+      }
+    } else {                                         // Meff[i = cc + c][k = rr]: four neighbouring lanes of one step
+      const uint32_t rt = cc >> 5;
+      uint32_t st, h;
+      if (rt < row_tiles && step_of(rr, st, h))
+        *reinterpret_cast<float4*>(img + (rt * nsteps + st) * 64u + (cc & 31u) + 32u * h) = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_zero(float* __restrict__ p, uint32_t n_floats) {   // n_floats % 4 == 0
+  for (uint32_t e = threadIdx.x; e < n_floats / 4u; e += blockDim.x) reinterpret_cast<float4*>(p)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // VALU-row image for the trailing (n_out % 32) output rows: imgv[(v*nsteps + s)*2 + h] = W[row0+v][chain k(s,h)]
@@ -97,31 +167,38 @@ __host__ __device__ inline MlpShape make_shape(uint32_t n_in, uint32_t n_out) {
 // ---- layer 0: acc[t] = W_in[t-th 32 rows] * x  (x streamed from global as float4, split halves) ----
 // The lane's half row (<= 64 floats) is fetched as two groups of eight 16-byte loads, the second group issued
 // before the first group's MFMAs, so the row's memory latency is paid once, under matrix work.
-template <int NT>
-__device__ __forceinline__ void layer_in(const float* __restrict__ xrow, bool valid, uint32_t khalf,
-                                         const float* __restrict__ img, uint32_t lane, f32x16 (&acc)[NT]) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = zero16();
+struct XRegs {
+  float4 a[8], b[8];                      // the lane's half row: <= 64 floats
+};
+
+__device__ __forceinline__ void x_load(XRegs& xr, const float* __restrict__ xrow, bool valid, uint32_t khalf) {
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xrow);
   const uint32_t n4 = khalf >> 2;   // <= 16
-  float4 xa[8], xb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    xa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && (uint32_t)j < n4) xa[j] = x4[j];
+    xr.a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && (uint32_t)j < n4) xr.a[j] = x4[j];
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    xb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && (uint32_t)(8 + j) < n4) xb[j] = x4[8 + j];
+    xr.b[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && (uint32_t)(8 + j) < n4) xr.b[j] = x4[8 + j];
   }
+}
+
+template <int NT>
+__device__ __forceinline__ void layer_in_regs(const XRegs& xr, uint32_t khalf, const float* __restrict__ img, uint32_t lane,
+                                              f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = zero16();
+  const uint32_t n4 = khalf >> 2;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t q = half * 8 + j;
       if (q < n4) {
-        const float4 xv = half ? xb[j] : xa[j];
+        const float4 xv = half ? xr.b[j] : xr.a[j];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -137,10 +214,21 @@ __device__ __forceinline__ void layer_in(const float* __restrict__ xrow, bool va
   }
 }
 
+template <int NT>
+__device__ __forceinline__ void layer_in(const float* __restrict__ xrow, bool valid, uint32_t khalf,
+                                         const float* __restrict__ img, uint32_t lane, f32x16 (&acc)[NT]) {
+  XRegs xr;
+  x_load(xr, xrow, valid, khalf);
+  layer_in_regs<NT>(xr, khalf, img, lane, acc);
+}
+
 // ---- chained layer: out[t] = W[t-th 32 rows] * act   (act in accumulator layout = B operand) ----
+// No conditionals inside: a per-MFMA `if (t < out_tiles)` (even a uniform one) makes the compiler emit
+// ds_read -> s_waitcnt lgkmcnt(0) -> MFMA -> branch for every step instead of batching the LDS reads ahead of the MFMAs;
+// callers pick NT_OUT by the tile count they need.
 template <int NT_OUT, int NT_IN>
 __device__ __forceinline__ void layer_chain(const f32x16 (&act)[NT_IN], const float* __restrict__ img, uint32_t lane,
-                                            uint32_t out_tiles, f32x16 (&out)[NT_OUT]) {
+                                            f32x16 (&out)[NT_OUT]) {
   constexpr uint32_t nsteps = NT_IN * 16;
 #pragma unroll
   for (int t = 0; t < NT_OUT; ++t) out[t] = zero16();
@@ -152,12 +240,24 @@ __device__ __forceinline__ void layer_chain(const f32x16 (&act)[NT_IN], const fl
       const float b = act[ti][r];
 #pragma unroll
       for (int t = 0; t < NT_OUT; ++t) {
-        if ((uint32_t)t < out_tiles) {
-          const float a = img[(t * nsteps + s) * 64u + lane];
-          out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[t], 0, 0, 0);
-        }
+        const float a = img[(t * nsteps + s) * 64u + lane];
+        out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[t], 0, 0, 0);
       }
     }
+  }
+}
+
+// one or two output tiles (uniform choice), results in o[0..nt)
+template <int NT_IN>
+__device__ __forceinline__ void layer_chain_1or2(const f32x16 (&act)[NT_IN], const float* __restrict__ img, uint32_t lane,
+                                                 uint32_t nt, f32x16 (&o)[2]) {
+  if (nt >= 2u) {
+    layer_chain<2, NT_IN>(act, img, lane, o);
+  } else {
+    f32x16 o1[1];
+    layer_chain<1, NT_IN>(act, img, lane, o1);
+    o[0] = o1[0];
+    o[1] = o1[0];
   }
 }
 
@@ -170,6 +270,234 @@ __device__ __forceinline__ void relu(f32x16 (&a)[NT]) {
 }
 
 __device__ __forceinline__ uint32_t param_off_hidden(uint32_t nn, uint32_t n_in) { return nn * n_in; }
+
+// ---- row-coalesced global I/O of accumulator-layout tiles through a wave-private LDS staging tile ----
+// In the accumulator layout a lane owns ONE point, so a direct float4 store (or load) instruction touches 64 different
+// cache lines for 1 KB of payload; the texture-addresser retires ~1 line per 2 cycles, and at 16 waves per CU those
+// line operations -- not MFMA, not HBM -- were what bounded the MLP kernels (measured with in-kernel time stamps: the
+// next tile's first load could not issue for 30-40 us behind one tile's stores).  Staged through LDS the same 1 KB
+// leaves as 8 rows x 128 contiguous bytes: 8 lines per instruction.
+constexpr uint32_t STG_LD = 36;              // floats per staged row: 32 + 4 (16-byte aligned rows, spread over banks)
+constexpr uint32_t STG_FLOATS = 32 * STG_LD;
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS instructions of one wave execute in order; this only stops the compiler from moving them across
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// a: 32 features x 32 points (accumulator layout) -> rows dst[row * ld + 0..31], row < nrows
+__device__ __forceinline__ void store_tile_staged(float* __restrict__ dst, uint32_t ld, uint32_t nrows, const f32x16& a,
+                                                  float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = rr + 8 * i;
+    const float4 v = *reinterpret_cast<const float4*>(stg + row * STG_LD + c4);
+    if (row < nrows) *reinterpret_cast<float4*>(dst + (size_t)row * ld + c4) = v;
+  }
+  wave_lds_fence();
+}
+
+// Row ids of the wave's 32-slot tile, kept in LDS (wave-private, STG_ROWS ints after the staging tile) so that every
+// coalesced access pattern can look up "the row of tile-row i" without re-reading the index.
+constexpr uint32_t STG_ROWS = 64;              // two tables: the tile being computed and the one being prefetched
+constexpr uint32_t STG_WAVE_FLOATS = STG_FLOATS + STG_ROWS;
+
+__device__ __forceinline__ void tile_rows_publish(int* __restrict__ rows_lds, const int32_t* __restrict__ row_index,
+                                                  uint32_t slot0, uint32_t n_slots, bool live, uint32_t lane) {
+  if (lane < 32u) {
+    const uint32_t slot = slot0 + lane;
+    int row = -1;
+    if (live && slot < n_slots) row = row_index ? row_index[slot] : (int)slot;
+    rows_lds[lane] = row;
+  }
+  wave_lds_fence();
+}
+
+// ---- layer 0 input: 32 columns (k = 32c .. 32c+31) of the tile's 32 rows per chunk ----
+// Global side: lane (r8 = l>>3, j = l&7) reads float4 j of rows r8, r8+8, r8+16, r8+24: 8 rows x 128 contiguous bytes
+// per instruction.  LDS side: written de-interleaved (even k -> [pt][0..15], odd k -> [pt][16..31]) so that the MFMA
+// lane (pt, h) finds its 16 B operands of the chunk (k = 32c + 2s + h, the K_PAIR map) as 4 aligned float4s.
+struct XChunk {
+  float4 v[4];
+};
+
+__device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restrict__ x, uint32_t ldx, uint32_t n_in,
+                                              const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
+  const uint32_t col = 32u * c + 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rows_lds[(lane >> 3) + 8 * i];
+    xc.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= 0 && col < n_in) xc.v[i] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + col);
+  }
+}
+
+__device__ __forceinline__ void x_chunk_commit(const XChunk& xc, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t j = lane & 7u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float* r = stg + ((lane >> 3) + 8 * i) * STG_LD;
+    *reinterpret_cast<float2*>(r + 2 * j) = make_float2(xc.v[i].x, xc.v[i].z);
+    *reinterpret_cast<float2*>(r + 16 + 2 * j) = make_float2(xc.v[i].y, xc.v[i].w);
+  }
+  wave_lds_fence();
+}
+
+// 16 steps of the chunk (fewer in the last one: `steps`, a multiple of 4), image in the K_PAIR map with khalf steps
+template <int NT>
+__device__ __forceinline__ void layer_in_chunk(const float* __restrict__ stg, const float* __restrict__ img, uint32_t khalf,
+                                               uint32_t c, uint32_t steps, uint32_t lane, f32x16 (&acc)[NT]) {
+  const float* src = stg + (lane & 31u) * STG_LD + 16u * (lane >> 5);
+  float xs[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(src + 4 * g);
+    xs[4 * g] = v.x; xs[4 * g + 1] = v.y; xs[4 * g + 2] = v.z; xs[4 * g + 3] = v.w;
+  }
+  wave_lds_fence();                                // the staging tile may be overwritten once these reads are issued
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if ((uint32_t)(4 * g) < steps) {               // one uniform branch per 4-step group
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t st = 16u * c + 4 * g + e;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float a = img[(t * khalf + st) * 64u + lane];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[4 * g + e], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// a: 32 output features x 32 points -> y[row][col0 + f], f < ncols, rows through the tile's row table; dword stores with
+// lane = feature: 2 rows x 128 bytes per instruction (any ldy / alignment)
+__device__ __forceinline__ void store_tile_rows_scalar(float* __restrict__ y, uint32_t ldy, uint32_t col0, uint32_t ncols,
+                                                       const int* __restrict__ rows_lds, const f32x16& a,
+                                                       float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t f = lane & 31u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t r = (lane >> 5) + 2 * i;
+    const int row = rows_lds[r];
+    const float v = stg[r * STG_LD + f];
+    if (row >= 0 && f < ncols) y[(size_t)row * ldy + col0 + f] = v;
+  }
+  wave_lds_fence();
+}
+
+// 32 consecutive slot rows x 32 floats (src + row * ld) -> accumulator layout, in two halves so that several tiles'
+// loads can be in flight before the first is committed
+struct TileQuads {
+  float4 v[4];
+};
+
+__device__ __forceinline__ void load_tile_issue(TileQuads& q, const float* __restrict__ src, uint32_t ld, uint32_t nrows,
+                                                uint32_t lane) {
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = rr + 8 * i;
+    q.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) q.v[i] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c4);
+  }
+}
+
+__device__ __forceinline__ void load_tile_commit(const TileQuads& q, f32x16& a, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(stg + (rr + 8 * i) * STG_LD + c4) = q.v[i];
+  wave_lds_fence();
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(stg + pt * STG_LD + 8 * g + 4 * h);
+    a[4 * g] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+  }
+  wave_lds_fence();
+}
+
+// dy columns 32c .. 32c+31 of the tile's rows -> staging, de-interleaved for the K_PAIR map (see x_chunk_commit); dword
+// loads with lane = column (any lddy): 2 rows x 128 bytes per instruction
+__device__ __forceinline__ void dy_chunk_stage(const float* __restrict__ dy, uint32_t lddy, uint32_t n_out,
+                                               const int* __restrict__ rows_lds, uint32_t c, float* __restrict__ stg,
+                                               uint32_t lane) {
+  const uint32_t f = lane & 31u, col = 32u * c + f;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = rows_lds[(lane >> 5) + 2 * i];
+    v[i] = (row >= 0 && col < n_out) ? dy[(size_t)row * lddy + col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stg[((lane >> 5) + 2 * i) * STG_LD + (f & 1u) * 16u + (f >> 1)] = v[i];
+  wave_lds_fence();
+}
+
+// a: 32 features x 32 points -> dst[row][col0 + f] (f < ncols, ncols % 4 == 0, 16-byte aligned rows), rows through the
+// tile's row table; optional read-add-write
+__device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst, uint32_t ld, uint32_t col0, uint32_t ncols,
+                                                    const int* __restrict__ rows_lds, const f32x16& a, bool accumulate,
+                                                    float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t r = rr + 8 * i;
+    const int row = rows_lds[r];
+    float4 v = *reinterpret_cast<const float4*>(stg + r * STG_LD + c4);
+    if (row >= 0 && c4 < ncols) {
+      float4* p = reinterpret_cast<float4*>(dst + (size_t)row * ld + col0 + c4);
+      if (accumulate) {
+        const float4 u = *p;
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      *p = v;
+    }
+  }
+  wave_lds_fence();
+}
+
+// same, dword accesses with lane = feature (any ld / ncols)
+__device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ dst, uint32_t ld, uint32_t col0, uint32_t ncols,
+                                                           const int* __restrict__ rows_lds, const f32x16& a, bool accumulate,
+                                                           float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t f = lane & 31u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t r = (lane >> 5) + 2 * i;
+    const int row = rows_lds[r];
+    float v = stg[r * STG_LD + f];
+    if (row >= 0 && f < ncols) {
+      float* p = dst + (size_t)row * ld + col0 + f;
+      if (accumulate) v += *p;
+      *p = v;
+    }
+  }
+  wave_lds_fence();
+}
 
 template <int NT>
 __device__ __forceinline__ void store_acc_rows(float* __restrict__ dst, const f32x16 (&a)[NT], uint32_t h) {
@@ -207,7 +535,7 @@ struct FwdLds {
 };
 
 template <int NN, int NL>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ x, uint32_t ldx,
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict__ x, uint32_t ldx,
                                                       const float* __restrict__ params, MlpShape sh,
                                                       float* __restrict__ y, uint32_t ldy, uint32_t n_slots,
                                                       const int32_t* __restrict__ row_index,
@@ -218,63 +546,112 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ 
   using L = FwdLds<NN, NL>;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t khalf = sh.n_in / 2;
+  const uint32_t n_chunks = (sh.n_in + 31u) / 32u;
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   const uint32_t bt0 = blockIdx.x * tiles_per_block;
   const uint32_t bt1 = min(bt0 + tiles_per_block, n_btiles);
+  float* stg = lds + L::total(sh.n_in, sh.mt, sh.vr) + wave * STG_WAVE_FLOATS;
+  int* rows_all = reinterpret_cast<int*>(stg + STG_FLOATS);
+  XChunk xc[4];                                  // n_in <= 128: at most 4 chunks of 32 columns
+  bool have_x = false;
+  uint32_t cur_buf = 0;
   int cur_group = -2;
+  uint32_t stamp = 0;
+  (void)stamp;
+  DNS_STAMP(stamp++);
   for (uint32_t bt = bt0; bt < bt1; ++bt) {
     const int grp = tile_group ? tile_group[bt] : 0;
     if (grp != cur_group) {
       __syncthreads();
       if (grp >= 0) {
         const float* pw = params + (size_t)grp * param_stride;
-        build_image(lds + L::img_in(sh.n_in), pw, NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
-        if (NL == 2)
-          build_image(lds + L::img_h(sh.n_in), pw + NN * sh.n_in, NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
         const float* wout = pw + NN * sh.n_in + (NL - 1) * NN * NN;
-        if (sh.mt) build_image(lds + L::img_out(sh.n_in), wout, sh.n_out, NN, false, sh.mt, NN / 2, K_CHAIN, 0, NN);
+        const uint32_t out_rows = min(sh.n_out, sh.mt * 32u);          // rows of W_out done on the matrix cores
+        ImgQuads<8> q_in;                                              // 64 x 128 / 4 / 256 threads
+        ImgQuads<4> q_h, q_out;
+        image_load(q_in, pw, NN, sh.n_in);
+        if (NL == 2) image_load(q_h, pw + NN * sh.n_in, NN, NN);
+        if (sh.mt) image_load(q_out, wout, out_rows, NN);
+        lds_zero(lds, L::total(sh.n_in, sh.mt, sh.vr));
+        __syncthreads();
+        image_scatter(q_in, lds + L::img_in(sh.n_in), NN, sh.n_in, false, NT, khalf, K_PAIR, 0, sh.n_in);
+        if (NL == 2) image_scatter(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+        if (sh.mt) image_scatter(q_out, lds + L::img_out(sh.n_in), out_rows, NN, false, sh.mt, NN / 2, K_CHAIN, 0, NN);
         if (sh.vr) build_valu_image(lds + L::img_valu(sh.n_in, sh.mt), wout, sh.mt * 32, sh.vr, NN, NN / 2);
       }
       cur_group = grp;
       __syncthreads();
+      DNS_STAMP(stamp++);
     }
     if (grp < 0) continue;
-    const uint32_t slot = bt * 128u + wave * 32u + (lane & 31u);
-    const uint32_t h = lane >> 5;
-    int row = -1;
-    if (slot < n_slots) row = row_index ? row_index[slot] : (int)slot;
-    const bool valid = row >= 0;
-    const float* xrow = x + (size_t)(valid ? row : 0) * ldx + h * khalf;
-
-    f32x16 a0[NT];
-    layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, a0);
-    relu<NT>(a0);
-    if (h_save && slot < n_slots) store_acc_rows<NT>(h_save + (size_t)slot * NN, a0, h);   // kept for the backward
-    f32x16 a1[NT];
-    if (NL == 2) {
-      layer_chain<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, NT, a1);
-      relu<NT>(a1);
-      if (h_save && slot < n_slots) store_acc_rows<NT>(h_save + (size_t)(n_slots + slot) * NN, a1, h);
+    const uint32_t slot0 = bt * 128u + wave * 32u;
+    const uint32_t nrows = slot0 < n_slots ? min(32u, n_slots - slot0) : 0u;
+    // The tile's x rows (all <= 4 chunks of 32 columns) were requested while the PREVIOUS tile ran its later layers;
+    // only a workgroup's first live tile pays the latency here.
+    if (have_x) {
+      cur_buf ^= 1u;
+    } else {
+      tile_rows_publish(rows_all + 32u * cur_buf, row_index, slot0, n_slots, true, lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], x, ldx, sh.n_in, rows_all + 32u * cur_buf, c, lane);
     }
-    const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
-    float* yrow = y + (size_t)(valid ? row : 0) * ldy;
-    if (sh.mt) {
-      f32x16 o[2];
-      layer_chain<2, NT>(hl, lds + L::img_out(sh.n_in), lane, sh.mt, o);
-      if (valid) {
+    const int* rows_lds = rows_all + 32u * cur_buf;
+
+    // layer 0: x goes through the staging tile in 32-column chunks
+    f32x16 a0[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          if ((uint32_t)t < sh.mt) {
+    for (int t = 0; t < NT; ++t) a0[t] = zero16();
+    DNS_STAMP(stamp++);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t orow = t * 32 + acc_row(r, h);
-              if (orow < sh.n_out) yrow[orow] = o[t][r];
-            }
-          }
-        }
+    for (int c = 0; c < 4; ++c) {
+      if ((uint32_t)c < n_chunks) {
+        x_chunk_commit(xc[c], stg, lane);
+        DNS_STAMP(stamp++);
+        layer_in_chunk<NT>(stg, lds + L::img_in(sh.n_in), khalf, c, min(16u, khalf - 16u * c), lane, a0);
+        DNS_STAMP(stamp++);
       }
     }
+    have_x = false;
+    for (uint32_t nbt = bt + 1; nbt < bt1; ++nbt) {
+      if ((tile_group ? tile_group[nbt] : 0) < 0) continue;
+      int* nrows_lds = rows_all + 32u * (cur_buf ^ 1u);
+      tile_rows_publish(nrows_lds, row_index, nbt * 128u + wave * 32u, n_slots, true, lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], x, ldx, sh.n_in, nrows_lds, c, lane);
+      have_x = true;
+      break;
+    }
+    DNS_STAMP(stamp++);
+    relu<NT>(a0);
+    if (h_save) {                                  // kept for the backward
+#pragma unroll
+      for (int t = 0; t < NT; ++t) store_tile_staged(h_save + (size_t)slot0 * NN + t * 32, NN, nrows, a0[t], stg, lane);
+    }
+    DNS_STAMP(stamp++);
+    f32x16 a1[NT];
+    if (NL == 2) {
+      layer_chain<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, a1);
+      relu<NT>(a1);
+      if (h_save) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          store_tile_staged(h_save + (size_t)(n_slots + slot0) * NN + t * 32, NN, nrows, a1[t], stg, lane);
+      }
+    }
+    DNS_STAMP(stamp++);
+    const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
+    if (sh.mt) {
+      f32x16 o[2];
+      layer_chain_1or2<NT>(hl, lds + L::img_out(sh.n_in), lane, sh.mt, o);
+      store_tile_rows_scalar(y, ldy, 0, min(32u, sh.n_out), rows_lds, o[0], stg, lane);
+      if (sh.mt > 1) store_tile_rows_scalar(y, ldy, 32, sh.n_out - 32u, rows_lds, o[1], stg, lane);
+    }
+    DNS_STAMP(stamp++);
     if (sh.vr) {
+      const uint32_t h = lane >> 5;
+      const int row = rows_lds[lane & 31u];
       const float* iv = lds + L::img_valu(sh.n_in, sh.mt);
       for (uint32_t v = 0; v < sh.vr; ++v) {
         float sum = 0.f;
@@ -283,7 +660,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ 
 #pragma unroll
           for (int r = 0; r < 16; ++r) sum += iv[(v * (NN / 2) + t * 16 + r) * 2 + h] * hl[t][r];
         sum += __shfl_xor(sum, 32);
-        if (valid && h == 0) yrow[sh.mt * 32 + v] = sum;
+        if (row >= 0 && h == 0) y[(size_t)row * ldy + sh.mt * 32 + v] = sum;
       }
     }
   }
@@ -299,10 +676,11 @@ template <int NN, int NL, bool SAVED>
 struct BwdLds {
   static __host__ __device__ uint32_t in_pad(uint32_t n_in) { return (n_in + 31u) / 32u * 32u; }
   static __host__ __device__ uint32_t ko2(uint32_t n_out) { return (n_out + 1u) / 2u; }
+  static __host__ __device__ uint32_t ko2p(uint32_t n_out) { return (ko2(n_out) + 3u) & ~3u; }   // image steps: 4-step chunks
   static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
   static __host__ __device__ uint32_t img_h(uint32_t n_in) { return SAVED ? 0 : NN * n_in; }
   static __host__ __device__ uint32_t img_outT(uint32_t n_in) { return SAVED ? 0 : img_h(n_in) + (NL - 1) * NN * NN; }
-  static __host__ __device__ uint32_t img_hT(uint32_t n_in, uint32_t n_out) { return img_outT(n_in) + NN * 2 * ko2(n_out); }
+  static __host__ __device__ uint32_t img_hT(uint32_t n_in, uint32_t n_out) { return img_outT(n_in) + NN * 2 * ko2p(n_out); }
   static __host__ __device__ uint32_t img_inT(uint32_t n_in, uint32_t n_out) { return img_hT(n_in, n_out) + (NL - 1) * NN * NN; }
   static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, bool need_dx) {
     return img_inT(n_in, n_out) + (need_dx ? in_pad(n_in) * NN : 0);
@@ -329,7 +707,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
   const uint32_t lane = threadIdx.x & 63u, wave8 = threadIdx.x >> 6;
   const uint32_t wave = wave8 & 3u, wsel = wave8 >> 2;
   const uint32_t khalf = sh.n_in / 2;
-  const uint32_t ko2 = L::ko2(sh.n_out);
+  const uint32_t ko2 = L::ko2(sh.n_out), ko2p = L::ko2p(sh.n_out);
   const uint32_t in_tiles = L::in_pad(sh.n_in) / 32u;
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   const uint32_t bt0 = blockIdx.x * tiles_per_block;
@@ -339,7 +717,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
   float* wsD1 = SAVED ? ws : ws + (size_t)n_slots * NN;
   float* wsH2 = SAVED ? nullptr : ws + (size_t)2 * n_slots * NN;
   float* wsD2 = SAVED ? ws + (size_t)n_slots * NN : ws + (size_t)3 * n_slots * NN;
+  float* stg = lds + L::total(sh.n_in, sh.n_out, dx != nullptr) + wave8 * STG_WAVE_FLOATS;
+  int* rows_lds = reinterpret_cast<int*>(stg + STG_FLOATS);
+  (void)ko2;
   int cur_group = -2;
+  uint32_t stamp = 0;
+  (void)stamp;
+  DNS_STAMP(stamp++);
   for (uint32_t btb = bt0; btb < bt1;) {
     const int grp = tile_group ? tile_group[btb] : 0;
     const uint32_t nb = (btb + 1 < bt1 && (tile_group ? tile_group[btb + 1] : 0) == grp) ? 2u : 1u;
@@ -351,76 +735,84 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
         const float* pw = params + (size_t)grp * param_stride;
         const float* wh = pw + NN * sh.n_in;
         const float* wout = wh + (NL - 1) * NN * NN;
-        if (!SAVED) build_image(lds + L::img_in(sh.n_in), pw, NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
+        ImgQuads<4> q_in;                                              // 64 x 128 / 4 / 512 threads
+        ImgQuads<2> q_h, q_out;
+        image_load(q_in, pw, NN, sh.n_in);                             // serves both W_in and W_in^T
+        if (NL == 2) image_load(q_h, wh, NN, NN);
+        image_load(q_out, wout, sh.n_out, NN);
+        lds_zero(lds, L::total(sh.n_in, sh.n_out, dx != nullptr));
+        __syncthreads();
+        if (!SAVED) image_scatter(q_in, lds + L::img_in(sh.n_in), NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
         if (NL == 2) {
-          if (!SAVED) build_image(lds + L::img_h(sh.n_in), wh, NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
-          build_image(lds + L::img_hT(sh.n_in, sh.n_out), wh, NN, NN, true, NT, NN / 2, K_CHAIN, 0, NN);
+          if (!SAVED) image_scatter(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+          image_scatter(q_h, lds + L::img_hT(sh.n_in, sh.n_out), NN, NN, true, NT, NN / 2, K_CHAIN, 0, NN);
         }
-        // A = W_out^T: rows = hidden (NN), k over outputs in split halves of ko2
-        build_image(lds + L::img_outT(sh.n_in), wout, sh.n_out, NN, true, NT, ko2, K_SPLIT, ko2, sh.n_out);
-        if (dx) build_image(lds + L::img_inT(sh.n_in, sh.n_out), pw, NN, sh.n_in, true, in_tiles, NN / 2, K_CHAIN, 0, NN);
+        // A = W_out^T: rows = hidden (NN), k over outputs in pairs (k = 2s + h)
+        image_scatter(q_out, lds + L::img_outT(sh.n_in), sh.n_out, NN, true, NT, ko2p, K_PAIR, 0, sh.n_out);
+        if (dx) image_scatter(q_in, lds + L::img_inT(sh.n_in, sh.n_out), NN, sh.n_in, true, in_tiles, NN / 2, K_CHAIN, 0, NN);
       }
       cur_group = grp;
       __syncthreads();
+      DNS_STAMP(stamp++);
     }
     if (wsel >= nb) continue;                      // no second tile of this weight set: waves 4-7 sit this one out
-    const uint32_t slot = bt * 128u + wave * 32u + (lane & 31u);
-    const uint32_t h = lane >> 5;
-    int row = -1;
-    if (slot < n_slots && grp >= 0) row = row_index ? row_index[slot] : (int)slot;
-    const bool valid = row >= 0;
+    const uint32_t slot0 = bt * 128u + wave * 32u;
+    const uint32_t nrows = slot0 < n_slots ? min(32u, n_slots - slot0) : 0u;
     if (grp < 0) {
       // padding tile of an empty group: zero its workspace rows so the weight GEMMs see zeros
-      if (slot < n_slots) {
-        f32x16 z[NT];
+      const f32x16 z = zero16();
 #pragma unroll
-        for (int t = 0; t < NT; ++t) z[t] = zero16();
-        if (!SAVED) store_acc_rows<NT>(wsH1 + (size_t)slot * NN, z, h);
-        store_acc_rows<NT>(wsD1 + (size_t)slot * NN, z, h);
+      for (int t = 0; t < NT; ++t) {
+        if (!SAVED) store_tile_staged(wsH1 + (size_t)slot0 * NN + t * 32, NN, nrows, z, stg, lane);
+        store_tile_staged(wsD1 + (size_t)slot0 * NN + t * 32, NN, nrows, z, stg, lane);
         if (NL == 2) {
-          if (!SAVED) store_acc_rows<NT>(wsH2 + (size_t)slot * NN, z, h);
-          store_acc_rows<NT>(wsD2 + (size_t)slot * NN, z, h);
+          if (!SAVED) store_tile_staged(wsH2 + (size_t)slot0 * NN + t * 32, NN, nrows, z, stg, lane);
+          store_tile_staged(wsD2 + (size_t)slot0 * NN + t * 32, NN, nrows, z, stg, lane);
         }
       }
       continue;
     }
+    tile_rows_publish(rows_lds, row_index, slot0, n_slots, true, lane);
+    const uint32_t h = lane >> 5;
     f32x16 h1[NT], h2[NT];
     if (SAVED) {
-      load_acc_rows<NT>(h_saved + (size_t)slot * NN, h1, h, slot < n_slots);
-      if (NL == 2) load_acc_rows<NT>(h_saved + (size_t)(h_stride + slot) * NN, h2, h, slot < n_slots);
+      // all <= 4 hidden tiles requested at once (row-coalesced), committed to the accumulator layout one by one
+      TileQuads qh[NL * NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        load_tile_issue(qh[t], h_saved + (size_t)slot0 * NN + t * 32, NN, nrows, lane);
+        if (NL == 2) load_tile_issue(qh[NT + t], h_saved + (size_t)(h_stride + slot0) * NN + t * 32, NN, nrows, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        load_tile_commit(qh[t], h1[t], stg, lane);
+        if (NL == 2) load_tile_commit(qh[NT + t], h2[t], stg, lane);
+      }
     } else {
+      const int row = rows_lds[lane & 31u];
+      const bool valid = row >= 0;
       const float* xrow = x + (size_t)(valid ? row : 0) * ldx + h * khalf;
       layer_in<NT>(xrow, valid, khalf, lds + L::img_in(sh.n_in), lane, h1);
       relu<NT>(h1);
       if (NL == 2) {
-        layer_chain<NT, NT>(h1, lds + L::img_h(sh.n_in), lane, NT, h2);
+        layer_chain<NT, NT>(h1, lds + L::img_h(sh.n_in), lane, h2);
         relu<NT>(h2);
       }
     }
-    // dH_last = W_out^T dY
+    DNS_STAMP(stamp++);   // h loads issued / recompute done
+    // dH_last = W_out^T dY: dy staged in 32-column chunks (k = 32c + 2s + h)
     f32x16 dl[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) dl[t] = zero16();
     {
-      const float* dyrow = dy + (size_t)(valid ? row : 0) * lddy;
       const float* img = lds + L::img_outT(sh.n_in);
-      float dyv[32];                           // ko2 <= 32: every load of the lane's half row in flight at once
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const uint32_t k = h * ko2 + s;
-        dyv[s] = (valid && (uint32_t)s < ko2 && k < sh.n_out) ? dyrow[k] : 0.f;
-      }
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        if ((uint32_t)s < ko2) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const float a = img[(t * ko2 + s) * 64u + lane];
-            dl[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dyv[s], dl[t], 0, 0, 0);
-          }
-        }
+      const uint32_t n_dy_chunks = (sh.n_out + 31u) / 32u;
+      for (uint32_t c = 0; c < n_dy_chunks; ++c) {
+        dy_chunk_stage(dy, lddy, sh.n_out, rows_lds, c, stg, lane);
+        layer_in_chunk<NT>(stg, img, ko2p, c, min(16u, ko2p - 16u * c), lane, dl);
       }
     }
+    DNS_STAMP(stamp++);   // dl mfma issued
     const f32x16(&hl)[NT] = (NL == 2) ? h2 : h1;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -428,55 +820,40 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) dl[t][r] = hl[t][r] > 0.f ? dl[t][r] : 0.f;
     f32x16 d1[NT];
     if (NL == 2) {
-      layer_chain<NT, NT>(dl, lds + L::img_hT(sh.n_in, sh.n_out), lane, NT, d1);
+      layer_chain<NT, NT>(dl, lds + L::img_hT(sh.n_in, sh.n_out), lane, d1);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[t][r] = h1[t][r] > 0.f ? d1[t][r] : 0.f;
     }
+    DNS_STAMP(stamp++);   // relu' + chain d1
     const f32x16(&dfirst)[NT] = (NL == 2) ? d1 : dl;
-    if (slot < n_slots) {
-      if (!SAVED) store_acc_rows<NT>(wsH1 + (size_t)slot * NN, h1, h);
-      store_acc_rows<NT>(wsD1 + (size_t)slot * NN, dfirst, h);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!SAVED) store_tile_staged(wsH1 + (size_t)slot0 * NN + t * 32, NN, nrows, h1[t], stg, lane);
+      store_tile_staged(wsD1 + (size_t)slot0 * NN + t * 32, NN, nrows, dfirst[t], stg, lane);
       if (NL == 2) {
-        if (!SAVED) store_acc_rows<NT>(wsH2 + (size_t)slot * NN, h2, h);
-        store_acc_rows<NT>(wsD2 + (size_t)slot * NN, dl, h);
+        if (!SAVED) store_tile_staged(wsH2 + (size_t)slot0 * NN + t * 32, NN, nrows, h2[t], stg, lane);
+        store_tile_staged(wsD2 + (size_t)slot0 * NN + t * 32, NN, nrows, dl[t], stg, lane);
       }
     }
+    DNS_STAMP(stamp++);   // ws stores
     if (dx) {
       // dX = W_in^T dH_1, two input tiles at a time to bound accumulator registers
       const float* img = lds + L::img_inT(sh.n_in, sh.n_out);
-      float* dxrow = dx + (size_t)(valid ? row : 0) * lddx;
+      const bool vec = ((lddx & 3u) == 0) && ((((uintptr_t)dx) & 15u) == 0);
       for (uint32_t it0 = 0; it0 < in_tiles; it0 += 2) {
         f32x16 o[2];
         const uint32_t nt = min(2u, in_tiles - it0);
-        layer_chain<2, NT>(dfirst, img + (size_t)it0 * (NN / 2) * 64u, lane, nt, o);
-        if (valid) {
+        layer_chain_1or2<NT>(dfirst, img + (size_t)it0 * (NN / 2) * 64u, lane, nt, o);
+        DNS_STAMP(stamp++);   // dX chain issued
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            if ((uint32_t)t < nt) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const uint32_t c0 = (it0 + t) * 32 + 8 * q + 4 * h;
-                if (c0 + 3 < sh.n_in) {
-                  if ((lddx & 3u) == 0) {
-                    float4 v = make_float4(o[t][4 * q], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]);
-                    if (accumulate_dx) {                 // a second network sharing the same input adds its gradient
-                      const float4 u = *reinterpret_cast<const float4*>(dxrow + c0);
-                      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                    }
-                    *reinterpret_cast<float4*>(dxrow + c0) = v;
-                  } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dxrow[c0 + e] = o[t][4 * q + e] + (accumulate_dx ? dxrow[c0 + e] : 0.f);
-                  }
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    if (c0 + e < sh.n_in) dxrow[c0 + e] = o[t][4 * q + e] + (accumulate_dx ? dxrow[c0 + e] : 0.f);
-                }
-              }
-            }
+        for (int t = 0; t < 2; ++t) {
+          if ((uint32_t)t < nt) {
+            const uint32_t col0 = (it0 + t) * 32u;
+            const uint32_t ncols = min(32u, sh.n_in - col0);           // n_in % 8 == 0
+            if (vec) store_tile_rows_vec(dx, lddx, col0, ncols, rows_lds, o[t], accumulate_dx != 0, stg, lane);
+            else store_tile_rows_scalar_acc(dx, lddx, col0, ncols, rows_lds, o[t], accumulate_dx != 0, stg, lane);
           }
         }
       }
@@ -868,18 +1245,25 @@ static bool shape_ok(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
          n_out <= 64;
 }
 
-static uint32_t pick_tiles_per_block(uint32_t n_btiles, const int32_t* tile_group) {
-  // persistent-ish: ~2 workgroups per CU, contiguous ranges so a group's LDS images are rebuilt rarely
-  const uint32_t target_blocks = 512;
+static uint32_t pick_tiles_per_block(uint32_t n_btiles, uint32_t target_blocks, const char* env_name) {
+  // contiguous tile ranges, one wave of workgroups: the forward holds 2 workgroups of 4 waves per CU (LDS: weight
+  // images + staging ~ 72 KB), the backward 1 workgroup of 8 waves (~ 98 KB) that takes tiles in pairs
+  const char* e = getenv(env_name);
+  if (e && atoi(e) > 0) target_blocks = (uint32_t)atoi(e);
   uint32_t tpb = (n_btiles + target_blocks - 1) / target_blocks;
   if (tpb < 1) tpb = 1;
-  (void)tile_group;
   return tpb;
 }
 
 }  // namespace dns
 
 using namespace dns;
+
+#ifdef DNS_TRACE
+extern "C" int dns_trace_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dns::dns_trace_buf), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers) {
   return (uint64_t)2 * n_hidden_layers * n_slots * n_neurons;
@@ -899,12 +1283,14 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
   if (n_slots == 0) return DNS_OK;
   const MlpShape sh = make_shape(n_in, n_out);
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
-  const uint32_t tpb = pick_tiles_per_block(n_btiles, tile_group);
+  const uint32_t tpb = pick_tiles_per_block(n_btiles, 512, "DNS_MLP_FWD_BLOCKS");
   const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_FWD(NN, NL)                                                                                         \
   {                                                                                                                \
-    const size_t lds_bytes = (size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) * sizeof(float);                    \
+    const size_t lds_bytes = ((size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) + 4 * STG_WAVE_FLOATS) * sizeof(float); \
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)lds_bytes);                                                                     \
     hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, params, sh, y, ldy, \
                        n_slots, row_index, tile_group, param_stride, tpb, h_save);                                 \
   }
@@ -951,11 +1337,11 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
     const int32_t* tg_c = tile_group ? tile_group + s0 / 128u : nullptr;
     const float* hs_c = h_saved ? h_saved + (size_t)s0 * NNr : nullptr;
     const uint32_t n_btiles = (n_c + 127u) / 128u;
-    const uint32_t tpb = pick_tiles_per_block(n_btiles, tg_c);
+    const uint32_t tpb = pick_tiles_per_block(n_btiles, 256, "DNS_MLP_BWD_BLOCKS");
     const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
 #define LAUNCH_BWD2(NN, NL, SV)                                                                                     \
   {                                                                                                                 \
-    const size_t lds_bytes = (size_t)BwdLds<NN, NL, SV>::total(n_in, n_out, d_x != nullptr) * sizeof(float);        \
+    const size_t lds_bytes = ((size_t)BwdLds<NN, NL, SV>::total(n_in, n_out, d_x != nullptr) + 8 * STG_WAVE_FLOATS) * sizeof(float); \
     (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds_bytes);                                                                      \
     hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV>), dim3(blocks), dim3(512), lds_bytes, st, x_c, ldx, dy_c,   \
