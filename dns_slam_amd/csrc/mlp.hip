@@ -1068,7 +1068,7 @@ struct GemmRoles {
 template <bool AIDX, bool BIDX, bool AVEC>
 __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slots, uint32_t bt0, uint32_t tstride, uint32_t ntl,
                                               const int* __restrict__ grp_lds, float* __restrict__ wlds, uint32_t c_stride) {
-  constexpr int D = 8;                       // load steps (1 KB per operand each) in flight
+  constexpr int D = 8;                       // load steps in flight (measured: 8 beats 4 and 2 here, 263 vs 283 us)
   const uint32_t lane = threadIdx.x & 63u;
   const float* __restrict__ A = u.A;
   const float* __restrict__ B = u.B;
@@ -1093,22 +1093,24 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
   float4 ra[D], rb[D];
   int ia[D], ib[D];                          // slot -> row of the step whose data is requested next round
   bool rv[D];                                // this lane's point of the step is real
-  auto slot_ok = [&](uint32_t q, uint32_t& slot) -> bool {
+  // liveness of a step's tile is looked up ONCE per group of D steps (D divides 32: a group never straddles tiles): a
+  // per-step LDS read + s_waitcnt lgkmcnt(0) would put an LDS round trip into every 16-MFMA step of the in-order stream
+  auto tile_live = [&](uint32_t q) -> bool { return q < nsteps && grp_lds[min(q >> 5, ntl - 1u)] >= 0; };   // uniform
+  auto slot_ok = [&](uint32_t q, bool live, uint32_t& slot) -> bool {
     slot = (bt0 + (q >> 5) * tstride) * 128u + (q & 31u) * 4u + k;
-    const bool live = q < nsteps && grp_lds[min(q >> 5, ntl - 1u)] >= 0;    // uniform
     return live && slot < n_slots;
   };
-  auto issue_idx = [&](int& xa, int& xb, uint32_t q) {
+  auto issue_idx = [&](int& xa, int& xb, uint32_t q, bool live) {
     if (!AIDX && !BIDX) return;
     uint32_t slot;
-    const bool ok = slot_ok(q, slot);
+    const bool ok = slot_ok(q, live, slot);
     const uint32_t sl = ok ? slot : 0u;      // slot 0 exists
     if (AIDX) xa = ai[sl];
     if (BIDX) xb = bi[sl];
   };
-  auto issue_data = [&](float4& a, float4& b, bool& valid, int xa, int xb, uint32_t q) {
+  auto issue_data = [&](float4& a, float4& b, bool& valid, int xa, int xb, uint32_t q, bool live) {
     uint32_t slot;
-    bool ok = slot_ok(q, slot);
+    bool ok = slot_ok(q, live, slot);
     if (AIDX) ok = ok && xa >= 0;
     if (BIDX) ok = ok && xb >= 0;
     valid = ok;
@@ -1148,20 +1150,24 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
   };
 
   // prologue: indices of steps 0..D-1, then their data + the indices of steps D..2D-1
+  {
+    const bool live0 = tile_live(0), live1 = tile_live(D);
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    ia[d] = 0;
-    ib[d] = 0;
-    issue_idx(ia[d], ib[d], (uint32_t)d);
-  }
+    for (int d = 0; d < D; ++d) {
+      ia[d] = 0;
+      ib[d] = 0;
+      issue_idx(ia[d], ib[d], (uint32_t)d, live0);
+    }
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    issue_data(ra[d], rb[d], rv[d], ia[d], ib[d], (uint32_t)d);
-    issue_idx(ia[d], ib[d], (uint32_t)(d + D));
-    asm volatile("" ::: "memory");
+    for (int d = 0; d < D; ++d) {
+      issue_data(ra[d], rb[d], rv[d], ia[d], ib[d], (uint32_t)d, live0);
+      issue_idx(ia[d], ib[d], (uint32_t)(d + D), live1);
+      asm volatile("" ::: "memory");
+    }
   }
   int cur = -2;
   for (uint32_t q0 = 0; q0 < nsteps; q0 += D) {
+    const bool live_d = tile_live(q0 + D), live_i = tile_live(q0 + 2 * D);
     if ((q0 & 31u) == 0) {
       const int grp = grp_lds[q0 >> 5];
       if (grp >= 0 && grp != cur) {
@@ -1175,8 +1181,8 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
       const bool va = rv[d];
       const float av[4] = {va ? ra[d].x : 0.f, va ? ra[d].y : 0.f, va ? ra[d].z : 0.f, va ? ra[d].w : 0.f};
       const float bv[4] = {rb[d].x, rb[d].y, rb[d].z, rb[d].w};
-      issue_data(ra[d], rb[d], rv[d], ia[d], ib[d], q + D);
-      issue_idx(ia[d], ib[d], q + 2 * D);
+      issue_data(ra[d], rb[d], rv[d], ia[d], ib[d], q + D, live_d);
+      issue_idx(ia[d], ib[d], q + 2 * D, live_i);
       asm volatile("" ::: "memory");         // keep the loads in program order: vmcnt waits are positional
 #pragma unroll
       for (int a = 0; a < 4; ++a)

@@ -155,6 +155,26 @@ class Mapper:
             gx, gy, gz = torch.meshgrid(ar, ar, ar, indexing="ij")
             self._lattice = torch.stack([gx, gy, gz], dim=-1).to(torch.float64).to(self.device)
             self._lattice_key = key
+        if u_offset is None and u_jitter is None and self.static_shapes:
+            # sync-free iteration: the same fp64 affine map, folded to  pts = lattice * A + B  with
+            # A = voxel / (b1 - b0),  B = (jitter * voxel + offset) / (b1 - b0)  -- 6 launches instead of 14
+            if getattr(self, "_lattice_consts", None) is None or self._lattice_consts[0] != key:
+                bd = self.bound_dev
+                d = bd[:, 1] - bd[:, 0]
+                self._lattice_consts = (key, voxel_size / d, self._offset_max / d, margin / d)
+            _, c_vox, c_off, c_mar = self._lattice_consts
+            r = torch.rand(6, device=self.device).to(torch.float64)            # [offset(3) | jitter(3)], as float32 draws
+            b = torch.addcmul(torch.addcmul(c_mar, r[:3], c_off), r[3:], c_vox)
+            pts = torch.addcmul(b, self._lattice, c_vox)
+            pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
+            coarse = self.decoder.coarse_fn(pe, features=grid_pts)
+            if self.fused_losses:
+                return ops.tv_smoothness(coarse, n, sample_points)
+            occ = coarse[:, 0:1].reshape(n, n, n, 1)
+            tv_x = torch.pow(occ[1:, ...] - occ[:-1, ...], 2).sum()
+            tv_y = torch.pow(occ[:, 1:, ...] - occ[:, :-1, ...], 2).sum()
+            tv_z = torch.pow(occ[:, :, 1:, ...] - occ[:, :, :-1, ...], 2).sum()
+            return (tv_x + tv_y + tv_z) / (sample_points ** 3)
         if u_offset is None:
             u_offset = torch.rand(3, device=self.device) if self.static_shapes else torch.rand(3)
         if u_jitter is None:
@@ -248,21 +268,23 @@ class Mapper:
             sorted_pix.append(order)
             starts.append(st[slot_class])
             counts.append(cnt[slot_class])
+        # stacked tables: one draw for all K frames (8 launches per iteration instead of 8 per frame)
+        offs = (torch.arange(K, device=self.device) * HW)[:, None]
+        cnt_all = torch.stack(counts)
         return {"color": color, "depth": depth, "label": label, "n1": n1, "n2": n2, "HW": HW,
-                "sorted_pix": sorted_pix, "starts": starts, "counts": counts}
+                "sorted_pix": sorted_pix, "starts": starts, "counts": counts,
+                "sorted_flat": torch.stack(sorted_pix).reshape(-1), "starts_flat": torch.stack(starts) + offs,
+                "counts_f64": cnt_all.to(torch.float64), "counts_m1": cnt_all - 1}
 
     def draw_pixels(self, prep):
         """Indices of one iteration: per frame n1 uniform picks (select_uv, common.py:274) then n2 class-balanced
         picks (select_by_class :313-328), concatenated in the reference's order."""
-        out = []
-        for f in range(self.n_target_frame):
-            i1 = torch.randint(prep["HW"], (prep["n1"],), device=self.device)
-            u = torch.rand(prep["n2"], device=self.device, dtype=torch.float64)
-            k = prep["counts"][f]
-            j = torch.minimum((u * k).to(torch.int64), k - 1)
-            i2 = prep["sorted_pix"][f][prep["starts"][f] + j]
-            out += [i1, i2]
-        return torch.cat(out)
+        K = self.n_target_frame
+        i1 = torch.randint(prep["HW"], (K, prep["n1"]), device=self.device)
+        u = torch.rand(K, prep["n2"], device=self.device, dtype=torch.float64)
+        j = torch.minimum((u * prep["counts_f64"]).to(torch.int64), prep["counts_m1"])
+        i2 = prep["sorted_flat"][prep["starts_flat"] + j]
+        return torch.cat((i1, i2), 1).reshape(-1)
 
     def draw_jitter(self):
         """The two draws of sample_along_rays (utils/common.py:571-574,582), forced 0.5 included.  Reference: CPU
