@@ -328,14 +328,28 @@ struct XChunk {
   float4 v[4];
 };
 
-__device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restrict__ x, uint32_t ldx, uint32_t n_in,
-                                              const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
+// Optional second input segment: columns [n_in1, n_in) of the network input come from x2 (its own row stride), so that
+// cat(a, b) inputs (reference models/decoder.py:123-124) are never materialised.  n_in1 % 4 == 0.
+struct XSeg {
+  const float* x2;
+  uint32_t ldx2, n_in1;
+};
+struct DxSeg {
+  float* dx2;
+  uint32_t lddx2, acc1, acc2;              // acc: read-add-write instead of overwrite
+};
+
+__device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restrict__ x, uint32_t ldx, const XSeg& seg,
+                                              uint32_t n_in, const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
   const uint32_t col = 32u * c + 4u * (lane & 7u);
+  const bool second = seg.x2 != nullptr && col >= seg.n_in1;
+  const float* base = second ? seg.x2 + (col - seg.n_in1) : x + col;
+  const uint32_t ld = second ? seg.ldx2 : ldx;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = rows_lds[(lane >> 3) + 8 * i];
     xc.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row >= 0 && col < n_in) xc.v[i] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + col);
+    if (row >= 0 && col < n_in) xc.v[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld);
   }
 }
 
@@ -449,9 +463,9 @@ __device__ __forceinline__ void dy_chunk_stage(const float* __restrict__ dy, uin
 
 // a: 32 features x 32 points -> dst[row][col0 + f] (f < ncols, ncols % 4 == 0, 16-byte aligned rows), rows through the
 // tile's row table; optional read-add-write
-__device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst, uint32_t ld, uint32_t col0, uint32_t ncols,
-                                                    const int* __restrict__ rows_lds, const f32x16& a, bool accumulate,
-                                                    float* __restrict__ stg, uint32_t lane) {
+__device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst1, uint32_t ld1, const DxSeg& seg, uint32_t n_in1,
+                                                    uint32_t col0, uint32_t ncols, const int* __restrict__ rows_lds,
+                                                    const f32x16& a, float* __restrict__ stg, uint32_t lane) {
   const uint32_t pt = lane & 31u, h = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -464,8 +478,11 @@ __device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst, uin
     const int row = rows_lds[r];
     float4 v = *reinterpret_cast<const float4*>(stg + r * STG_LD + c4);
     if (row >= 0 && c4 < ncols) {
-      float4* p = reinterpret_cast<float4*>(dst + (size_t)row * ld + col0 + c4);
-      if (accumulate) {
+      const uint32_t col = col0 + c4;
+      const bool second = seg.dx2 != nullptr && col >= n_in1;
+      float4* p = second ? reinterpret_cast<float4*>(seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1))
+                         : reinterpret_cast<float4*>(dst1 + (size_t)row * ld1 + col);
+      if (second ? seg.acc2 : seg.acc1) {
         const float4 u = *p;
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
@@ -476,8 +493,9 @@ __device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst, uin
 }
 
 // same, dword accesses with lane = feature (any ld / ncols)
-__device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ dst, uint32_t ld, uint32_t col0, uint32_t ncols,
-                                                           const int* __restrict__ rows_lds, const f32x16& a, bool accumulate,
+__device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ dst1, uint32_t ld1, const DxSeg& seg,
+                                                           uint32_t n_in1, uint32_t col0, uint32_t ncols,
+                                                           const int* __restrict__ rows_lds, const f32x16& a,
                                                            float* __restrict__ stg, uint32_t lane) {
   const uint32_t pt = lane & 31u, h = lane >> 5;
 #pragma unroll
@@ -491,8 +509,10 @@ __device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ d
     const int row = rows_lds[r];
     float v = stg[r * STG_LD + f];
     if (row >= 0 && f < ncols) {
-      float* p = dst + (size_t)row * ld + col0 + f;
-      if (accumulate) v += *p;
+      const uint32_t col = col0 + f;
+      const bool second = seg.dx2 != nullptr && col >= n_in1;
+      float* p = second ? seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1) : dst1 + (size_t)row * ld1 + col;
+      if (second ? seg.acc2 : seg.acc1) v += *p;
       *p = v;
     }
   }
@@ -535,7 +555,7 @@ struct FwdLds {
 };
 
 template <int NN, int NL>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict__ x, uint32_t ldx,
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict__ x, uint32_t ldx, XSeg seg,
                                                       const float* __restrict__ params, MlpShape sh,
                                                       float* __restrict__ y, uint32_t ldy, uint32_t n_slots,
                                                       const int32_t* __restrict__ row_index,
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict
       tile_rows_publish(rows_all + 32u * cur_buf, row_index, slot0, n_slots, true, lane);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], x, ldx, sh.n_in, rows_all + 32u * cur_buf, c, lane);
+        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], x, ldx, seg, sh.n_in, rows_all + 32u * cur_buf, c, lane);
     }
     const int* rows_lds = rows_all + 32u * cur_buf;
 
@@ -619,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict
       tile_rows_publish(nrows_lds, row_index, nbt * 128u + wave * 32u, n_slots, true, lane);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], x, ldx, sh.n_in, nrows_lds, c, lane);
+        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], x, ldx, seg, sh.n_in, nrows_lds, c, lane);
       have_x = true;
       break;
     }
@@ -691,13 +711,12 @@ template <int NN, int NL, bool SAVED>
 __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restrict__ x, uint32_t ldx,
                                                            const float* __restrict__ dy, uint32_t lddy,
                                                            const float* __restrict__ params, MlpShape sh,
-                                                           float* __restrict__ dx, uint32_t lddx,
+                                                           float* __restrict__ dx, uint32_t lddx, DxSeg dseg, uint32_t n_in1,
                                                            float* __restrict__ ws, uint32_t n_slots,
                                                            const int32_t* __restrict__ row_index,
                                                            const int32_t* __restrict__ tile_group,
                                                            uint32_t param_stride, uint32_t tiles_per_block,
-                                                           const float* __restrict__ h_saved, uint32_t h_stride,
-                                                           int accumulate_dx) {
+                                                           const float* __restrict__ h_saved, uint32_t h_stride) {
   constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = BwdLds<NN, NL, SAVED>;
@@ -841,7 +860,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
     if (dx) {
       // dX = W_in^T dH_1, two input tiles at a time to bound accumulator registers
       const float* img = lds + L::img_inT(sh.n_in, sh.n_out);
-      const bool vec = ((lddx & 3u) == 0) && ((((uintptr_t)dx) & 15u) == 0);
+      const bool vec = ((lddx & 3u) == 0) && ((((uintptr_t)dx) & 15u) == 0) &&
+                       (!dseg.dx2 || (((dseg.lddx2 & 3u) == 0) && ((((uintptr_t)dseg.dx2) & 15u) == 0)));
       for (uint32_t it0 = 0; it0 < in_tiles; it0 += 2) {
         f32x16 o[2];
         const uint32_t nt = min(2u, in_tiles - it0);
@@ -852,8 +872,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
           if ((uint32_t)t < nt) {
             const uint32_t col0 = (it0 + t) * 32u;
             const uint32_t ncols = min(32u, sh.n_in - col0);           // n_in % 8 == 0
-            if (vec) store_tile_rows_vec(dx, lddx, col0, ncols, rows_lds, o[t], accumulate_dx != 0, stg, lane);
-            else store_tile_rows_scalar_acc(dx, lddx, col0, ncols, rows_lds, o[t], accumulate_dx != 0, stg, lane);
+            if (vec) store_tile_rows_vec(dx, lddx, dseg, n_in1, col0, ncols, rows_lds, o[t], stg, lane);
+            else store_tile_rows_scalar_acc(dx, lddx, dseg, n_in1, col0, ncols, rows_lds, o[t], stg, lane);
           }
         }
       }
@@ -927,7 +947,7 @@ __device__ __forceinline__ void stage_store(const StageRegs& rg, float* __restri
 }
 
 struct GemmTnBatch {
-  GemmTnArgs g[3];
+  GemmTnArgs g[4];
 };
 
 // Weight gradients C[M x N] += sum_slots A[slot][m] * B[slot][n] (K dimension = points), per parameter group.
@@ -1275,10 +1295,18 @@ extern "C" uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, 
   return (uint64_t)2 * n_hidden_layers * n_slots * n_neurons;
 }
 
-extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
-                           uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
-                           const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, float* h_save,
-                           void* stream) {
+static int check_segments(const char* who, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in) {
+  if (!x2) return DNS_OK;
+  DNS_REQUIRE(n_in1 >= 4 && n_in1 < n_in && (n_in1 % 4) == 0, "%s: first input segment must hold a multiple of 4 columns in (0, n_in)", who);
+  DNS_REQUIRE((ldx2 % 4) == 0 && (((uintptr_t)x2) % 16) == 0 && ldx2 >= n_in - n_in1,
+              "%s: x2 must be 16-byte aligned with ldx2 %% 4 == 0 and ldx2 >= n_in - n_in1", who);
+  return DNS_OK;
+}
+
+extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
+                           const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
+                           uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots, const int32_t* row_index,
+                           const int32_t* tile_group, uint32_t param_stride, float* h_save, void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
   DNS_REQUIRE(!h_save || (((uintptr_t)h_save) % 16) == 0, "dns_mlp_fwd: h_save must be 16-byte aligned");
@@ -1286,7 +1314,11 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
   DNS_REQUIRE(ldy >= n_out, "dns_mlp_fwd: ldy < n_out");
-  if (n_slots == 0) return DNS_OK;
+  {
+    const int rc = check_segments("dns_mlp_fwd", x2, ldx2, n_in1, n_in);
+    if (rc != DNS_OK) return rc;
+  }
+  const XSeg seg = {x2, ldx2, x2 ? n_in1 : n_in};
   const MlpShape sh = make_shape(n_in, n_out);
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   const uint32_t tpb = pick_tiles_per_block(n_btiles, 512, "DNS_MLP_FWD_BLOCKS");
@@ -1297,8 +1329,8 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
     const size_t lds_bytes = ((size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) + 4 * STG_WAVE_FLOATS) * sizeof(float); \
     (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)lds_bytes);                                                                     \
-    hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, params, sh, y, ldy, \
-                       n_slots, row_index, tile_group, param_stride, tpb, h_save);                                 \
+    hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, seg, params, sh, y, \
+                       ldy, n_slots, row_index, tile_group, param_stride, tpb, h_save);                            \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
@@ -1308,9 +1340,10 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, ui
   return check_launch("dns_mlp_fwd");
 }
 
-extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
-                           uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* d_x,
-                           uint32_t lddx, float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
+extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
+                           uint32_t lddy, const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
+                           uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2,
+                           float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
                            const int32_t* tile_group, uint32_t param_stride, const float* h_saved, int accumulate_dx,
                            void* stream) {
   if (n_slots == 0) return DNS_OK;
@@ -1319,113 +1352,100 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_bwd: x must be 16-byte aligned with ldx %% 4 == 0");
   DNS_REQUIRE((((uintptr_t)ws) % 16) == 0, "dns_mlp_bwd: ws must be 16-byte aligned");
-  if (d_x) DNS_REQUIRE(lddx >= n_in && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
+  {
+    const int rc = check_segments("dns_mlp_bwd", x2, ldx2, n_in1, n_in);
+    if (rc != DNS_OK) return rc;
+  }
+  if (!x2) n_in1 = n_in;
+  DNS_REQUIRE(!x2 || h_saved, "dns_mlp_bwd: a two-segment input needs the hidden activations kept by dns_mlp_fwd (h_saved)");
+  DNS_REQUIRE(!x2 || !d_x || d_x2, "dns_mlp_bwd: d_x2 is required with a two-segment input when d_x is asked for");
+  if (d_x) DNS_REQUIRE(lddx >= n_in1 && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
+  if (d_x && x2) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd: lddx2 < n_in - n_in1");
   const MlpShape sh = make_shape(n_in, n_out);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t NNr = n_neurons;
-  // The backward can run in CHUNKS of slots (data-gradient kernel, then the weight-gradient GEMMs of the same chunk,
-  // with ONE chunk-sized dH workspace reused so the hand-off stays cache resident).  Measured on MI355X at 262 144
-  // points it does NOT pay: 335 us unchunked vs 378 / 500 / 606 us at 131072 / 65536 / 32768-slot chunks -- the two
-  // kernels are bound by per-launch ramp and staging latency, not by the HBM round trip.  Default: one chunk;
-  // DNS_MLP_CHUNK overrides (kept for larger-than-cache workloads).
-  static const char* ck_env = getenv("DNS_MLP_CHUNK");
-  uint32_t chunk = ck_env ? (uint32_t)atoi(ck_env) : 0x40000000u;
-  chunk = chunk / 128u * 128u;
-  if (chunk < 128u) chunk = 128u;
   static const char* gb_env = getenv("DNS_GEMM_BLOCKS");
-  const uint32_t n_total = n_slots;
-  for (uint32_t s0 = 0; s0 < n_total; s0 += chunk) {
-    const uint32_t n_c = (n_total - s0 < chunk) ? n_total - s0 : chunk;
-    const float* x_c = row_index ? x : x + (size_t)s0 * ldx;
-    const float* dy_c = row_index ? dy : dy + (size_t)s0 * lddy;
-    float* dx_c = (d_x && !row_index) ? d_x + (size_t)s0 * lddx : d_x;
-    const int32_t* ri_c = row_index ? row_index + s0 : nullptr;
-    const int32_t* tg_c = tile_group ? tile_group + s0 / 128u : nullptr;
-    const float* hs_c = h_saved ? h_saved + (size_t)s0 * NNr : nullptr;
-    const uint32_t n_btiles = (n_c + 127u) / 128u;
-    const uint32_t tpb = pick_tiles_per_block(n_btiles, 256, "DNS_MLP_BWD_BLOCKS");
-    const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
+  const DxSeg dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)(accumulate_dx & 1), (uint32_t)((accumulate_dx >> 1) & 1)};
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  const uint32_t tpb = pick_tiles_per_block(n_btiles, 256, "DNS_MLP_BWD_BLOCKS");
+  const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
 #define LAUNCH_BWD2(NN, NL, SV)                                                                                     \
   {                                                                                                                 \
     const size_t lds_bytes = ((size_t)BwdLds<NN, NL, SV>::total(n_in, n_out, d_x != nullptr) + 8 * STG_WAVE_FLOATS) * sizeof(float); \
     (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds_bytes);                                                                      \
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV>), dim3(blocks), dim3(512), lds_bytes, st, x_c, ldx, dy_c,   \
-                       lddy, params, sh, dx_c, lddx, ws, n_c, ri_c, tg_c, param_stride, tpb, hs_c, n_total,         \
-                       accumulate_dx);                                                                              \
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy, \
+                       params, sh, d_x, lddx, dseg, n_in1, ws, n_slots, row_index, tile_group, param_stride, tpb,   \
+                       h_saved, n_slots);                                                                           \
   }
 #define LAUNCH_BWD(NN, NL)            \
   {                                   \
     if (h_saved) LAUNCH_BWD2(NN, NL, true) \
     else LAUNCH_BWD2(NN, NL, false)   \
   }
-    if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_BWD(32, 1)
-    else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_BWD(32, 2)
-    else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_BWD(64, 1)
-    else LAUNCH_BWD(64, 2)
+  if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_BWD(32, 1)
+  else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_BWD(32, 2)
+  else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_BWD(64, 1)
+  else LAUNCH_BWD(64, 2)
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD2
-    int rc = check_launch("dns_mlp_bwd(data)");
-    if (rc != DNS_OK) return rc;
-    if (!d_params) continue;
-    // weight gradients: dW_in = dH1^T X ; dW_h = dH2^T H1 ; dW_out = dY^T H_last
-    const size_t SN = (size_t)n_c * NNr;
-    const float* wsH1 = hs_c ? hs_c : ws;
-    const float* wsD1 = hs_c ? ws : ws + SN;
-    const float* wsH2 = hs_c ? hs_c + (size_t)n_total * NNr : ws + 2 * SN;
-    const float* wsD2 = hs_c ? ws + SN : ws + 3 * SN;
-    GemmTnBatch batch;
-    int ng = 0;
-    auto add = [&](const float* A, uint32_t lda, const int32_t* ai, uint32_t M, const float* B, uint32_t ldb,
-                   const int32_t* bi, uint32_t N, float* Cp, uint32_t ldc) {
-      GemmTnArgs& g = batch.g[ng++];
-      g.A = A; g.lda = lda; g.a_index = ai; g.M = M;
-      g.B = B; g.ldb = ldb; g.b_index = bi; g.N = N;
-      g.C = Cp; g.ldc = ldc; g.c_stride = param_stride;
-      g.n_slots = n_c; g.tile_group = tg_c; g.tiles_per_block = tpb;
-    };
-    add(wsD1, NNr, nullptr, NNr, x_c, ldx, ri_c, n_in, d_params, n_in);
-    float* dwo = d_params + (size_t)NNr * n_in;
-    if (n_hidden_layers == 2) {
-      add(wsD2, NNr, nullptr, NNr, wsH1, NNr, nullptr, NNr, dwo, NNr);
-      dwo += (size_t)NNr * NNr;
-    }
-    add(dy_c, lddy, ri_c, n_out, (n_hidden_layers == 2) ? wsH2 : wsH1, NNr, nullptr, NNr, dwo, NNr);
-    for (int k = ng; k < 3; ++k) batch.g[k] = batch.g[0];
+  int rc = check_launch("dns_mlp_bwd(data)");
+  if (rc != DNS_OK) return rc;
+  if (!d_params) return DNS_OK;
+  // weight gradients: dW_in = dH1^T X ; dW_h = dH2^T H1 ; dW_out = dY^T H_last
+  const size_t SN = (size_t)n_slots * NNr;
+  const float* wsH1 = h_saved ? h_saved : ws;
+  const float* wsD1 = h_saved ? ws : ws + SN;
+  const float* wsH2 = h_saved ? h_saved + SN : ws + 2 * SN;
+  const float* wsD2 = h_saved ? ws + SN : ws + 3 * SN;
+  GemmTnBatch batch;
+  int ng = 0;
+  auto add = [&](const float* A, uint32_t lda, const int32_t* ai, uint32_t M, const float* B, uint32_t ldb,
+                 const int32_t* bi, uint32_t N, float* Cp, uint32_t ldc) {
+    GemmTnArgs& g = batch.g[ng++];
+    g.A = A; g.lda = lda; g.a_index = ai; g.M = M;
+    g.B = B; g.ldb = ldb; g.b_index = bi; g.N = N;
+    g.C = Cp; g.ldc = ldc; g.c_stride = param_stride;
+    g.n_slots = n_slots; g.tile_group = tile_group; g.tiles_per_block = tpb;
+  };
+  add(wsD1, NNr, nullptr, NNr, x, ldx, row_index, n_in1, d_params, n_in);
+  if (x2) add(wsD1, NNr, nullptr, NNr, x2, ldx2, row_index, n_in - n_in1, d_params + n_in1, n_in);
+  float* dwo = d_params + (size_t)NNr * n_in;
+  if (n_hidden_layers == 2) {
+    add(wsD2, NNr, nullptr, NNr, wsH1, NNr, nullptr, NNr, dwo, NNr);
+    dwo += (size_t)NNr * NNr;
+  }
+  add(dy, lddy, row_index, n_out, (n_hidden_layers == 2) ? wsH2 : wsH1, NNr, nullptr, NNr, dwo, NNr);
+  for (int k = ng; k < 4; ++k) batch.g[k] = batch.g[0];
+  static const char* gemm_env = getenv("DNS_GEMM");
+  GemmRoles roles;
+  const bool staged = (gemm_env && gemm_env[0] == 's') || !make_roles(batch.g, ng, roles);
+  DNS_REQUIRE(!(staged && x2), "dns_mlp_bwd: this two-segment input shape is not supported by the weight-gradient kernel");
+  if (staged) {                               // LDS-staged 32x32x2 form: operand shapes the direct form does not take, or A/B
     const uint32_t max_cols = ((n_in + 31u) / 32u) * 32u + NNr > 2 * NNr ? ((n_in + 31u) / 32u) * 32u + NNr : 2 * NNr;
     const uint32_t out_cols = ((n_out + 31u) / 32u) * 32u + NNr;
     const size_t gemm_lds = (size_t)64 * (max_cols > out_cols ? max_cols : out_cols) * sizeof(float);
-    // workgroups per GEMM: measured flat between 256 and 1024 for a 262 144-slot launch (latency-bound staging, not the
-    // final atomic flush, sets the time; fewer than 256 starves the CUs)
     uint32_t gblocks = gb_env ? (uint32_t)atoi(gb_env) : 512u;
     if (gblocks < 1) gblocks = 1;
     uint32_t gtpb = (n_btiles + gblocks - 1) / gblocks;
     if (gtpb < 1) gtpb = 1;
     gblocks = (n_btiles + gtpb - 1) / gtpb;
-    for (int k = 0; k < 3; ++k) batch.g[k].tiles_per_block = gtpb;
-    static const char* gemm_env = getenv("DNS_GEMM");
-    if (gemm_env && gemm_env[0] == 's') {     // LDS-staged 32x32x2 form, kept for A/B measurement
-      hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
-    } else {
-      GemmRoles roles;
-      if (make_roles(batch.g, ng, roles)) {
-        // two workgroups per CU by default (each wave = one unit on its own SIMD); tiles per workgroup bounded by the
-        // LDS weight-set table
-        uint32_t nb = gb_env ? (uint32_t)atoi(gb_env) : 512u;   // 2 workgroups per CU: measured 275 vs 285 us at 256
-        if (nb > n_btiles) nb = n_btiles;
-        const uint32_t nb_min = (n_btiles + GEMM_MAX_TPB - 1) / GEMM_MAX_TPB;
-        if (nb < nb_min) nb = nb_min;
-        if (nb < 1) nb = 1;
-        roles.tiles_per_block = (n_btiles + nb - 1) / nb;
-        nb = (n_btiles + roles.tiles_per_block - 1) / roles.tiles_per_block;
-        static const char* order_env = getenv("DNS_GEMM_ORDER");     // 'c' contiguous / 's' strided, for A/B
-        roles.strided = order_env ? (order_env[0] == 's') : (roles.tile_group == nullptr);
-        const size_t roles_lds = (GEMM_MAX_TPB + (size_t)roles.n_units * 4096) * sizeof(float);
-        hipLaunchKernelGGL(gemm_roles_kernel, dim3(nb), dim3(64 * roles.n_units), roles_lds, st, roles);
-      } else {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
-      }
-    }
+    for (int k = 0; k < 4; ++k) batch.g[k].tiles_per_block = gtpb;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(gblocks, ng), dim3(256), gemm_lds, st, batch);
+  } else {
+    // two workgroups per CU by default (each wave = one unit on its own SIMD); tiles per workgroup bounded by the
+    // LDS weight-set table
+    uint32_t nb = gb_env ? (uint32_t)atoi(gb_env) : 512u;   // 2 workgroups per CU: measured 275 vs 285 us at 256
+    if (nb > n_btiles) nb = n_btiles;
+    const uint32_t nb_min = (n_btiles + GEMM_MAX_TPB - 1) / GEMM_MAX_TPB;
+    if (nb < nb_min) nb = nb_min;
+    if (nb < 1) nb = 1;
+    roles.tiles_per_block = (n_btiles + nb - 1) / nb;
+    nb = (n_btiles + roles.tiles_per_block - 1) / roles.tiles_per_block;
+    static const char* order_env = getenv("DNS_GEMM_ORDER");     // 'c' contiguous / 's' strided, for A/B
+    roles.strided = order_env ? (order_env[0] == 's') : (roles.tile_group == nullptr);
+    const size_t roles_lds = (GEMM_MAX_TPB + (size_t)roles.n_units * 4096) * sizeof(float);
+    hipLaunchKernelGGL(gemm_roles_kernel, dim3(nb), dim3(64 * roles.n_units), roles_lds, st, roles);
   }
   return check_launch("dns_mlp_bwd(weights)");
 }

@@ -398,13 +398,19 @@ class Mapper:
         return torch.cat(out, 0)
 
     # ------------------------------------------------------------------ slams/mapping.py:590-601
-    def fine_fn(self, pes, classes=None, features=None, strict=True):
+    def _class_slots(self, classes, strict):
+        """class id -> row of the pooled per-class parameters (-1: no network); ``strict`` mirrors the reference's
+        ValueError on an unknown class (one host sync)."""
         lut = self.fine_decoders.lut(0)
         cls = classes.clamp(min=0, max=lut.numel() - 1)
         slot = torch.where((classes >= 0) & (classes < lut.numel()), lut[cls], torch.full_like(classes, -1))
         if strict and bool((slot < 0).any()):
             missing = torch.unique(classes[slot < 0]).tolist()
             raise ValueError("Fine decoders does NOT have class", missing)
+        return slot
+
+    def fine_fn(self, pes, classes=None, features=None, strict=True):
+        slot = self._class_slots(classes, strict)
         x = fused_cat(pes, features)
         n = len(self.fine_decoders)
         return ops.mlp_grouped(x, self.fine_decoders.pool[:max(n, 1)], slot, self.pe_dim + self.grid_dim,
@@ -423,9 +429,22 @@ class Mapper:
         pixel_pts = samples["features"].flatten(0, 1)
         buf = self.decoder.pe_fn.forward_world(pts.flatten(0, 1), self.bound)     # :608 + pe_fn, fused
         pe, grid_pts = buf[:, :self.pe_dim], buf[:, self.pe_dim:]
-        coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts)
-        fine_latents = self.fine_fn(pe, classes=classes, features=grid_pts, strict=strict)
-        color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((fine_latents[:, 1:], pixel_pts), -1))
+        if getattr(self, "fused_nets", True) and self.pe_dim % 4 == 0 and self.pe_dim <= 64 and \
+                self.hidden_dim + pixel_pts.shape[1] <= 64 and (self.hidden_dim + pixel_pts.shape[1]) % 4 == 0:
+            # the four networks as one autograd node: no cat for the colour / logit input, in-place gradient sums
+            slot = self._class_slots(classes, strict)
+            dec, pool = self.decoder, self.fine_decoders
+            net = lambda m: (m.n_input_dims, m.n_output_dims, m.n_neurons, m.n_hidden_layers)
+            coarse_latents, fine_latents, color_raw, logits_pts = ops.render_nets(
+                buf, pixel_pts, dec.coarse_fn.decoder.params, pool.pool[:max(len(pool), 1)],
+                dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, slot, self.pe_dim,
+                net(dec.coarse_fn.decoder), (self.pe_dim + self.grid_dim, self.hidden_dim + 1, pool.nn_, pool.nl),
+                net(dec.out_fn.color_decoder), net(dec.out_fn.logit_decoder))
+            color_pts = torch.sigmoid(color_raw)
+        else:
+            coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts)
+            fine_latents = self.fine_fn(pe, classes=classes, features=grid_pts, strict=strict)
+            color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((fine_latents[:, 1:], pixel_pts), -1))
         values_pts = torch.cat((color_pts, fine_latents[:, 0:1]), -1).reshape(n_pts, n_samples, -1)
         logits_pts = logits_pts.reshape(n_pts, n_samples, -1)
         pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)

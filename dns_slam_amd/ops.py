@@ -41,7 +41,7 @@ class _TimedLib:
         return timed
 
     # argument index holding the number of units (points / slots / rays) a launch processes
-    _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 9, "dns_mlp_bwd": 13,
+    _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 12, "dns_mlp_bwd": 18,
                   "dns_composite_fwd": 3, "dns_composite_bwd": 3, "dns_raygen_sample": (14, 15), "dns_raygen_bwd": (7, 8),
                   "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5)}
 
@@ -216,7 +216,7 @@ class _MlpFn(torch.autograd.Function):
         # keep the hidden activations when a backward will follow: it then skips the forward recompute
         keep = MLP_SAVE_HIDDEN and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         h_save = torch.empty(nl * n_slots * nn, device=x.device, dtype=torch.float32) if keep else None
-        check(lib.dns_mlp_fwd(ptr(x), x.stride(0), ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, n_slots,
+        check(lib.dns_mlp_fwd(ptr(x), x.stride(0), None, 0, 0, ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, n_slots,
                               ptr(row_index), ptr(tile_group), stride, ptr(h_save), stream_ptr()), "dns_mlp_fwd")
         ctx.save_for_backward(x, params, row_index, tile_group, h_save)
         ctx.shape, ctx.n_slots, ctx.stride = shape, n_slots, stride
@@ -235,9 +235,9 @@ class _MlpFn(torch.autograd.Function):
             d_x = torch.zeros(P, n_in, device=x.device, dtype=torch.float32) if need_x else None
         d_p = torch.zeros_like(params) if need_p else None
         ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(ctx.n_slots, nn, nl)), device=x.device, dtype=torch.float32)
-        check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(d_x), n_in,
-                              ptr(d_p), ptr(ws), ctx.n_slots, ptr(row_index), ptr(tile_group), ctx.stride,
-                              ptr(h_save), 0, stream_ptr()), "dns_mlp_bwd")
+        check(lib.dns_mlp_bwd(ptr(x), x.stride(0), None, 0, 0, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl,
+                              ptr(d_x), n_in, None, 0, ptr(d_p), ptr(ws), ctx.n_slots, ptr(row_index), ptr(tile_group),
+                              ctx.stride, ptr(h_save), 0, stream_ptr()), "dns_mlp_bwd")
         return d_x, d_p, None, None, None, None
 
 
@@ -274,6 +274,97 @@ def mlp_grouped(x: torch.Tensor, params_pool: torch.Tensor, slot_of_point: torch
     G = params_pool.shape[0]
     row_index, tile_group, n_slots = group_slots(slot_of_point, G, min_count)
     return _MlpFn.apply(x, params_pool, (n_in, n_out, n_neurons, n_hidden_layers), row_index, tile_group, n_slots)
+
+
+# ----------------------------------------------------------------------------- the renderer's four networks, fused glue
+class _RenderNetsFn(torch.autograd.Function):
+    """Coarse + per-class fine + colour + logit networks of ``Mapper.renderer`` (slams/mapping.py:616-626) as ONE
+    autograd node.  Same kernels as ``mlp`` / ``mlp_grouped``; what it removes is glue traffic:
+      * the colour / logit input ``cat(pe, cat(fine[:, 1:], pixel))`` (models/decoder.py:123-124) is never built: the
+        networks read the pe columns of ``buf`` and the [P, 64] feature block as a two-segment input;
+      * in the backward every network adds its input gradient in place (accumulate_dx) into one d_buf / d_feat pair
+        instead of autograd materialising one [P, 80] / [P, 112] gradient per consumer and summing them.
+    buf: [P, pe_dim + grid_dim] (OneBlob | hash grid), pixel: [P, C] 2-D feature code."""
+
+    @staticmethod
+    def forward(ctx, buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg):
+        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count = cfg
+        require_cuda(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point)
+        buf = _row_major_2d(buf.float())
+        pixel = pixel.float()
+        P, dev = buf.shape[0], buf.device
+        keep = MLP_SAVE_HIDDEN
+        st = stream_ptr()
+
+        def run(x, x2, n_in1, params, shape, y, ri, tg, n_slots, stride):
+            n_in, n_out, nn, nl = shape
+            h = torch.empty(nl * n_slots * nn, device=dev, dtype=torch.float32) if keep else None
+            check(lib.dns_mlp_fwd(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params),
+                                  n_in, n_out, nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(h), st),
+                  "dns_mlp_fwd")
+            return h
+
+        coarse = torch.empty(P, shp_c[1], device=dev, dtype=torch.float32)
+        h_c = run(buf, None, 0, coarse_p, shp_c, coarse, None, None, P, 0)
+        ri, tg, n_slots = group_slots(slot_of_point, fine_pool.shape[0], min_count)
+        fine = torch.zeros(P, shp_f[1], device=dev, dtype=torch.float32)
+        h_f = run(buf, None, 0, fine_pool, shp_f, fine, ri, tg, n_slots, fine_pool.shape[-1])
+        feat = torch.cat((fine[:, 1:], pixel), -1)                        # [P, hidden + C]
+        color = torch.empty(P, shp_col[1], device=dev, dtype=torch.float32)
+        logit = torch.empty(P, shp_log[1], device=dev, dtype=torch.float32)
+        h_col = run(buf, feat, pe_dim, color_p, shp_col, color, None, None, P, 0)
+        h_log = run(buf, feat, pe_dim, logit_p, shp_log, logit, None, None, P, 0)
+        ctx.save_for_backward(buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log)
+        ctx.cfg, ctx.n_slots, ctx.pixel_dim = cfg, n_slots, pixel.shape[1]
+        return coarse, fine, color, logit
+
+    @staticmethod
+    def backward(ctx, d_coarse, d_fine, d_color, d_logit):
+        buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log = ctx.saved_tensors
+        pe_dim, shp_c, shp_f, shp_col, shp_log, _ = ctx.cfg
+        P, dev = buf.shape[0], buf.device
+        st = stream_ptr()
+        need_buf = ctx.needs_input_grad[0]
+        need_pix = ctx.needs_input_grad[1]
+        d_buf = torch.empty_like(buf)
+        d_feat = torch.empty_like(feat)
+
+        def run(x, x2, n_in1, dy, params, shape, d_x, d_x2, need_p, ri_, tg_, n_slots, stride, h, acc):
+            n_in, n_out, nn, nl = shape
+            d_p = torch.zeros_like(params) if need_p else None
+            ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(n_slots, nn, nl)), device=dev, dtype=torch.float32)
+            check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1,
+                                  ptr(dy), dy.stride(0), ptr(params), n_in, n_out, nn, nl,
+                                  ptr(d_x), d_x.stride(0), ptr(d_x2), 0 if d_x2 is None else d_x2.stride(0),
+                                  ptr(d_p), ptr(ws), n_slots, ptr(ri_), ptr(tg_), stride, ptr(h), acc, st), "dns_mlp_bwd")
+            return d_p
+
+        def grad(d, like_cols):
+            return torch.zeros(P, like_cols, device=dev) if d is None else _row_major_2d(d.float())
+
+        # 1. coarse: writes all columns of d_buf
+        d_cp = run(buf, None, 0, grad(d_coarse, shp_c[1]), coarse_p, shp_c, d_buf, None, ctx.needs_input_grad[2],
+                   None, None, P, 0, h_c, 0)
+        # 2./3. colour then logit: pe columns of d_buf (+=), feature block d_feat (=, then +=)
+        d_colp = run(buf, feat, pe_dim, grad(d_color, shp_col[1]), color_p, shp_col, d_buf, d_feat,
+                     ctx.needs_input_grad[4], None, None, P, 0, h_col, 1)
+        d_logp = run(buf, feat, pe_dim, grad(d_logit, shp_log[1]), logit_p, shp_log, d_buf, d_feat,
+                     ctx.needs_input_grad[5], None, None, P, 0, h_log, 3)
+        # 4. fine: its output gradient = the caller's + what colour / logit sent back through the feature block
+        d_ft = grad(d_fine, shp_f[1]).clone() if d_fine is not None else torch.zeros(P, shp_f[1], device=dev)
+        d_ft[:, 1:] += d_feat[:, :shp_f[1] - 1]
+        d_fp = run(buf, None, 0, d_ft, fine_pool, shp_f, d_buf, None, ctx.needs_input_grad[3], ri, tg, ctx.n_slots,
+                   fine_pool.shape[-1], h_f, 1)
+        d_pix = d_feat[:, shp_f[1] - 1:] if need_pix else None
+        return (d_buf if need_buf else None), d_pix, d_cp, d_fp, d_colp, d_logp, None, None
+
+
+def render_nets(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, pe_dim, shp_coarse, shp_fine,
+                shp_color, shp_logit, min_count=2):
+    """-> (coarse [P, h+1], fine [P, h+1], colour (pre-sigmoid) [P, 3], logits [P, n_class]); shapes are
+    (n_in, n_out, n_neurons, n_hidden_layers) tuples."""
+    cfg = (int(pe_dim), tuple(shp_coarse), tuple(shp_fine), tuple(shp_color), tuple(shp_logit), int(min_count))
+    return _RenderNetsFn.apply(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg)
 
 
 # ----------------------------------------------------------------------------- compositing

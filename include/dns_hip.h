@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 1
+#define DNS_ABI_VERSION 2
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -125,25 +125,33 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * params: flat fp32 [n_neurons*n_in | (n_hidden_layers-1)*n_neurons^2 | out_pad*n_neurons], row-major
  * matrices, out_pad = next multiple of 16 of n_out.  n_neurons in {32,64}; n_hidden_layers in {1,2};
  * n_in a multiple of 8 and <= 128; n_out <= 64; x 16-byte aligned with ldx % 4 == 0.
- * A workgroup handles 128 consecutive point SLOTS.  row_index (NULL = identity) maps slot -> row of x / y /
- * dy / d_x, -1 = padding slot (computes on zeros, stores nothing).  tile_group (NULL = one net) gives, per
+ * Two-segment input (x2 != NULL): input columns [0, n_in1) are read from x, columns [n_in1, n_in) from
+ * x2[row*ldx2 + (col - n_in1)] -- the torch.cat((pe, features), -1) inputs of decoder.py:73,93,123-124 without
+ * the copy.  n_in1 % 4 == 0; x2 16-byte aligned, ldx2 % 4 == 0.  x2 == NULL: one segment (ldx2, n_in1 ignored).
+ * A workgroup handles 128 consecutive point SLOTS.  row_index (NULL = identity) maps slot -> row of x / x2 / y /
+ * dy / d_x / d_x2, -1 = padding slot (computes on zeros, stores nothing).  tile_group (NULL = one net) gives, per
  * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class
  * fine decoders of slams/mapping.py:590-601 without gathering activations. */
-int dns_mlp_fwd(const float* x, uint32_t ldx, const float* params, uint32_t n_in, uint32_t n_out,
+int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
+                const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
                 float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: hidden activations kept for dns_mlp_bwd */,
                 void* stream);
 
-/* Backward.  Hidden activations come from h_saved (what dns_mlp_fwd wrote) or, if NULL, are recomputed from x.
- * d_x [rows, lddx] written for valid slots (NULL =
- * skip); d_params (+=) same layout as params (+ group*param_stride), NULL = skip.  ws: 16-byte aligned
- * float workspace of dns_mlp_bwd_ws_floats(n_slots, n_neurons, n_hidden_layers) elements. */
-int dns_mlp_bwd(const float* x, uint32_t ldx, const float* dy, uint32_t lddy, const float* params,
+/* Backward.  Hidden activations come from h_saved (what dns_mlp_fwd wrote) or, if NULL, are recomputed from x
+ * (one-segment inputs only).  d_x [rows, lddx] (columns [0, n_in1)) and, with a two-segment input, d_x2
+ * [rows, lddx2] (columns [n_in1, n_in)) are written for valid slots (d_x NULL = skip both); d_params (+=) same
+ * layout as params (+ group*param_stride), NULL = skip.  ws: 16-byte aligned float workspace of
+ * dns_mlp_bwd_ws_floats(n_slots, n_neurons, n_hidden_layers) elements.
+ * accumulate_dx: bit 0 -> d_x += instead of =, bit 1 -> d_x2 += (several networks reading one input add their
+ * input gradients in place instead of through separate buffers and an add). */
+int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
+                const float* dy, uint32_t lddy, const float* params,
                 uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
-                float* d_x, uint32_t lddx, float* d_params, float* ws, uint32_t n_slots,
+                float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params, float* ws, uint32_t n_slots,
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, const float* h_saved,
-                int accumulate_dx /* != 0: d_x += (a second network reading the same input) */, void* stream);
+                int accumulate_dx, void* stream);
 uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers);
 
 /* ---- occupancy compositing (raw2nerf_color, utils/common.py:506-537, + the logit composite of

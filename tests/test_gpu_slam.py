@@ -252,6 +252,35 @@ def test_fused_losses_match_torch_losses():
         assert_close(a.cpu(), b.cpu(), rtol=1e-5, what="fused vs torch loss gradient")
 
 
+@pytest.mark.parametrize("nn,nl", [(32, 1), (64, 2)])
+def test_fused_render_nets_match_per_network_path(nn, nl):
+    """ops.render_nets (two-segment colour / logit input, in-place input-gradient sums) vs the module-by-module path with
+    torch.cat and autograd's own gradient accumulation: same loss, same gradients (incl. poses through the samples)."""
+    cfg, bound, cam, frames, dec, mapper = _setup(n_neurons=nn, n_hidden_layers=nl)
+    mapper.is_BA = True
+    _, ql, Tl = mapper.set_optimizer(frames)
+    torch.manual_seed(31)
+    prep = mapper.prepare_frames(frames)
+    pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+    g = torch.Generator().manual_seed(32)
+    u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+    res = []
+    for fused in (True, False):
+        mapper.fused_nets = fused
+        for q in ql + Tl:
+            q.grad = None
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
+        lo, terms, grads = _loss_and_grads(mapper, dec, s, u_off, u_jit)
+        grads += [dec.out_fn.color_decoder.params.grad.clone()] + [q.grad.clone() for q in ql[1:] + Tl[1:]]
+        res.append((lo, terms, grads))
+    (lf, tf, gf), (lu, tu, gu) = res
+    assert abs(lf - lu) <= 1e-5 * abs(lu)
+    for k in tu:
+        assert abs(tf[k] - tu[k]) <= 1e-5 * max(abs(tu[k]), 1e-7), k
+    for a, b in zip(gf, gu):
+        assert_close(a.cpu(), b.cpu(), rtol=2e-5, what="fused vs per-network gradient")
+
+
 def test_static_shapes_masking_equals_ray_dropping():
     """Rays whose depth leaves the box: dropped by the reference (slams/mapping.py:576-586, host sync) vs kept with
     valid=0 in the sync-free path -- same loss and gradients (per_ray label layout)."""
