@@ -36,23 +36,28 @@ __global__ __launch_bounds__(256) void tv_fwd_kernel(const float* __restrict__ l
 }
 
 // d_lat [n^3, ld]: column 0 = d loss / d occ, the other columns zero (the gradient of coarse[:, 0:1] padded back)
+// Flat walk over the [n^3 * ld] output (coalesced stores; a thread-per-point walk writes 132-byte rows at a 132-byte lane
+// stride, 33 scattered store instructions per wave): the element that is a row's column 0 evaluates the stencil.
 __global__ __launch_bounds__(256) void tv_bwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t n, float inv_norm,
                                                      const float* __restrict__ g, float* __restrict__ d_lat) {
-  const uint32_t total = n * n * n;
+  const uint32_t total = n * n * n * ld;               // < 2^32 (checked on the host)
   const float c = 2.0f * inv_norm * g[0];
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
-    const float v = lat[(size_t)e * ld];
-    float a = 0.f;
-    if (i + 1 < n) a -= lat[(size_t)(e + n * n) * ld] - v;
-    if (i > 0) a += v - lat[(size_t)(e - n * n) * ld];
-    if (j + 1 < n) a -= lat[(size_t)(e + n) * ld] - v;
-    if (j > 0) a += v - lat[(size_t)(e - n) * ld];
-    if (k + 1 < n) a -= lat[(size_t)(e + 1) * ld] - v;
-    if (k > 0) a += v - lat[(size_t)(e - 1) * ld];
-    float* row = d_lat + (size_t)e * ld;
-    row[0] = c * a;
-    for (uint32_t q = 1; q < ld; ++q) row[q] = 0.f;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const uint32_t e = t / ld;
+    float out = 0.f;
+    if (t - e * ld == 0) {
+      const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
+      const float v = lat[(size_t)e * ld];
+      float a = 0.f;
+      if (i + 1 < n) a -= lat[(size_t)(e + n * n) * ld] - v;
+      if (i > 0) a += v - lat[(size_t)(e - n * n) * ld];
+      if (j + 1 < n) a -= lat[(size_t)(e + n) * ld] - v;
+      if (j > 0) a += v - lat[(size_t)(e - n) * ld];
+      if (k + 1 < n) a -= lat[(size_t)(e + 1) * ld] - v;
+      if (k > 0) a += v - lat[(size_t)(e - 1) * ld];
+      out = c * a;
+    }
+    d_lat[t] = out;
   }
 }
 
@@ -146,8 +151,9 @@ extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sa
 extern "C" int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, const float* g, float* d_lat,
                           void* stream) {
   DNS_REQUIRE(lat && g && d_lat && n >= 1 && ld >= 1, "dns_tv_bwd: bad argument");
-  const uint32_t total = n * n * n;
-  const uint32_t blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+  DNS_REQUIRE((uint64_t)n * n * n * ld < 0xFFFFFFFFull, "dns_tv_bwd: lattice too large for 32-bit indexing");
+  const uint32_t total = n * n * n * ld;
+  const uint32_t blocks = (total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192;
   const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
   hipLaunchKernelGGL(tv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lat, ld, n, inv, g, d_lat);
   return check_launch("dns_tv_bwd");

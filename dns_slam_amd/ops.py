@@ -193,6 +193,7 @@ def _row_major_2d(x: torch.Tensor) -> torch.Tensor:
 
 # True: the forward keeps the hidden activations (512 B/point at 2x64) and the backward skips the recompute;
 # False: nothing is kept and dns_mlp_bwd recomputes them from x (less memory, ~1.7x more MFMA work in the backward).
+LOSS_SUMS_FLOATS = 32 + 5 * 1024          # include/dns_hip.h DNS_LOSS_SUMS_FLOATS
 MLP_SAVE_HIDDEN = True
 
 
@@ -504,11 +505,12 @@ class _LossFn(torch.autograd.Function):
         L = 1 if fine is None else fine.shape[-1]
         dev = pred_depth.device
         lam = (C.c_float * 8)(*[float(v) for v in lambdas])
-        sums = torch.empty(16, device=dev)
+        sums_ws = torch.empty(LOSS_SUMS_FLOATS, device=dev)     # [0:16] results, the rest reduction workspace
+        sums = sums_ws[:16]
         out = torch.empty(16, device=dev)
         check(lib.dns_loss_sums(lam, N, S, Cn, L, int(tracker), ptr(pred_color), ptr(pred_depth), ptr(pred_var),
                                 ptr(pred_logits), ptr(gt_color), ptr(gt_depth), ptr(gt_label), ptr(valid), ptr(fine),
-                                ptr(coarse), ptr(z), ptr(sums), stream_ptr()), "dns_loss_sums")
+                                ptr(coarse), ptr(z), ptr(sums_ws), stream_ptr()), "dns_loss_sums")
         if reduce_sums is not None:
             reduce_sums(sums)                      # multi-GPU: global numerators / counts (dns_slam_amd.dist)
         check(lib.dns_loss_finalize(lam, N, S, Cn, L, int(tracker), ptr(sums), ptr(out), stream_ptr()), "dns_loss_finalize")

@@ -172,10 +172,12 @@ int dns_composite_bwd(const float* raw, const float* z, const float* logits, uin
  * lambdas [host, 8 floats] = lambda_p, lambda_d, lambda_l, lambda_lt, lambda_fs, lambda_opacity, truncation, sigma.
  * Rays: pred_color [N,3], pred_depth [N], pred_var [N] (tracker), pred_logits [N,C], gt_color [N,3], gt_depth [N],
  * gt_label [N] int64, valid [N] uint8 (NULL = all rays count).  Points (mapper): fine, coarse [N*S, L], z [N,S].
- * Three calls: dns_loss_sums fills sums[16] (numerators and counts; multi-GPU callers all-reduce it here),
+ * Three calls: dns_loss_sums fills sums[0..15] (numerators and counts; multi-GPU callers all-reduce those 16 here;
+ * the buffer must hold DNS_LOSS_SUMS_FLOATS floats, the rest is reduction workspace),
  * dns_loss_finalize turns it into out[16] = {p, d, l, lt, fs, op, total, -, coefficients...},
  * dns_loss_bwd writes d(total * g_total)/d(inputs): d_color, d_depth, d_var (tracker; may be NULL), d_logits,
  * d_fine, d_coarse (overwritten). */
+#define DNS_LOSS_SUMS_FLOATS (32 + 5 * 1024)
 int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
                   const float* pred_color, const float* pred_depth, const float* pred_var, const float* pred_logits,
                   const float* gt_color, const float* gt_depth, const int64_t* gt_label, const uint8_t* valid,
