@@ -12,6 +12,7 @@
 // (__fmul_rn/__fadd_rn, never contracted), the cell is (uint32)(int)floorf(pos); hash primes
 // {1, 2654435761, 805459861}; index % level size.  Those make the table rows bit-exact.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 
 namespace dns {
@@ -330,6 +331,15 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
   if ((threadIdx.x & 63u) == 0 && m > 0.f && m < INFINITY) atomicMax(gmax, __float_as_uint(m));
 }
 
+// round-to-nearest-even of an fp32 value with |v| < 2^40 to a 64-bit integer: v = hi * 2^16 + lo exactly (hi = trunc(v /
+// 2^16), |hi| < 2^24; lo = v - hi * 2^16 is exact in fp32), and rint(v) = hi * 2^16 + rint(lo) because hi * 2^16 is even
+__device__ __forceinline__ long long fixed_rn(float v) {
+  const float hi_f = truncf(v * (1.0f / 65536.0f));
+  const float lo_f = fmaf(-hi_f, 65536.0f, v);
+  const int hi = (int)hi_f, lo = (int)rintf(lo_f);
+  return ((long long)hi << 16) + (long long)lo;
+}
+
 __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* __restrict__ xin, uint32_t P,
                                                                     GridLevels lv, BinPlan plan,
                                                                     const float2* __restrict__ dg_t,
@@ -403,57 +413,71 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
       xn[2] = xin[(size_t)p * 3 + 2];
     }
   }
-  for (uint32_t it = 0; it < n_it; ++it) {
-    const float2 gg = gg_n;
-    const float xc[3] = {xn[0], xn[1], xn[2]};
-    const bool live = point_of(it) < p_hi;
-    gg_n = make_float2(0.f, 0.f);
-    if (it + 1 < n_it) {
-      const uint32_t pn = point_of(it + 1);
-      if (pn < p_hi) {
-        gg_n = dgl[pn];
-        xn[0] = xin[(size_t)pn * 3];
-        xn[1] = xin[(size_t)pn * 3 + 1];
-        xn[2] = xin[(size_t)pn * 3 + 2];
+  // The kernel is VALU-bound (SQ counters: 77 % VALU-busy, 288 vector instructions per 64-point visit before this form):
+  // the per-axis hash / stride terms are computed once per point (two quarter-rate multiplies instead of two per corner
+  // and again per hit), the dense / hashed split is hoisted to a uniform branch, and the float -> 64-bit fixed-point
+  // conversion is the 11-instruction split below instead of the library's generic f32 -> i64.
+  auto sweep = [&](auto hashed_tag) {
+    constexpr bool HASHED = decltype(hashed_tag)::value;
+    const uint32_t mask = size - 1u, res2 = res * res;
+    for (uint32_t it = 0; it < n_it; ++it) {
+      const float2 gg = gg_n;
+      const float xc[3] = {xn[0], xn[1], xn[2]};
+      const bool live = point_of(it) < p_hi;
+      gg_n = make_float2(0.f, 0.f);
+      if (it + 1 < n_it) {
+        const uint32_t pn = point_of(it + 1);
+        if (pn < p_hi) {
+          gg_n = dgl[pn];
+          xn[0] = xin[(size_t)pn * 3];
+          xn[1] = xin[(size_t)pn * 3 + 1];
+          xn[2] = xin[(size_t)pn * 3 + 2];
+        }
+      }
+      const bool work = live && !(gg.x == 0.f && gg.y == 0.f);
+      const float gs0 = gg.x * scale, gs1 = gg.y * scale;                  // exact: power-of-two scale
+      float f[3];
+      uint32_t g[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
+        const float fl = floorf(pos);
+        g[a] = (uint32_t)(int)fl;
+        f[a] = pos - fl;
+      }
+      // per-axis terms of the row index: hashed  x ^ y*P1 ^ z*P2,  dense  x + y*res + z*res^2
+      const uint32_t ax0 = g[0], ax1 = g[0] + 1u;
+      const uint32_t ay0 = HASHED ? g[1] * 2654435761u : g[1] * res, ay1 = ay0 + (HASHED ? 2654435761u : res);
+      const uint32_t az0 = HASHED ? g[2] * 805459861u : g[2] * res2, az1 = az0 + (HASHED ? 805459861u : res2);
+      auto row_of = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {
+        if (HASHED) return (x ^ y ^ z) & mask;                            // hashed levels are exactly 2^T rows
+        uint32_t idx = x + y + z;
+        if (idx >= size) idx %= size;
+        return idx;
+      };
+      const uint32_t rows_eff = work ? rows : 0u;                          // idle lanes never hit
+      // Only ~1/8 of the corners of a hashed level land in this chunk: a branch-free pass builds the lane's 8-bit hit
+      // mask, then the wave pops one hit per lane per round (max-hits-per-lane rounds of two ds_add_u64).
+      uint32_t hit_mask = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t local = row_of((c & 1) ? ax1 : ax0, (c & 2) ? ay1 : ay0, (c & 4) ? az1 : az0) - base;
+        hit_mask |= (local < rows_eff ? 1u : 0u) << c;
+      }
+      while (__any(hit_mask != 0)) {
+        if (hit_mask) {
+          const uint32_t c = (uint32_t)__ffs((int)hit_mask) - 1u;
+          hit_mask &= hit_mask - 1u;
+          const uint32_t local = row_of((c & 1u) ? ax1 : ax0, (c & 2u) ? ay1 : ay0, (c & 4u) ? az1 : az0) - base;
+          const float w = ((c & 1u) ? f[0] : 1.0f - f[0]) * ((c & 2u) ? f[1] : 1.0f - f[1]) * ((c & 4u) ? f[2] : 1.0f - f[2]);
+          atomicAdd(bins + 2 * local, (unsigned long long)fixed_rn(w * gs0));
+          atomicAdd(bins + 2 * local + 1, (unsigned long long)fixed_rn(w * gs1));
+        }
       }
     }
-    const bool work = live && !(gg.x == 0.f && gg.y == 0.f);
-    const float gs0 = gg.x * scale, gs1 = gg.y * scale;                  // exact: power-of-two scale
-    float fsave[3];
-    uint32_t gsave[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
-      const float fl = floorf(pos);
-      gsave[a] = (uint32_t)(int)fl;
-      fsave[a] = pos - fl;
-    }
-    uint32_t hit_mask = 0;
-    const uint32_t* g = gsave;
-    const uint32_t rows_eff = work ? rows : 0u;                          // idle lanes never hit
-    // Only ~1/8 of the corners of a hashed level land in this chunk.  Issuing the two ds_add_u64 under each corner's own
-    // branch costs 16 LDS atomic instructions per step with ~8 live lanes each (the LDS atomic pipe is paid per
-    // instruction, not per lane); instead: a branch-free pass builds the lane's 8-bit hit mask, then the wave pops one
-    // hit per lane per round -- max-hits-per-lane rounds (3-4) of two denser atomics.
-    uint32_t hits = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint32_t local = grid_row(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, size, hashed) - base;
-      hits |= (local < rows_eff ? 1u : 0u) << c;
-    }
-    hit_mask = hits;
-    while (__any(hit_mask != 0)) {
-      if (hit_mask) {
-        const uint32_t c = (uint32_t)__ffs((int)hit_mask) - 1u;
-        hit_mask &= hit_mask - 1u;
-        const uint32_t local = grid_row(gsave[0] + (c & 1u), gsave[1] + ((c >> 1) & 1u), gsave[2] + ((c >> 2) & 1u), res, size, hashed) - base;
-        const float w = ((c & 1u) ? fsave[0] : 1.0f - fsave[0]) * ((c & 2u) ? fsave[1] : 1.0f - fsave[1]) *
-                        ((c & 4u) ? fsave[2] : 1.0f - fsave[2]);
-        atomicAdd(bins + 2 * local, (unsigned long long)__float2ll_rn(w * gs0));
-        atomicAdd(bins + 2 * local + 1, (unsigned long long)__float2ll_rn(w * gs1));
-      }
-    }
-  }
+  };
+  if (hashed) sweep(std::true_type{});
+  else sweep(std::false_type{});
   __syncthreads();
   float* out = d_table + 2 * ((size_t)lv.offset[l] + base);
   for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) {
