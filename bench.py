@@ -55,7 +55,7 @@ def algorithmic_cost(name, units, wl):
     return 0, 0
 
 
-def build(wl, device, seed, dist_ctx):
+def build(wl, device, seed, dist_ctx, overlap=False):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
@@ -71,6 +71,7 @@ def build(wl, device, seed, dist_ctx):
     mapper.dist = dist_ctx
     mapper.is_BA = True
     mapper.static_shapes = True                              # sync-free iteration: capturable in a hipGraph
+    mapper.overlap_smooth = overlap
     mapper.set_decoder(frames)
     optimizer, quad_list, T_list = mapper.set_optimizer(frames, fused=True)     # csrc/adam.hip: one launch, step count on device
     for grp, lr in zip(optimizer.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):
@@ -186,7 +187,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-step progress on stderr")
     ap.add_argument("--no-render-forward", action="store_true", help="skip the secondary full-image render line")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the iteration from a hipGraph (one stream) instead of launching it eagerly on two streams")
+    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches; kept for older command lines")
+    ap.add_argument("--no-overlap", action="store_true", help="eager, but keep the smoothness branch on the main stream")
     args = ap.parse_args()
 
     from dns_slam_amd import dist as ddist
@@ -196,13 +200,14 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]
-    cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + ctx.rank, dist_ctx=ctx)
+    overlap = not args.graph and not args.no_overlap          # hipGraph replay serialises the two branches: no gain there
+    cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + ctx.rank, dist_ctx=ctx, overlap=overlap)
     n_rays = 4 * sum(wl["rays"])
     S = wl["nu"] + wl["ns"]
 
     run = step
     graphed = False
-    if not args.no_graph:
+    if args.graph and not args.no_graph:
         try:
             run = capture(step)
             graphed = True
@@ -275,7 +280,7 @@ def main():
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "hip_graph": graphed,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
                    "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
         "roofline": roofline,

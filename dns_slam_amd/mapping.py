@@ -482,6 +482,18 @@ class Mapper:
 
     # ------------------------------------------------------------------ slams/mapping.py:887-907
     def iteration_loss(self, samples, lambda_lt=10.0, smooth=True, u_offset=None, u_jitter=None, strict=False):
+        # The smoothness branch (lattice encode + coarse network, forward and -- since autograd replays a node on its
+        # forward stream -- backward) shares nothing with the ray branch until the gradients meet: on a second HIP
+        # stream its kernels fill the ramps / tails of the ray branch's launches (both capture into one hipGraph).
+        side = None
+        if smooth and getattr(self, "overlap_smooth", False) and self.device != "cpu":
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                smooth_pre = self.smoothness(sample_points=self.cfg["training"]["smooth_pts"], u_offset=u_offset,
+                                             u_jitter=u_jitter)
         pred_color, pred_depth, _, pred_logits, fine_latents, coarse_latents = self.renderer(samples, strict=strict)
         tr = self.cfg["training"]
         world = self.dist.world_size if (self.dist is not None and self.dist.enabled) else 1
@@ -507,7 +519,11 @@ class Mapper:
             terms = {"p_loss": p_loss, "d_loss": d_loss, "l_loss": l_loss, "lt_loss": lt_loss, "fs_loss": fs_loss,
                      "opacity_loss": opacity_loss}
         if smooth:
-            smooth_loss = self.smoothness(sample_points=tr["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                smooth_loss = smooth_pre
+            else:
+                smooth_loss = self.smoothness(sample_points=tr["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
             # multi-GPU: gradients are SUMMED over ranks, so each rank's lattice contributes 1/W (average of W lattices)
             loss = loss + (self.lambda_sm / world) * smooth_loss
             terms["smooth_loss"] = smooth_loss

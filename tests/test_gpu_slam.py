@@ -281,6 +281,26 @@ def test_fused_render_nets_match_per_network_path(nn, nl):
         assert_close(a.cpu(), b.cpu(), rtol=2e-5, what="fused vs per-network gradient")
 
 
+def test_smoothness_branch_on_a_second_stream_matches_single_stream():
+    """Mapper.overlap_smooth: the lattice branch runs (forward and backward) on a side stream; same loss and gradients."""
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    mapper.is_BA = False
+    _, ql, Tl = mapper.set_optimizer(frames)
+    torch.manual_seed(41)
+    s = mapper.get_target_samples(frames, ql, Tl)
+    g = torch.Generator().manual_seed(42)
+    u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+    res = []
+    for ov in (True, False, True):
+        mapper.overlap_smooth = ov
+        res.append(_loss_and_grads(mapper, dec, s, u_off, u_jit))
+        torch.cuda.synchronize()
+    for lo, terms, grads in (res[0], res[2]):
+        assert abs(lo - res[1][0]) <= 1e-6 * abs(res[1][0])
+        for a, b in zip(grads, res[1][2]):
+            assert_close(a.cpu(), b.cpu(), rtol=1e-5, what="two-stream vs one-stream gradient")
+
+
 def test_static_shapes_masking_equals_ray_dropping():
     """Rays whose depth leaves the box: dropped by the reference (slams/mapping.py:576-586, host sync) vs kept with
     valid=0 in the sync-free path -- same loss and gradients (per_ray label layout)."""
