@@ -168,6 +168,51 @@ def test_mlp_grouped_matches_per_class_loop(nn, nl):
     assert_close(pp.grad.cpu()[:, :used], po.grad[:, :used], what="grouped dparams")
 
 
+@pytest.mark.parametrize("nn,nl,P", [(64, 2, 1500), (32, 1, 333)])
+def test_render_nets_two_segment_input_and_in_place_gradient_sums(nn, nl, P):
+    """ops.render_nets vs the oracle MLPs wired like Mapper.renderer (slams/mapping.py:616-626, models/decoder.py:
+    123-124): coarse(buf), per-class fine(buf), colour / logit(cat(pe, fine[:, 1:], pixel)).  Covers the two-segment
+    input of dns_mlp_fwd/bwd (48 | 64 columns), accumulate_dx bits 0 and 1, the grouped network adding into the same
+    input gradient, and the pixel-feature gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    G, pe_dim, hid, C, n_class = 3, 48, 32, 32, 8
+    shp_c, shp_f = (80, hid + 1, nn, nl), (80, hid + 1, nn, nl)
+    shp_col, shp_log = (pe_dim + hid + C, 3, nn, nl), (pe_dim + hid + C, n_class, nn, nl)
+    cp = tr.mlp_init(*shp_c, g)
+    pool = torch.stack([tr.mlp_init(*shp_f, g) for _ in range(G)])
+    colp, logp = tr.mlp_init(*shp_col, g), tr.mlp_init(*shp_log, g)
+    buf, pix = torch.randn(P, 80, generator=g), torch.randn(P, C, generator=g)
+    slot = torch.randint(0, G, (P,), generator=g)
+    slot[5] = -1
+    gw = [torch.randn(P, n, generator=g) for n in (hid + 1, hid + 1, 3, n_class)]
+
+    # oracle wiring
+    bo, xo = buf.clone().requires_grad_(True), pix.clone().requires_grad_(True)
+    po = [t.clone().requires_grad_(True) for t in (cp, pool, colp, logp)]
+    coarse = tr.mlp_forward(bo, po[0], *shp_c)
+    fine = torch.zeros(P, hid + 1)
+    for c in range(G):
+        idx = torch.nonzero(slot == c).reshape(-1)
+        if idx.numel() > 1:
+            fine = fine.index_put((idx,), tr.mlp_forward(bo[idx], po[1][c], *shp_f))
+    xin = torch.cat((bo[:, :pe_dim], fine[:, 1:], xo), -1)
+    outs_o = [coarse, fine, tr.mlp_forward(xin, po[2], *shp_col), tr.mlp_forward(xin, po[3], *shp_log)]
+    sum((o * w).sum() for o, w in zip(outs_o, gw)).backward()
+
+    bp, xp = buf.to(DEV).requires_grad_(True), pix.to(DEV).requires_grad_(True)
+    pp = [t.to(DEV).requires_grad_(True) for t in (cp, pool, colp, logp)]
+    outs_p = ops.render_nets(bp, xp, pp[0], pp[1], pp[2], pp[3], slot.to(DEV), pe_dim, shp_c, shp_f, shp_col, shp_log)
+    sum((o * w.to(DEV)).sum() for o, w in zip(outs_p, gw)).backward()
+    for a, b, name in zip(outs_p, outs_o, ("coarse", "fine", "colour", "logit")):
+        assert_close(a.cpu(), b, what=f"render_nets {name}")
+    assert_close(bp.grad.cpu(), bo.grad, what="render_nets d_buf")
+    assert_close(xp.grad.cpu(), xo.grad, what="render_nets d_pixel")
+    for a, b, shp, name in zip(pp, po, (shp_c, shp_f, shp_col, shp_log), ("coarse", "fine pool", "colour", "logit")):
+        used = shp[0] * nn + (nl - 1) * nn * nn + shp[1] * nn
+        assert_close(a.grad.cpu()[..., :used], b.grad[..., :used], what=f"render_nets d_params {name}")
+
+
 # ----------------------------------------------------------------------------------------- compositing
 def test_composite_golden(golden_dir):
     """raw2nerf_color outputs and input gradient of the IMPORTED reference."""

@@ -1,6 +1,6 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/pmc_traffic.json + a text table.
 
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-timing
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 2 --no-overlap --no-cpu-baseline --no-kernel-timing --no-render-forward
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py ... (same)
     python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg2 r01
 
@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, workload, tag = sys.argv[1:5]
 ENTRY = {  # C-ABI entry point -> kernels it launches
-    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_data_kernel", "gemm_tn_kernel"],
+    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_data_kernel", "gemm_tn_kernel", "gemm_roles_kernel"],
     "dns_encode_fwd": ["encode_fwd_kernel"], "dns_encode_bwd": ["encode_bwd_kernel", "dgrid_transpose_kernel", "hashgrid_bwd_binned_kernel"],
     "dns_composite_fwd": ["composite_fwd_kernel"], "dns_composite_bwd": ["composite_bwd_kernel"],
     "dns_loss_sums": ["loss_ray_sums_kernel", "loss_point_sums_kernel"], "dns_loss_bwd": ["loss_ray_bwd_kernel", "loss_point_bwd_kernel"],
@@ -23,7 +23,7 @@ GATHER = ("encode_fwd_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel"
 
 
 def load(d):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if "dns::" not in r["Kernel_Name"]:
