@@ -194,6 +194,8 @@ def main():
     args = ap.parse_args()
 
     from dns_slam_amd import dist as ddist
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # intended: the lattice branch's stream
     from dns_slam_amd import ops
     ctx = ddist.init_from_env()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -237,11 +239,13 @@ def main():
     # C-ABI call (a replayed graph cannot be bracketed per kernel; kernels and shapes are identical)
     kernel_times = {}
     if not args.no_kernel_timing:
+        mapper.overlap_smooth = False           # one stream: an event pair must bracket its own kernel only
         ops.timer.arm()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         kernel_times = ops.timer.disarm()
+        mapper.overlap_smooth = overlap
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_rays * S * ctx.world_size / (ms_per_step / 1e3)
 

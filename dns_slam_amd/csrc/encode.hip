@@ -66,6 +66,10 @@ __device__ __forceinline__ void load_point(const float* __restrict__ in, const B
 // the lane's channels go to an LDS tile (row stride +1 float: conflict-free) and the workgroup's tile leaves as one
 // contiguous, fully coalesced run.  Direct 16-byte row stores at a 320-byte lane stride were measured to cost 3.4x
 // the bytes in HBM writes (rocprofv3 WRITE_SIZE 286 MB for an 84 MB output): every store instruction touches 64 lines.
+// TILED: the workgroup's output rows leave as contiguous runs through an LDS tile (direct 16-byte row stores at a 320-byte
+// lane stride cost 3.4x the bytes in HBM writes).  The tile is used TWICE -- OneBlob columns, flush, then grid columns,
+// flush -- so it holds max(pe_dim, g_dim) + 1 floats per point (25 KB instead of 41 KB): LDS, not registers (68 VGPRs),
+// is what limits this gather kernel's occupancy, and 12 waves per CU hide the table-gather latency better than 6.
 template <bool TILED>
 __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict__ in, Bound6 bd, int normalise,
                                                          uint32_t P, uint32_t n_bins,
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
-  const uint32_t ldt = pe_dim + g_dim + 1;
+  const uint32_t ldt = max(pe_dim, g_dim) + 1;
   const bool live = p < P;
   float x[3] = {0.f, 0.f, 0.f};
   if (live) load_point(in, bd, normalise != 0, p, x);
@@ -86,74 +90,77 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
     x_out[(size_t)p * 3 + 2] = x[2];
   }
   float* trow = tile + threadIdx.x * ldt;
-  if (live && pe_out) {
-    const float n = (float)n_bins;
-    float* row = TILED ? trow : pe_out + (size_t)p * ld_pe;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float xa = x[a];
-      float first = 0.f, left = 0.f;
-      for (uint32_t b = 0; b <= n_bins; ++b) {
-        float g;
-        if (b < n_bins) {
-          const float d = (float)b / n - xa;
-          g = quartic_cdf(d, n) + quartic_cdf(d - 1.0f, n) + quartic_cdf(d + 1.0f, n);
-          if (b == 0) first = g;
-        } else {
-          g = first + 1.0f;  // right edge of the last bin wraps (tcnn kernel_one_blob)
-        }
-        if (b > 0) row[a * n_bins + b - 1] = g - left;
-        left = g;
-      }
-    }
-  }
-  if (live && grid_out) {
-    float* row = TILED ? trow + pe_dim : grid_out + (size_t)p * ld_grid;
-#pragma unroll 4
-    for (uint32_t l = 0; l < lv.n_levels; ++l) {
-      const float s = lv.scale[l];
-      const uint32_t res = lv.resolution[l], size = lv.size[l], hashed = lv.hashed[l];
-      const float2* __restrict__ t = table + lv.offset[l];
-      float f[3];
-      uint32_t g[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float pos = __fadd_rn(__fmul_rn(x[a], s), 0.5f);
-        const float fl = floorf(pos);
-        g[a] = (uint32_t)(int)fl;
-        f[a] = pos - fl;
-      }
-      float2 v[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        v[c] = t[grid_row(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, size, hashed)];
-      float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float w = ((c & 1) ? f[0] : 1.0f - f[0]) * ((c & 2) ? f[1] : 1.0f - f[1]) * ((c & 4) ? f[2] : 1.0f - f[2]);
-        a0 += w * v[c].x;
-        a1 += w * v[c].y;
-      }
-      row[2 * l] = a0;
-      row[2 * l + 1] = a1;
-    }
-  }
-  if (TILED) {
+  // rows [p0, p0 + rows) x columns [c0, c0 + nc) of the row-major output with leading dimension ld, from the tile
+  auto flush = [&](float* out_base, uint32_t ld, uint32_t nc) {
     __syncthreads();
-    const uint32_t ld = pe_dim + g_dim;
     const uint32_t p0 = blockIdx.x * blockDim.x;
     const uint32_t rows = min(blockDim.x, P - p0);
-    float* out = pe_out + (size_t)p0 * ld;
-    for (uint32_t i = threadIdx.x; i < rows * ld; i += blockDim.x) {
-      const uint32_t r = i / ld, c = i - r * ld;
-      out[i] = tile[r * ldt + c];
+    float* out = out_base + (size_t)p0 * ld;
+    for (uint32_t i = threadIdx.x; i < rows * nc; i += blockDim.x) {
+      const uint32_t r = i / nc, c = i - r * nc;
+      out[(size_t)r * ld + c] = tile[r * ldt + c];
     }
+    __syncthreads();
+  };
+  if (pe_out) {
+    if (live) {
+      const float n = (float)n_bins;
+      float* row = TILED ? trow : pe_out + (size_t)p * ld_pe;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float xa = x[a];
+        float first = 0.f, left = 0.f;
+        for (uint32_t b = 0; b <= n_bins; ++b) {
+          float g;
+          if (b < n_bins) {
+            const float d = (float)b / n - xa;
+            g = quartic_cdf(d, n) + quartic_cdf(d - 1.0f, n) + quartic_cdf(d + 1.0f, n);
+            if (b == 0) first = g;
+          } else {
+            g = first + 1.0f;  // right edge of the last bin wraps (tcnn kernel_one_blob)
+          }
+          if (b > 0) row[a * n_bins + b - 1] = g - left;
+          left = g;
+        }
+      }
+    }
+    if (TILED) flush(pe_out, ld_pe, pe_dim);
+  }
+  if (grid_out) {
+    if (live) {
+      float* row = TILED ? trow : grid_out + (size_t)p * ld_grid;
+#pragma unroll 4
+      for (uint32_t l = 0; l < lv.n_levels; ++l) {
+        const float s = lv.scale[l];
+        const uint32_t res = lv.resolution[l], size = lv.size[l], hashed = lv.hashed[l];
+        const float2* __restrict__ t = table + lv.offset[l];
+        float f[3];
+        uint32_t g[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float pos = __fadd_rn(__fmul_rn(x[a], s), 0.5f);
+          const float fl = floorf(pos);
+          g[a] = (uint32_t)(int)fl;
+          f[a] = pos - fl;
+        }
+        float2 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          v[c] = t[grid_row(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, size, hashed)];
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float w = ((c & 1) ? f[0] : 1.0f - f[0]) * ((c & 2) ? f[1] : 1.0f - f[1]) * ((c & 4) ? f[2] : 1.0f - f[2]);
+          a0 += w * v[c].x;
+          a1 += w * v[c].y;
+        }
+        row[2 * l] = a0;
+        row[2 * l + 1] = a1;
+      }
+    }
+    if (TILED) flush(grid_out, ld_grid, g_dim);
   }
 }
-
-// Input-gradient walk (and, without a workspace, the per-corner atomic table scatter).  TILED = d_pe | d_grid are the
-// columns of one contiguous [P, ld] buffer: the workgroup's 128 rows are read as one coalesced run into LDS and each
-// lane takes its row from there (row stride +1 float) instead of walking a 320-byte-strided row in global memory.
 template <bool TILED>
 __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict__ xin, Bound6 bd, int scale_by_bound,
                                                          uint32_t P, uint32_t n_bins,
@@ -534,7 +541,7 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
   const uint32_t pe_dim = 3 * n_bins, g_dim = grid_out ? 2 * meta->n_levels : 0;
   const bool tiled = pe_out && grid_out && ld_pe == pe_dim + g_dim && ld_grid == ld_pe && grid_out == pe_out + pe_dim;
   if (tiled) {
-    const size_t lds_bytes = (size_t)128 * (pe_dim + g_dim + 1) * sizeof(float);
+    const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
     hipLaunchKernelGGL(encode_fwd_kernel<true>, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound),
                        bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid);
   } else {
