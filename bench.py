@@ -199,6 +199,8 @@ def main():
     from dns_slam_amd import ops
     ctx = ddist.init_from_env()
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DNS_FORCE_DEVICE") is not None:       # rehearsal of the N-rank path on a one-GPU box (with gloo)
+        local = int(os.environ["DNS_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]

@@ -104,7 +104,7 @@ def init_from_env(backend: Optional[str] = None) -> DistCtx:
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("DNS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
