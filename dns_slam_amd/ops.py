@@ -330,9 +330,17 @@ class _RenderNetsFn(torch.autograd.Function):
         d_buf = torch.empty_like(buf)
         d_feat = torch.empty_like(feat)
 
+        # one zero-fill for the four parameter gradients (they are views of one buffer)
+        need = [ctx.needs_input_grad[i] for i in (2, 3, 4, 5)]
+        sizes = [p.numel() if n else 0 for p, n in zip((coarse_p, fine_pool, color_p, logit_p), need)]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        offs = [sum(sizes[:i]) for i in range(4)]
+        dps = {id(p): (flat[o:o + z].view_as(p) if n else None)
+               for p, o, z, n in zip((coarse_p, fine_pool, color_p, logit_p), offs, sizes, need)}
+
         def run(x, x2, n_in1, dy, params, shape, d_x, d_x2, need_p, ri_, tg_, n_slots, stride, h, acc):
             n_in, n_out, nn, nl = shape
-            d_p = torch.zeros_like(params) if need_p else None
+            d_p = dps[id(params)] if need_p else None
             ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(n_slots, nn, nl)), device=dev, dtype=torch.float32)
             check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1,
                                   ptr(dy), dy.stride(0), ptr(params), n_in, n_out, nn, nl,
