@@ -17,6 +17,7 @@ event time, measured on the launch stream inside the timed region) and `cpu_base
 this host's cores, bounded sample).
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -39,7 +40,11 @@ WORKLOADS = {
                 desc="reference Replica defaults: 1992 rays x 47 samples, 1x32 MLPs"),
     "cfg5": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
                  desc="BASELINE configs[4] shape in fp32: scene0000 bound, 8192 rays x 128 samples, T=2^20 (58.7 MB table), "
-                      "2x64 MLPs (the fp16 MLP variant is not built yet)"),
+                      "2x64 MLPs"),
+    "cfg5_fp16": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
+                      mlp_dtype="fp16",
+                      desc="BASELINE configs[4]: scene0000 bound, 8192 rays x 128 samples, T=2^20, 2x64 MLPs with fp16 MFMA "
+                           "operands / fp32 accumulate (tcnn's precision); encodings, losses, weight gradients fp32"),
 }
 
 
@@ -63,7 +68,7 @@ def build(wl, device, seed, dist_ctx, overlap=False):
     n_per_frame = sum(wl["rays"])
     cfg = synthetic.default_cfg(n_pixels=4 * n_per_frame, n_samples_ray=wl["nu"], n_surface_ray=wl["ns"], n_frames=4,
                                 hash_size=wl["hash_size"], voxel_size=wl["voxel"], n_neurons=wl["nn"],
-                                n_hidden_layers=wl["nl"], smooth_pts=wl["smooth_pts"])
+                                n_hidden_layers=wl["nl"], smooth_pts=wl["smooth_pts"], mlp_dtype=wl.get("mlp_dtype", "fp32"))
     torch.manual_seed(1234)                                  # identical initial parameters on every rank
     dec = Decoder(cfg["model"], bound, n_class=8).to(device)
     mapper = Mapper(cfg, dec, bound, cam, device=device)
@@ -231,11 +236,15 @@ def main():
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        run()
+        last = run()
     ctx.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    final_loss = float(last) if torch.is_tensor(last) else None        # after the clock stopped
+    if final_loss is not None and not math.isfinite(final_loss):
+        raise RuntimeError(f"non-finite loss after the timed steps ({final_loss}): the measurement is void")
     elapsed = ctx.max_over_ranks(elapsed, device)
     # per-kernel durations for the roofline: the same K steps launched eagerly with an event pair around every
     # C-ABI call (a replayed graph cannot be bracketed per kernel; kernels and shapes are identical)
@@ -286,7 +295,7 @@ def main():
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands, f32 accumulate" if wl.get("mlp_dtype") == "fp16" else "f32", "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "final_loss": final_loss,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
                    "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
         "roofline": roofline,

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class DnsGridMeta(C.Structure):
@@ -46,7 +46,7 @@ SIGNATURES = {
     "dns_encode_bwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _U, _P, _U, _P, _P, _P, _P]),
     "dns_encode_bwd_ws_floats": (C.c_uint64, [_U, C.POINTER(DnsGridMeta)]),
     "dns_hashgrid_indices": (C.c_int, [_P, _U, C.POINTER(DnsGridMeta), _P, _P]),
-    "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P, _P]),
+    "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P, _U, _P]),
     "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P, _I, _P]),
     "dns_mlp_bwd_ws_floats": (C.c_uint64, [_U, _U, _U]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

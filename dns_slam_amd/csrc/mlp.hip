@@ -120,6 +120,52 @@ __device__ __forceinline__ void image_scatter(const ImgQuads<MAXQ>& q, float* __
   }
 }
 
+// ---- fp16 compute mode (tcnn's CutlassMLP precision: fp16 operands, fp32 accumulate; BASELINE configs[4]) ----
+// v_mfma_f32_32x32x8_f16: A[i][k] lane = i + 32*(k/4), element k%4; B[k][j] lane = j + 32*(k/4), element k%4 (checked on
+// the hardware: tools/mfma16_layout.hip); D as the fp32 32x32 tile.  Registers 4g..4g+3 of an accumulator are rows
+// 8g + 4h + {0,1,2,3}: converted to four halfs they ARE the B operand of K-step g of the next layer, so the chaining of
+// the fp32 kernels carries over with 4x fewer, 4x faster matrix instructions.  Images hold 4 halfs per lane and step
+// (natural k order: k = 8s + 4h + e); accumulators, hidden activations kept for the backward, dH and the weight
+// gradients stay fp32.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half4_t to_half4(float a, float b, float c, float d) {
+  half4_t h;
+  h[0] = (_Float16)a; h[1] = (_Float16)b; h[2] = (_Float16)c; h[3] = (_Float16)d;
+  return h;
+}
+
+template <int MAXQ>
+__device__ __forceinline__ void image_scatter16(const ImgQuads<MAXQ>& q, float* __restrict__ img_f, uint32_t R, uint32_t C,
+                                                bool transpose, uint32_t row_tiles, uint32_t nsteps, uint32_t klimit) {
+  _Float16* img = reinterpret_cast<_Float16*>(img_f);
+  const uint32_t qpr = C >> 2;
+  const uint32_t nq = R * qpr;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    const uint32_t e = threadIdx.x + j * blockDim.x;
+    if (e >= nq) continue;
+    const uint32_t rr = e / qpr, cc = (e - rr * qpr) * 4u;
+    const float4 v = q.v[j];
+    if (!transpose) {                                // Meff[i = rr][k = cc .. cc+3]: one lane slot of one step
+      const uint32_t rt = rr >> 5, st = cc >> 3;
+      if (rt < row_tiles && st < nsteps && cc < klimit)
+        *reinterpret_cast<half4_t*>(img + ((size_t)(rt * nsteps + st) * 64u + (rr & 31u) + 32u * ((cc >> 2) & 1u)) * 4u) =
+            to_half4(v.x, v.y, v.z, v.w);
+    } else {                                         // Meff[i = cc + c][k = rr]: one element of four neighbouring lanes
+      const uint32_t st = rr >> 3, h = (rr >> 2) & 1u, el = rr & 3u;
+      if (rr < klimit && st < nsteps) {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; ++c) {
+          const uint32_t i = cc + c, rt = i >> 5;
+          if (rt < row_tiles) img[((size_t)(rt * nsteps + st) * 64u + (i & 31u) + 32u * h) * 4u + el] = (_Float16)vv[c];
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void lds_zero(float* __restrict__ p, uint32_t n_floats) {   // n_floats % 4 == 0
   for (uint32_t e = threadIdx.x; e < n_floats / 4u; e += blockDim.x) reinterpret_cast<float4*>(p)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -261,6 +307,70 @@ __device__ __forceinline__ void layer_chain_1or2(const f32x16 (&act)[NT_IN], con
   }
 }
 
+template <int NT_OUT, int NT_IN>
+__device__ __forceinline__ void layer_chain16(const f32x16 (&act)[NT_IN], const float* __restrict__ img_f, uint32_t lane,
+                                              f32x16 (&out)[NT_OUT]) {
+  constexpr uint32_t nsteps = NT_IN * 4;
+  const half4_t* __restrict__ img = reinterpret_cast<const half4_t*>(img_f);
+#pragma unroll
+  for (int t = 0; t < NT_OUT; ++t) out[t] = zero16();
+#pragma unroll
+  for (int ti = 0; ti < NT_IN; ++ti) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint32_t st = ti * 4 + g;
+      const half4_t b = to_half4(act[ti][4 * g], act[ti][4 * g + 1], act[ti][4 * g + 2], act[ti][4 * g + 3]);
+#pragma unroll
+      for (int t = 0; t < NT_OUT; ++t) out[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(img[(t * nsteps + st) * 64u + lane], b, out[t], 0, 0, 0);
+    }
+  }
+}
+
+template <int NT_IN>
+__device__ __forceinline__ void layer_chain16_1or2(const f32x16 (&act)[NT_IN], const float* __restrict__ img, uint32_t lane,
+                                                   uint32_t nt, f32x16 (&o)[2]) {
+  if (nt >= 2u) {
+    layer_chain16<2, NT_IN>(act, img, lane, o);
+  } else {
+    f32x16 o1[1];
+    layer_chain16<1, NT_IN>(act, img, lane, o1);
+    o[0] = o1[0];
+    o[1] = o1[0];
+  }
+}
+
+// Backward values (dY, dH) can sit far below fp16's normal range (6e-5): before each fp16 conversion the wave scales its
+// tile by a power of two chosen from the tile's max magnitude (exact, undone in fp32 after the matrix products) -- a
+// per-tile dynamic version of tcnn's loss scaling.
+__device__ __forceinline__ float wave_pow2_scale(float local_max) {
+  float m = local_max;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+  int ex;
+  (void)frexpf(m, &ex);                              // m < 2^ex
+  return ldexpf(1.0f, min(max(8 - ex, -100), 100));   // scaled max in [2^7, 2^8); clamped: 2^(8-ex) must stay finite
+                                                      // for tiles whose largest magnitude is denormal-small
+}
+
+template <int NT>
+__device__ __forceinline__ float tile_max_abs(const f32x16 (&a)[NT]) {
+  float m = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(a[t][r]));
+  return m;
+}
+
+template <int NT>
+__device__ __forceinline__ void tile_scale(f32x16 (&a)[NT], float s) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[t][r] *= s;
+}
+
 template <int NT>
 __device__ __forceinline__ void relu(f32x16 (&a)[NT]) {
 #pragma unroll
@@ -392,6 +502,36 @@ __device__ __forceinline__ void layer_in_chunk(const float* __restrict__ stg, co
   }
 }
 
+// fp16 mode: the chunk is staged in natural column order and lane (pt, h) reads the 4 B operands (4 halfs each) of the
+// chunk's <= 4 K-steps (k = 32c + 8s + 4h + e) as 4 float4s
+__device__ __forceinline__ void x_chunk_commit_nat(const XChunk& xc, float* __restrict__ stg, uint32_t lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(stg + ((lane >> 3) + 8 * i) * STG_LD + 4u * (lane & 7u)) = xc.v[i];
+  wave_lds_fence();
+}
+
+template <int NT>
+__device__ __forceinline__ void layer_in_chunk16(const float* __restrict__ stg, const float* __restrict__ img_f, uint32_t nsteps,
+                                                 uint32_t c, uint32_t steps, uint32_t lane, f32x16 (&acc)[NT]) {
+  const half4_t* __restrict__ img = reinterpret_cast<const half4_t*>(img_f);
+  const float* src = stg + (lane & 31u) * STG_LD + 4u * (lane >> 5);
+  half4_t xs[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(src + 8 * g);
+    xs[g] = to_half4(v.x, v.y, v.z, v.w);
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if ((uint32_t)g < steps) {                      // uniform
+      const uint32_t st = 4u * c + g;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(img[(t * nsteps + st) * 64u + lane], xs[g], acc[t], 0, 0, 0);
+    }
+  }
+}
+
 // a: 32 output features x 32 points -> y[row][col0 + f], f < ncols, rows through the tile's row table; dword stores with
 // lane = feature: 2 rows x 128 bytes per instruction (any ldy / alignment)
 __device__ __forceinline__ void store_tile_rows_scalar(float* __restrict__ y, uint32_t ldy, uint32_t col0, uint32_t ncols,
@@ -458,6 +598,35 @@ __device__ __forceinline__ void dy_chunk_stage(const float* __restrict__ dy, uin
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) stg[((lane >> 5) + 2 * i) * STG_LD + (f & 1u) * 16u + (f >> 1)] = v[i];
+  wave_lds_fence();
+}
+
+// fp16 mode: both (<= 2) 32-column chunks of the tile's dY rows are loaded first (their max picks the wave's power-of-two
+// scale), then staged one at a time in natural column order
+struct DyTile {
+  float v[2][16];
+};
+
+__device__ __forceinline__ float dy_tile_load(DyTile& d, const float* __restrict__ dy, uint32_t lddy, uint32_t n_out,
+                                              const int* __restrict__ rows_lds, uint32_t lane) {
+  float m = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t col = 32u * c + (lane & 31u);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = rows_lds[(lane >> 5) + 2 * i];
+      d.v[c][i] = (row >= 0 && col < n_out) ? dy[(size_t)row * lddy + col] : 0.f;
+      m = fmaxf(m, fabsf(d.v[c][i]));
+    }
+  }
+  return m;
+}
+
+__device__ __forceinline__ void dy_tile_commit_nat(const DyTile& d, int c, float scale, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t f = lane & 31u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stg[((lane >> 5) + 2 * i) * STG_LD + f] = (c ? d.v[1][i] : d.v[0][i]) * scale;
   wave_lds_fence();
 }
 
@@ -554,7 +723,7 @@ struct FwdLds {
   static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t mt, uint32_t vr) { return img_valu(n_in, mt) + vr * NN; }
 };
 
-template <int NN, int NL>
+template <int NN, int NL, bool F16>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict__ x, uint32_t ldx, XSeg seg,
                                                       const float* __restrict__ params, MlpShape sh,
                                                       float* __restrict__ y, uint32_t ldy, uint32_t n_slots,
@@ -594,9 +763,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict
         if (sh.mt) image_load(q_out, wout, out_rows, NN);
         lds_zero(lds, L::total(sh.n_in, sh.mt, sh.vr));
         __syncthreads();
-        image_scatter(q_in, lds + L::img_in(sh.n_in), NN, sh.n_in, false, NT, khalf, K_PAIR, 0, sh.n_in);
-        if (NL == 2) image_scatter(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
-        if (sh.mt) image_scatter(q_out, lds + L::img_out(sh.n_in), out_rows, NN, false, sh.mt, NN / 2, K_CHAIN, 0, NN);
+        if (F16) {
+          image_scatter16(q_in, lds + L::img_in(sh.n_in), NN, sh.n_in, false, NT, sh.n_in / 8u, sh.n_in);
+          if (NL == 2) image_scatter16(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NT * 4, NN);
+          if (sh.mt) image_scatter16(q_out, lds + L::img_out(sh.n_in), out_rows, NN, false, sh.mt, NT * 4, NN);
+        } else {
+          image_scatter(q_in, lds + L::img_in(sh.n_in), NN, sh.n_in, false, NT, khalf, K_PAIR, 0, sh.n_in);
+          if (NL == 2) image_scatter(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+          if (sh.mt) image_scatter(q_out, lds + L::img_out(sh.n_in), out_rows, NN, false, sh.mt, NN / 2, K_CHAIN, 0, NN);
+        }
         if (sh.vr) build_valu_image(lds + L::img_valu(sh.n_in, sh.mt), wout, sh.mt * 32, sh.vr, NN, NN / 2);
       }
       cur_group = grp;
@@ -626,10 +801,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if ((uint32_t)c < n_chunks) {
-        x_chunk_commit(xc[c], stg, lane);
-        DNS_STAMP(stamp++);
-        layer_in_chunk<NT>(stg, lds + L::img_in(sh.n_in), khalf, c, min(16u, khalf - 16u * c), lane, a0);
-        DNS_STAMP(stamp++);
+        if (F16) {
+          x_chunk_commit_nat(xc[c], stg, lane);
+          layer_in_chunk16<NT>(stg, lds + L::img_in(sh.n_in), sh.n_in / 8u, c, min(4u, sh.n_in / 8u - 4u * c), lane, a0);
+        } else {
+          x_chunk_commit(xc[c], stg, lane);
+          DNS_STAMP(stamp++);
+          layer_in_chunk<NT>(stg, lds + L::img_in(sh.n_in), khalf, c, min(16u, khalf - 16u * c), lane, a0);
+          DNS_STAMP(stamp++);
+        }
       }
     }
     have_x = false;
@@ -652,7 +832,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict
     DNS_STAMP(stamp++);
     f32x16 a1[NT];
     if (NL == 2) {
-      layer_chain<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, a1);
+      if (F16) layer_chain16<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, a1);
+      else layer_chain<NT, NT>(a0, lds + L::img_h(sh.n_in), lane, a1);
       relu<NT>(a1);
       if (h_save) {
 #pragma unroll
@@ -664,7 +845,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict
     const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
     if (sh.mt) {
       f32x16 o[2];
-      layer_chain_1or2<NT>(hl, lds + L::img_out(sh.n_in), lane, sh.mt, o);
+      if (F16) layer_chain16_1or2<NT>(hl, lds + L::img_out(sh.n_in), lane, sh.mt, o);
+      else layer_chain_1or2<NT>(hl, lds + L::img_out(sh.n_in), lane, sh.mt, o);
       store_tile_rows_scalar(y, ldy, 0, min(32u, sh.n_out), rows_lds, o[0], stg, lane);
       if (sh.mt > 1) store_tile_rows_scalar(y, ldy, 32, sh.n_out - 32u, rows_lds, o[1], stg, lane);
     }
@@ -707,7 +889,7 @@ struct BwdLds {
   }
 };
 
-template <int NN, int NL, bool SAVED>
+template <int NN, int NL, bool SAVED, bool F16>
 __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restrict__ x, uint32_t ldx,
                                                            const float* __restrict__ dy, uint32_t lddy,
                                                            const float* __restrict__ params, MlpShape sh,
@@ -727,6 +909,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
   const uint32_t wave = wave8 & 3u, wsel = wave8 >> 2;
   const uint32_t khalf = sh.n_in / 2;
   const uint32_t ko2 = L::ko2(sh.n_out), ko2p = L::ko2p(sh.n_out);
+  const uint32_t ns16 = (sh.n_out + 7u) / 8u;      // fp16 mode: K-steps of 8 outputs
   const uint32_t in_tiles = L::in_pad(sh.n_in) / 32u;
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   const uint32_t bt0 = blockIdx.x * tiles_per_block;
@@ -762,13 +945,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
         lds_zero(lds, L::total(sh.n_in, sh.n_out, dx != nullptr));
         __syncthreads();
         if (!SAVED) image_scatter(q_in, lds + L::img_in(sh.n_in), NN, sh.n_in, false, NT, khalf, K_SPLIT, khalf, sh.n_in);
-        if (NL == 2) {
-          if (!SAVED) image_scatter(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
-          image_scatter(q_h, lds + L::img_hT(sh.n_in, sh.n_out), NN, NN, true, NT, NN / 2, K_CHAIN, 0, NN);
+        if (F16) {                                 // SAVED only (host-checked): transposed images, natural k order
+          if (NL == 2) image_scatter16(q_h, lds + L::img_hT(sh.n_in, sh.n_out), NN, NN, true, NT, NT * 4, NN);
+          image_scatter16(q_out, lds + L::img_outT(sh.n_in), sh.n_out, NN, true, NT, ns16, sh.n_out);
+          if (dx) image_scatter16(q_in, lds + L::img_inT(sh.n_in, sh.n_out), NN, sh.n_in, true, in_tiles, NT * 4, NN);
+        } else {
+          if (NL == 2) {
+            if (!SAVED) image_scatter(q_h, lds + L::img_h(sh.n_in), NN, NN, false, NT, NN / 2, K_CHAIN, 0, NN);
+            image_scatter(q_h, lds + L::img_hT(sh.n_in, sh.n_out), NN, NN, true, NT, NN / 2, K_CHAIN, 0, NN);
+          }
+          // A = W_out^T: rows = hidden (NN), k over outputs in pairs (k = 2s + h)
+          image_scatter(q_out, lds + L::img_outT(sh.n_in), sh.n_out, NN, true, NT, ko2p, K_PAIR, 0, sh.n_out);
+          if (dx) image_scatter(q_in, lds + L::img_inT(sh.n_in, sh.n_out), NN, sh.n_in, true, in_tiles, NN / 2, K_CHAIN, 0, NN);
         }
-        // A = W_out^T: rows = hidden (NN), k over outputs in pairs (k = 2s + h)
-        image_scatter(q_out, lds + L::img_outT(sh.n_in), sh.n_out, NN, true, NT, ko2p, K_PAIR, 0, sh.n_out);
-        if (dx) image_scatter(q_in, lds + L::img_inT(sh.n_in, sh.n_out), NN, sh.n_in, true, in_tiles, NN / 2, K_CHAIN, 0, NN);
       }
       cur_group = grp;
       __syncthreads();
@@ -826,9 +1015,22 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
     {
       const float* img = lds + L::img_outT(sh.n_in);
       const uint32_t n_dy_chunks = (sh.n_out + 31u) / 32u;
-      for (uint32_t c = 0; c < n_dy_chunks; ++c) {
-        dy_chunk_stage(dy, lddy, sh.n_out, rows_lds, c, stg, lane);
-        layer_in_chunk<NT>(stg, img, ko2p, c, min(16u, ko2p - 16u * c), lane, dl);
+      if (F16) {
+        DyTile dt;
+        const float sc = wave_pow2_scale(dy_tile_load(dt, dy, lddy, sh.n_out, rows_lds, lane));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if ((uint32_t)c < n_dy_chunks) {
+            dy_tile_commit_nat(dt, c, sc, stg, lane);
+            layer_in_chunk16<NT>(stg, img, ns16, c, min(4u, ns16 - 4u * c), lane, dl);
+          }
+        }
+        tile_scale<NT>(dl, 1.0f / sc);
+      } else {
+        for (uint32_t c = 0; c < n_dy_chunks; ++c) {
+          dy_chunk_stage(dy, lddy, sh.n_out, rows_lds, c, stg, lane);
+          layer_in_chunk<NT>(stg, img, ko2p, c, min(16u, ko2p - 16u * c), lane, dl);
+        }
       }
     }
     DNS_STAMP(stamp++);   // dl mfma issued
@@ -839,7 +1041,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) dl[t][r] = hl[t][r] > 0.f ? dl[t][r] : 0.f;
     f32x16 d1[NT];
     if (NL == 2) {
-      layer_chain<NT, NT>(dl, lds + L::img_hT(sh.n_in, sh.n_out), lane, d1);
+      if (F16) {
+        const float sc = wave_pow2_scale(tile_max_abs<NT>(dl));
+        f32x16 dls[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dls[t] = dl[t] * sc;
+        layer_chain16<NT, NT>(dls, lds + L::img_hT(sh.n_in, sh.n_out), lane, d1);
+        tile_scale<NT>(d1, 1.0f / sc);
+      } else {
+        layer_chain<NT, NT>(dl, lds + L::img_hT(sh.n_in, sh.n_out), lane, d1);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -860,12 +1071,27 @@ __global__ __launch_bounds__(512) void mlp_bwd_data_kernel(const float* __restri
     if (dx) {
       // dX = W_in^T dH_1, two input tiles at a time to bound accumulator registers
       const float* img = lds + L::img_inT(sh.n_in, sh.n_out);
+      f32x16 dfs[NT];                                // fp16 mode: dH_1 scaled into fp16's range once for all input tiles
+      float inv_dfs = 1.0f;
+      if (F16) {
+        const float sc = wave_pow2_scale(tile_max_abs<NT>(dfirst));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dfs[t] = dfirst[t] * sc;
+        inv_dfs = 1.0f / sc;
+      }
       const bool vec = ((lddx & 3u) == 0) && ((((uintptr_t)dx) & 15u) == 0) &&
                        (!dseg.dx2 || (((dseg.lddx2 & 3u) == 0) && ((((uintptr_t)dseg.dx2) & 15u) == 0)));
       for (uint32_t it0 = 0; it0 < in_tiles; it0 += 2) {
         f32x16 o[2];
         const uint32_t nt = min(2u, in_tiles - it0);
-        layer_chain_1or2<NT>(dfirst, img + (size_t)it0 * (NN / 2) * 64u, lane, nt, o);
+        if (F16) {
+          // image tile stride: NT*4 steps x 64 lanes x 4 halfs = NT*512 floats
+          layer_chain16_1or2<NT>(dfs, img + (size_t)it0 * (NT * 4) * 64u * 2u, lane, nt, o);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) o[t] *= inv_dfs;
+        } else {
+          layer_chain_1or2<NT>(dfirst, img + (size_t)it0 * (NN / 2) * 64u, lane, nt, o);
+        }
         DNS_STAMP(stamp++);   // dX chain issued
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1306,7 +1532,7 @@ static int check_segments(const char* who, const float* x2, uint32_t ldx2, uint3
 extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                            const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
                            uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots, const int32_t* row_index,
-                           const int32_t* tile_group, uint32_t param_stride, float* h_save, void* stream) {
+                           const int32_t* tile_group, uint32_t param_stride, float* h_save, uint32_t flags, void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
   DNS_REQUIRE(!h_save || (((uintptr_t)h_save) % 16) == 0, "dns_mlp_fwd: h_save must be 16-byte aligned");
@@ -1324,19 +1550,25 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   const uint32_t tpb = pick_tiles_per_block(n_btiles, 512, "DNS_MLP_FWD_BLOCKS");
   const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_FWD(NN, NL)                                                                                         \
+#define LAUNCH_FWD2(NN, NL, H)                                                                                     \
   {                                                                                                                \
     const size_t lds_bytes = ((size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) + 4 * STG_WAVE_FLOATS) * sizeof(float); \
-    (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, H>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                               (int)lds_bytes);                                                                     \
-    hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, seg, params, sh, y, \
+    hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL, H>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, seg, params, sh, y, \
                        ldy, n_slots, row_index, tile_group, param_stride, tpb, h_save);                            \
+  }
+#define LAUNCH_FWD(NN, NL)                \
+  {                                       \
+    if (flags & DNS_MLP_FP16) LAUNCH_FWD2(NN, NL, true) \
+    else LAUNCH_FWD2(NN, NL, false)       \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
   else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_FWD(64, 1)
   else LAUNCH_FWD(64, 2)
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD2
   return check_launch("dns_mlp_fwd");
 }
 
@@ -1357,6 +1589,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
     if (rc != DNS_OK) return rc;
   }
   if (!x2) n_in1 = n_in;
+  const bool fp16 = (accumulate_dx & (int)DNS_MLP_FP16) != 0;
+  DNS_REQUIRE(!fp16 || h_saved, "dns_mlp_bwd: the fp16 mode needs the hidden activations kept by dns_mlp_fwd (h_saved)");
   DNS_REQUIRE(!x2 || h_saved, "dns_mlp_bwd: a two-segment input needs the hidden activations kept by dns_mlp_fwd (h_saved)");
   DNS_REQUIRE(!x2 || !d_x || d_x2, "dns_mlp_bwd: d_x2 is required with a two-segment input when d_x is asked for");
   if (d_x) DNS_REQUIRE(lddx >= n_in1 && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
@@ -1369,19 +1603,20 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   const uint32_t tpb = pick_tiles_per_block(n_btiles, 256, "DNS_MLP_BWD_BLOCKS");
   const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
-#define LAUNCH_BWD2(NN, NL, SV)                                                                                     \
+#define LAUNCH_BWD2(NN, NL, SV, H)                                                                                  \
   {                                                                                                                 \
     const size_t lds_bytes = ((size_t)BwdLds<NN, NL, SV>::total(n_in, n_out, d_x != nullptr) + 8 * STG_WAVE_FLOATS) * sizeof(float); \
-    (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV, H>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds_bytes);                                                                      \
-    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy, \
+    hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV, H>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy, \
                        params, sh, d_x, lddx, dseg, n_in1, ws, n_slots, row_index, tile_group, param_stride, tpb,   \
                        h_saved, n_slots);                                                                           \
   }
 #define LAUNCH_BWD(NN, NL)            \
   {                                   \
-    if (h_saved) LAUNCH_BWD2(NN, NL, true) \
-    else LAUNCH_BWD2(NN, NL, false)   \
+    if (fp16) LAUNCH_BWD2(NN, NL, true, true) \
+    else if (h_saved) LAUNCH_BWD2(NN, NL, true, false) \
+    else LAUNCH_BWD2(NN, NL, false, false)   \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_BWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_BWD(32, 2)

@@ -8,7 +8,8 @@ reference class works against this one.  Differences, all inside the module bodi
   * ``Pos_Encoding.forward`` is ONE kernel writing OneBlob and hash-grid channels into one [P, 80] buffer;
     the returned ``(pe, grid)`` are views of it, and ``Coarse`` re-uses the buffer instead of ``torch.cat``.
   * MLPs compute in fp32 on the matrix cores (tcnn: fp16) -- SURVEY D11.
-  * extra cfg keys ``cfg['mlp'] = {'n_neurons': 32|64, 'n_hidden_layers': 1|2}`` (default = the reference's 1x32).
+  * extra cfg keys ``cfg['mlp'] = {'n_neurons': 32|64, 'n_hidden_layers': 1|2, 'dtype': 'fp32'|'fp16'}`` (default = the
+    reference's 1x32; fp32 is the parity path, 'fp16' computes the matrix products with fp16 operands like tcnn).
 """
 import torch
 from torch import nn
@@ -21,7 +22,8 @@ from .pos_encoding import get_encoder
 def _mlp_cfg(cfg, hidden_dim):
     m = cfg.get("mlp", {}) if isinstance(cfg, dict) else {}
     return {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None",
-            "n_neurons": int(m.get("n_neurons", hidden_dim)), "n_hidden_layers": int(m.get("n_hidden_layers", 1))}
+            "n_neurons": int(m.get("n_neurons", hidden_dim)), "n_hidden_layers": int(m.get("n_hidden_layers", 1)),
+            "dtype": str(m.get("dtype", "fp32"))}          # "fp16": tcnn's operand precision (BASELINE configs[4])
 
 
 def fused_cat(pe, features):

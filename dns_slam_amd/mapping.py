@@ -38,6 +38,7 @@ class FineDecoderPool(nn.Module):
         super().__init__()
         self.n_in, self.n_out, self.net_cfg = n_in, n_out, dict(net_cfg)
         self.nn_, self.nl = int(net_cfg["n_neurons"]), int(net_cfg["n_hidden_layers"])
+        self.fp16 = str(net_cfg.get("dtype", "fp32")).lower() in ("fp16", "half", "float16")
         self.count = ops.mlp_param_count(n_in, n_out, self.nn_, self.nl)
         self.pool = nn.Parameter(torch.zeros(capacity, self.count, device=device))
         self.slot: Dict[int, int] = {}
@@ -418,7 +419,8 @@ class Mapper:
         x = fused_cat(pes, features)
         n = len(self.fine_decoders)
         return ops.mlp_grouped(x, self.fine_decoders.pool[:max(n, 1)], slot, self.pe_dim + self.grid_dim,
-                               self.hidden_dim + 1, self.fine_decoders.nn_, self.fine_decoders.nl)
+                               self.hidden_dim + 1, self.fine_decoders.nn_, self.fine_decoders.nl,
+                               fp16=getattr(self.fine_decoders, "fp16", False))
 
     # ------------------------------------------------------------------ slams/mapping.py:603-635
     def renderer(self, samples, strict=True):
@@ -443,7 +445,8 @@ class Mapper:
                 buf, pixel_pts, dec.coarse_fn.decoder.params, pool.pool[:max(len(pool), 1)],
                 dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, slot, self.pe_dim,
                 net(dec.coarse_fn.decoder), (self.pe_dim + self.grid_dim, self.hidden_dim + 1, pool.nn_, pool.nl),
-                net(dec.out_fn.color_decoder), net(dec.out_fn.logit_decoder))
+                net(dec.out_fn.color_decoder), net(dec.out_fn.logit_decoder),
+                fp16=getattr(dec.coarse_fn.decoder, "fp16", False))
             color_pts = torch.sigmoid(color_raw)
         else:
             coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts)

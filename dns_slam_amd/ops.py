@@ -195,6 +195,7 @@ def _row_major_2d(x: torch.Tensor) -> torch.Tensor:
 # False: nothing is kept and dns_mlp_bwd recomputes them from x (less memory, ~1.7x more MFMA work in the backward).
 LOSS_SUMS_FLOATS = 32 + 5 * 1024          # include/dns_hip.h DNS_LOSS_SUMS_FLOATS
 MLP_SAVE_HIDDEN = True
+MLP_FP16_FLAG = 0x100                      # include/dns_hip.h DNS_MLP_FP16
 
 
 class _MlpFn(torch.autograd.Function):
@@ -202,7 +203,8 @@ class _MlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, params, shape, row_index, tile_group, n_slots):
-        n_in, n_out, nn, nl = shape
+        n_in, n_out, nn, nl = shape[:4]
+        fp16 = MLP_FP16_FLAG if (len(shape) > 4 and shape[4]) else 0
         require_cuda(params, row_index, tile_group)
         if not x.is_cuda:
             raise ValueError("dns_slam_amd ops run on the GPU only (got a non-CUDA tensor); there is no CPU fallback")
@@ -215,12 +217,12 @@ class _MlpFn(torch.autograd.Function):
             y = torch.zeros(P, n_out, device=x.device, dtype=torch.float32)
         stride = params.shape[-1] if params.dim() == 2 else 0
         # keep the hidden activations when a backward will follow: it then skips the forward recompute
-        keep = MLP_SAVE_HIDDEN and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        keep = (MLP_SAVE_HIDDEN or fp16) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         h_save = torch.empty(nl * n_slots * nn, device=x.device, dtype=torch.float32) if keep else None
         check(lib.dns_mlp_fwd(ptr(x), x.stride(0), None, 0, 0, ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, n_slots,
-                              ptr(row_index), ptr(tile_group), stride, ptr(h_save), stream_ptr()), "dns_mlp_fwd")
+                              ptr(row_index), ptr(tile_group), stride, ptr(h_save), fp16, stream_ptr()), "dns_mlp_fwd")
         ctx.save_for_backward(x, params, row_index, tile_group, h_save)
-        ctx.shape, ctx.n_slots, ctx.stride = shape, n_slots, stride
+        ctx.shape, ctx.n_slots, ctx.stride, ctx.fp16 = shape[:4], n_slots, stride, fp16
         return y
 
     @staticmethod
@@ -238,14 +240,15 @@ class _MlpFn(torch.autograd.Function):
         ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(ctx.n_slots, nn, nl)), device=x.device, dtype=torch.float32)
         check(lib.dns_mlp_bwd(ptr(x), x.stride(0), None, 0, 0, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl,
                               ptr(d_x), n_in, None, 0, ptr(d_p), ptr(ws), ctx.n_slots, ptr(row_index), ptr(tile_group),
-                              ctx.stride, ptr(h_save), 0, stream_ptr()), "dns_mlp_bwd")
+                              ctx.stride, ptr(h_save), ctx.fp16, stream_ptr()), "dns_mlp_bwd")
         return d_x, d_p, None, None, None, None
 
 
 def mlp(x: torch.Tensor, params: torch.Tensor, n_in: int, n_out: int, n_neurons: int = 32,
-        n_hidden_layers: int = 1) -> torch.Tensor:
-    """Bias-free ReLU MLP, fp32 on the matrix cores (tcnn CutlassMLP replacement)."""
-    return _MlpFn.apply(x, params, (n_in, n_out, n_neurons, n_hidden_layers), None, None, 0)
+        n_hidden_layers: int = 1, fp16: bool = False) -> torch.Tensor:
+    """Bias-free ReLU MLP on the matrix cores (tcnn CutlassMLP replacement): exact fp32, or with ``fp16`` tcnn's own
+    precision (fp16 operands, fp32 accumulate; parameters, kept activations and weight gradients stay fp32)."""
+    return _MlpFn.apply(x, params, (n_in, n_out, n_neurons, n_hidden_layers, bool(fp16)), None, None, 0)
 
 
 def group_slots(slot_of_point: torch.Tensor, n_groups: int, min_count: int = 2):
@@ -269,12 +272,12 @@ def group_slots(slot_of_point: torch.Tensor, n_groups: int, min_count: int = 2):
 
 
 def mlp_grouped(x: torch.Tensor, params_pool: torch.Tensor, slot_of_point: torch.Tensor, n_in: int, n_out: int,
-                n_neurons: int = 32, n_hidden_layers: int = 1, min_count: int = 2) -> torch.Tensor:
+                n_neurons: int = 32, n_hidden_layers: int = 1, min_count: int = 2, fp16: bool = False) -> torch.Tensor:
     """Per-point weight sets (the per-class fine decoders, slams/mapping.py:590-601): point p runs through
     ``params_pool[slot_of_point[p]]``; points with no network / tiny groups get zeros."""
     G = params_pool.shape[0]
     row_index, tile_group, n_slots = group_slots(slot_of_point, G, min_count)
-    return _MlpFn.apply(x, params_pool, (n_in, n_out, n_neurons, n_hidden_layers), row_index, tile_group, n_slots)
+    return _MlpFn.apply(x, params_pool, (n_in, n_out, n_neurons, n_hidden_layers, bool(fp16)), row_index, tile_group, n_slots)
 
 
 # ----------------------------------------------------------------------------- the renderer's four networks, fused glue
@@ -289,19 +292,20 @@ class _RenderNetsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg):
-        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count = cfg
+        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count, fp16 = cfg
+        fp16 = MLP_FP16_FLAG if fp16 else 0
         require_cuda(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point)
         buf = _row_major_2d(buf.float())
         pixel = pixel.float()
         P, dev = buf.shape[0], buf.device
-        keep = MLP_SAVE_HIDDEN
+        keep = MLP_SAVE_HIDDEN or bool(fp16)
         st = stream_ptr()
 
         def run(x, x2, n_in1, params, shape, y, ri, tg, n_slots, stride):
             n_in, n_out, nn, nl = shape
             h = torch.empty(nl * n_slots * nn, device=dev, dtype=torch.float32) if keep else None
             check(lib.dns_mlp_fwd(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params),
-                                  n_in, n_out, nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(h), st),
+                                  n_in, n_out, nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(h), fp16, st),
                   "dns_mlp_fwd")
             return h
 
@@ -322,7 +326,8 @@ class _RenderNetsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_coarse, d_fine, d_color, d_logit):
         buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log = ctx.saved_tensors
-        pe_dim, shp_c, shp_f, shp_col, shp_log, _ = ctx.cfg
+        pe_dim, shp_c, shp_f, shp_col, shp_log, _, fp16 = ctx.cfg
+        fp16 = MLP_FP16_FLAG if fp16 else 0
         P, dev = buf.shape[0], buf.device
         st = stream_ptr()
         need_buf = ctx.needs_input_grad[0]
@@ -345,7 +350,7 @@ class _RenderNetsFn(torch.autograd.Function):
             check(lib.dns_mlp_bwd(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1,
                                   ptr(dy), dy.stride(0), ptr(params), n_in, n_out, nn, nl,
                                   ptr(d_x), d_x.stride(0), ptr(d_x2), 0 if d_x2 is None else d_x2.stride(0),
-                                  ptr(d_p), ptr(ws), n_slots, ptr(ri_), ptr(tg_), stride, ptr(h), acc, st), "dns_mlp_bwd")
+                                  ptr(d_p), ptr(ws), n_slots, ptr(ri_), ptr(tg_), stride, ptr(h), acc | fp16, st), "dns_mlp_bwd")
             return d_p
 
         def grad(d, like_cols):
@@ -369,10 +374,10 @@ class _RenderNetsFn(torch.autograd.Function):
 
 
 def render_nets(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, pe_dim, shp_coarse, shp_fine,
-                shp_color, shp_logit, min_count=2):
+                shp_color, shp_logit, min_count=2, fp16=False):
     """-> (coarse [P, h+1], fine [P, h+1], colour (pre-sigmoid) [P, 3], logits [P, n_class]); shapes are
     (n_in, n_out, n_neurons, n_hidden_layers) tuples."""
-    cfg = (int(pe_dim), tuple(shp_coarse), tuple(shp_fine), tuple(shp_color), tuple(shp_logit), int(min_count))
+    cfg = (int(pe_dim), tuple(shp_coarse), tuple(shp_fine), tuple(shp_color), tuple(shp_logit), int(min_count), bool(fp16))
     return _RenderNetsFn.apply(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg)
 
 

@@ -25,13 +25,13 @@ def load_bound(bound, bound_divisible=0.32, scale=1.0) -> torch.Tensor:
 
 
 def default_cfg(n_pixels=2000, n_samples_ray=32, n_surface_ray=15, n_frames=4, hash_size=16, voxel_size=0.02,
-                n_neurons=32, n_hidden_layers=1, smooth_pts=64, track_pixels=500, track_iters=50) -> dict:
+                n_neurons=32, n_hidden_layers=1, smooth_pts=64, track_pixels=500, track_iters=50, mlp_dtype="fp32") -> dict:
     """The keys of reference configs/slam.yaml + configs/replica/replica.yaml that shape the hot path."""
     return {
         "model": {"pts_dim": 3, "pixel_dim": 64, "hidden_dim": 32,
                   "pos": {"method": "OneBlob", "n_bins": 16},
                   "grid": {"method": "HashGrid", "hash_size": hash_size, "voxel_size": voxel_size},
-                  "mlp": {"n_neurons": n_neurons, "n_hidden_layers": n_hidden_layers}},
+                  "mlp": {"n_neurons": n_neurons, "n_hidden_layers": n_hidden_layers, "dtype": mlp_dtype}},
         "training": {"lr": 0.005, "lambda_color": 5.0, "lambda_depth": 5.0, "lambda_label": 0.1,
                      "lambda_smooth": 0.00001, "lambda_fs": 10, "lambda_opacity": 10,
                      "n_samples_ray": n_samples_ray, "n_surface_ray": n_surface_ray, "smooth_pts": smooth_pts,

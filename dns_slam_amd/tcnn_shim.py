@@ -75,6 +75,7 @@ class Network(nn.Module):
         self.n_neurons = int(network_config.get("n_neurons", 32))
         self.n_hidden_layers = int(network_config.get("n_hidden_layers", 1))
         self.network_config = dict(network_config)
+        self.fp16 = str(network_config.get("dtype", "fp32")).lower() in ("fp16", "half", "float16")
         self.seed = seed
         n = ops.mlp_param_count(self.n_input_dims, self.n_output_dims, self.n_neurons, self.n_hidden_layers)
         self.params = nn.Parameter(self._xavier(seed))
@@ -93,4 +94,5 @@ class Network(nn.Module):
         return torch.cat(chunks).float()
 
     def forward(self, x):
-        return ops.mlp(x, self.params, self.n_input_dims, self.n_output_dims, self.n_neurons, self.n_hidden_layers)
+        return ops.mlp(x, self.params, self.n_input_dims, self.n_output_dims, self.n_neurons, self.n_hidden_layers,
+                       fp16=getattr(self, "fp16", False))

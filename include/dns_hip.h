@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 2
+#define DNS_ABI_VERSION 3
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -132,11 +132,13 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * dy / d_x / d_x2, -1 = padding slot (computes on zeros, stores nothing).  tile_group (NULL = one net) gives, per
  * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class
  * fine decoders of slams/mapping.py:590-601 without gathering activations. */
+#define DNS_MLP_FP16 0x100u   /* flags of dns_mlp_fwd; bit 8 of accumulate_dx of dns_mlp_bwd */
 int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
                 float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: hidden activations kept for dns_mlp_bwd */,
+                uint32_t flags /* DNS_MLP_FP16: fp16 operands, fp32 accumulate (tcnn's precision); 0: exact fp32 */,
                 void* stream);
 
 /* Backward.  Hidden activations come from h_saved (what dns_mlp_fwd wrote) or, if NULL, are recomputed from x
@@ -145,7 +147,8 @@ int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, ui
  * layout as params (+ group*param_stride), NULL = skip.  ws: 16-byte aligned float workspace of
  * dns_mlp_bwd_ws_floats(n_slots, n_neurons, n_hidden_layers) elements.
  * accumulate_dx: bit 0 -> d_x += instead of =, bit 1 -> d_x2 += (several networks reading one input add their
- * input gradients in place instead of through separate buffers and an add). */
+ * input gradients in place instead of through separate buffers and an add); | DNS_MLP_FP16: data-gradient products with
+ * fp16 operands (per-tile power-of-two scaling), fp32 accumulate; dH, the weight gradients and their GEMM stay fp32. */
 int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* dy, uint32_t lddy, const float* params,
                 uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,

@@ -168,6 +168,78 @@ def test_mlp_grouped_matches_per_class_loop(nn, nl):
     assert_close(pp.grad.cpu()[:, :used], po.grad[:, :used], what="grouped dparams")
 
 
+def _mlp_fp16_emulation(x, w, gy, n_in, n_out, nn, nl):
+    """What the fp16 mode computes, restated with torch: every matrix-product OPERAND rounded to fp16 (weights, layer
+    inputs, output / hidden gradients), products and sums exact (float64), ReLU masks from the fp32-stored activations;
+    weight gradients from the fp32 dH and fp32 activations / inputs."""
+    q = lambda t: t.to(torch.float16).to(torch.float64)
+    f32 = lambda t: t.to(torch.float32)
+    o = 0
+    Ws = []
+    for r, c in [(nn, n_in)] + [(nn, nn)] * (nl - 1) + [(n_out, nn)]:
+        Ws.append(w[o:o + r * c].reshape(r, c))
+        o += r * c
+    acts = [x]
+    h = x
+    for W in Ws[:-1]:
+        h = f32(torch.relu(q(h) @ q(W).T))
+        acts.append(h)
+    y = f32(q(h) @ q(Ws[-1]).T)
+    d = gy
+    dWs = [None] * len(Ws)
+    for li in range(len(Ws) - 1, -1, -1):
+        dWs[li] = f32(d.double().T @ acts[li].double())
+        d_in = f32(q(d) @ q(Ws[li]))
+        if li > 0:
+            d_in = d_in * (acts[li] > 0).float()
+        d = d_in
+    return y, d, torch.cat([t.reshape(-1) for t in dWs])
+
+
+@pytest.mark.parametrize("n_in,n_out,nn,nl", [(80, 33, 64, 2), (112, 8, 64, 2), (112, 40, 32, 1), (80, 3, 64, 1), (16, 64, 32, 2)])
+def test_mlp_fp16_mode(n_in, n_out, nn, nl):
+    """BASELINE configs[4] / SURVEY D11: the fp16-operand MFMA mode (tcnn's own precision: fp16 operands, fp32
+    accumulate).  (i) Against a torch restatement that rounds the same operands to fp16: 2e-3 of the scale (summation
+    order; a hidden unit at ~0 may still fall on the other side of the ReLU: <= 0.5 % of the points may be off).
+    (ii) Against the exact-fp32 kernels: within 1e-2 (outputs) / 5e-2 rms (gradients: ReLU flips).  (iii) Output
+    gradients of 1e-7 -- far below fp16's normal range -- give the same input gradient up to scale: the per-tile
+    power-of-two scaling of the backward."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    P = 2000
+    w = tr.mlp_init(n_in, n_out, nn, nl, g).to(DEV)
+    x = torch.randn(P, n_in, generator=g).to(DEV)
+    gy = torch.randn(P, n_out, generator=g).to(DEV)
+
+    def run(fp16, scale=1.0):
+        xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = ops.mlp(xp, wp, n_in, n_out, nn, nl, fp16=fp16)
+        (y * (gy * scale)).sum().backward()
+        used = n_in * nn + (nl - 1) * nn * nn + n_out * nn
+        return y.detach(), xp.grad, wp.grad[:used]
+
+    r16, r32 = run(True), run(False)
+    emu = _mlp_fp16_emulation(x, w, gy, n_in, n_out, nn, nl)
+    for a, b, name in zip(r16, emu, ("y", "dx", "dparams")):
+        scale = float(b.abs().max())
+        d = (a - b).abs()
+        if name == "dx":
+            bad = float((d.max(1)[0] > 2e-3 * scale).float().mean())
+            assert bad <= 0.005, f"fp16 mode vs fp16 emulation, dx: {bad * 100:.2f} % of the points off by > 2e-3"
+        else:
+            rms = float(d.pow(2).mean().sqrt()) / float(b.pow(2).mean().sqrt())
+            assert rms <= 2e-3, f"fp16 mode vs fp16 emulation, {name}: relative rms error {rms:.3e}"
+    assert float((r16[0] - r32[0]).abs().max()) <= 1e-2 * float(r32[0].abs().max())
+    assert float((r16[0] - r32[0]).abs().max()) > 0, "fp16 mode returned bit-identical outputs: the fp32 kernel ran instead"
+    for a, b in zip(r16[1:], r32[1:]):
+        assert float((a - b).pow(2).mean().sqrt()) <= 5e-2 * float(b.pow(2).mean().sqrt())
+    tiny = run(True, 1e-7)
+    d = (tiny[1] / 1e-7 - r16[1]).abs()
+    assert float((d.max(1)[0] > 5e-3 * float(r16[1].abs().max())).float().mean()) <= 0.01, "tiny output gradients lost in fp16"
+    den = run(True, 1e-41)                       # denormal output gradients: the power-of-two scale must stay finite
+    assert all(bool(torch.isfinite(t).all()) for t in den), "denormal-small output gradients produced inf / nan"
+
+
 @pytest.mark.parametrize("nn,nl,P", [(64, 2, 1500), (32, 1, 333)])
 def test_render_nets_two_segment_input_and_in_place_gradient_sums(nn, nl, P):
     """ops.render_nets vs the oracle MLPs wired like Mapper.renderer (slams/mapping.py:616-626, models/decoder.py:

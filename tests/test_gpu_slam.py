@@ -301,6 +301,53 @@ def test_smoothness_branch_on_a_second_stream_matches_single_stream():
             assert_close(a.cpu(), b.cpu(), rtol=1e-5, what="two-stream vs one-stream gradient")
 
 
+def test_mapper_iteration_in_fp16_mlp_mode_tracks_fp32():
+    """cfg['model']['mlp']['dtype'] = 'fp16' (BASELINE configs[4]): same scene, parameters and rays as the fp32 path; the
+    loss terms agree to 2e-2 and training still reduces the loss (looser, stated tolerance)."""
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    out = {}
+    for dtype in ("fp32", "fp16"):
+        cam = synthetic.camera(H=60, W=80, fx=60.0, fy=60.0)
+        bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=0)
+        cfg = synthetic.default_cfg(n_pixels=360, n_samples_ray=32, n_surface_ray=15, n_frames=4, hash_size=14, voxel_size=0.08,
+                                    n_neurons=64, n_hidden_layers=2, smooth_pts=12, mlp_dtype=dtype)
+        dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+        mapper = Mapper(cfg, dec, bound, cam, device=DEV)
+        mapper.set_decoder(frames)
+        randomise_(dec, 11, scale=1.0)
+        with torch.no_grad():
+            dec.pe_fn.grid_fn.params.mul_(2000.0)
+        randomise_([mapper.fine_decoders.pool], 12)
+        assert dec.coarse_fn.decoder.fp16 == (dtype == "fp16") and mapper.fine_decoders.fp16 == (dtype == "fp16")
+        mapper.is_BA = False
+        opt, ql, Tl = mapper.set_optimizer(frames, fused=True)
+        for grp, lr in zip(opt.param_groups, (0.01, 0.0, 0.0)):
+            grp["lr"] = lr
+        torch.manual_seed(51)
+        prep = mapper.prepare_frames(frames)
+        pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+        g = torch.Generator().manual_seed(52)
+        u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+        hist = []
+        for it in range(12):
+            opt.zero_grad(set_to_none=True)
+            s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
+            loss, terms = mapper.iteration_loss(s, smooth=True, u_offset=u_off, u_jitter=u_jit)
+            loss.backward()
+            opt.step()
+            hist.append((float(loss), {k: float(v) for k, v in terms.items()}))
+        out[dtype] = hist
+    l32, t32 = out["fp32"][0]
+    l16, t16 = out["fp16"][0]
+    assert abs(l16 - l32) <= 2e-2 * abs(l32)
+    for k in t32:
+        assert abs(t16[k] - t32[k]) <= 2e-2 * max(abs(t32[k]), 1e-3), k
+    assert out["fp16"][-1][0] < 0.9 * out["fp16"][0][0], "fp16 mode does not train"
+    assert abs(out["fp16"][-1][0] - out["fp32"][-1][0]) <= 0.1 * abs(out["fp32"][-1][0])
+
+
 def test_static_shapes_masking_equals_ray_dropping():
     """Rays whose depth leaves the box: dropped by the reference (slams/mapping.py:576-586, host sync) vs kept with
     valid=0 in the sync-free path -- same loss and gradients (per_ray label layout)."""
