@@ -520,6 +520,232 @@ static Bound6 make_bound(const double* bound) {
   return b;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Hashed levels of LARGE tables, partition form.  The binned kernel above visits every (point, level) once per 8192-row
+// chunk of the level: 8 visits at T = 2^16, 128 at T = 2^20 (11 ms of an 18 ms iteration at 1 M points).  Here every
+// (point, level) is hashed ONCE: pass 1 partitions its 8 corner contributions {local row, w*g0, w*g1} by chunk through
+// LDS and appends each chunk's run to that chunk's global queue (structure of arrays: coalesced both ways); pass 2
+// streams a queue slice into the same 64-bit fixed-point LDS bins with every lane busy.  The queues cost 24 bytes of
+// HBM traffic per corner, which at 8 chunks per level is MORE than the redundant hashing it removes (measured at
+// T = 2^16, 262 k points: 141 + 122 us against ~190 us for the same levels binned) -- so the host picks this form from
+// 16 chunks per level up.  Queues are sized for the uniform-hash expectation plus slack; what does not fit goes straight
+// to d_table with float atomics (correct, merely slow: only reachable with adversarially clustered points).
+constexpr uint32_t PART_MAX_CHUNKS = 128;      // chunks per hashed level (T <= 2^20)
+constexpr uint32_t PART_THREADS = 256;         // points per pass-1 workgroup
+constexpr uint32_t PART_ENTRIES = PART_THREADS * 8;
+
+struct PartPlan {
+  uint32_t n;                                  // levels handled by the partition form
+  uint32_t level[DNS_MAX_LEVELS];              // their level indices
+  uint32_t chunks[DNS_MAX_LEVELS];             // 8192-row chunks of the level
+  uint32_t qoff[DNS_MAX_LEVELS + 1];           // first queue of the level (prefix sum of chunks)
+  uint32_t cap[DNS_MAX_LEVELS];                // entries per queue of the level
+  uint64_t qbase[DNS_MAX_LEVELS];              // float offset of the level's first queue
+  uint32_t chunk_shift;                        // log2(rows per chunk) = 13
+  uint32_t slices;                             // pass-2 workgroups per queue
+};
+
+__global__ __launch_bounds__(PART_THREADS) void hashgrid_bwd_partition_kernel(const float* __restrict__ xin, uint32_t P,
+                                                                               GridLevels lv, PartPlan pp,
+                                                                               const float2* __restrict__ dg_t,
+                                                                               uint32_t* __restrict__ qcount,
+                                                                               float* __restrict__ queues,
+                                                                               float* __restrict__ d_table) {
+  __shared__ uint32_t cnt[PART_MAX_CHUNKS], base[PART_MAX_CHUNKS + 1], gofs[PART_MAX_CHUNKS];
+  __shared__ uint32_t st_row[PART_ENTRIES];
+  __shared__ float st_v0[PART_ENTRIES], st_v1[PART_ENTRIES];
+  __shared__ uint8_t st_chunk[PART_ENTRIES];
+  const uint32_t p = blockIdx.x * PART_THREADS + threadIdx.x;
+  const bool live = p < P;
+  float xc[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    xc[0] = xin[(size_t)p * 3];
+    xc[1] = xin[(size_t)p * 3 + 1];
+    xc[2] = xin[(size_t)p * 3 + 2];
+  }
+  const uint32_t row_mask = (1u << pp.chunk_shift) - 1u;
+  for (uint32_t li = 0; li < pp.n; ++li) {
+    const uint32_t l = pp.level[li], C = pp.chunks[li], cap = pp.cap[li];
+    const float2 gg = live ? dg_t[(size_t)l * P + p] : make_float2(0.f, 0.f);
+    const bool work = live && !(gg.x == 0.f && gg.y == 0.f);
+    const float s = lv.scale[l];
+    const uint32_t size = lv.size[l], res = lv.resolution[l];
+    const bool hashed = lv.hashed[l] != 0;       // uniform
+    float f[3];
+    uint32_t g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
+      const float fl = floorf(pos);
+      g[a] = (uint32_t)(int)fl;
+      f[a] = pos - fl;
+    }
+    // per-axis terms of the row index: hashed  x ^ y*P1 ^ z*P2 (size = 2^T),  dense  (x + y*res + z*res^2) mod size
+    const uint32_t ax0 = g[0], ax1 = g[0] + 1u;
+    const uint32_t ay0 = hashed ? g[1] * 2654435761u : g[1] * res, ay1 = ay0 + (hashed ? 2654435761u : res);
+    const uint32_t az0 = hashed ? g[2] * 805459861u : g[2] * res * res, az1 = az0 + (hashed ? 805459861u : res * res);
+    for (uint32_t i = threadIdx.x; i < C; i += PART_THREADS) cnt[i] = 0;
+    __syncthreads();
+    uint32_t rows8[8], slot8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t x = (c & 1) ? ax1 : ax0, y = (c & 2) ? ay1 : ay0, z = (c & 4) ? az1 : az0;
+      uint32_t r;
+      if (hashed) {
+        r = (x ^ y ^ z) & (size - 1u);
+      } else {
+        r = x + y + z;
+        if (r >= size) r %= size;
+      }
+      rows8[c] = r;
+      slot8[c] = work ? atomicAdd(&cnt[r >> pp.chunk_shift], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the <= 128 chunk counts by the first wave, and one global reservation per chunk
+    if (threadIdx.x < 64u) {
+      uint32_t run = 0;
+      for (uint32_t c0 = 0; c0 < C; c0 += 64u) {
+        const uint32_t c = c0 + threadIdx.x;
+        const uint32_t v = c < C ? cnt[c] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = __shfl_up(incl, o);
+          if ((int)threadIdx.x >= o) incl += t;
+        }
+        if (c < C) {
+          base[c] = run + incl - v;
+          gofs[c] = v ? atomicAdd(&qcount[pp.qoff[li] + c], v) : 0u;
+        }
+        run += __shfl(incl, 63);
+      }
+      if (threadIdx.x == 0) base[C] = run;
+    }
+    __syncthreads();
+    if (work) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float w = ((c & 1) ? f[0] : 1.0f - f[0]) * ((c & 2) ? f[1] : 1.0f - f[1]) * ((c & 4) ? f[2] : 1.0f - f[2]);
+        const uint32_t ch = rows8[c] >> pp.chunk_shift;
+        const uint32_t at = base[ch] + slot8[c];
+        st_row[at] = rows8[c] & row_mask;
+        st_v0[at] = w * gg.x;
+        st_v1[at] = w * gg.y;
+        st_chunk[at] = (uint8_t)ch;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = base[C];
+    for (uint32_t i = threadIdx.x; i < total; i += PART_THREADS) {
+      const uint32_t ch = st_chunk[i];
+      const uint32_t at = gofs[ch] + (i - base[ch]);
+      if (at < cap) {
+        float* q = queues + pp.qbase[li] + (size_t)ch * cap * 3u;
+        reinterpret_cast<uint32_t*>(q)[at] = st_row[i];
+        q[cap + at] = st_v0[i];
+        q[2u * (size_t)cap + at] = st_v1[i];
+      } else {                                     // queue full (clustered points on a dense level): straight to the table
+        float* t = d_table + 2 * ((size_t)lv.offset[l] + ((size_t)ch << pp.chunk_shift) + st_row[i]);
+        atomicAdd(t, st_v0[i]);
+        atomicAdd(t + 1, st_v1[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void hashgrid_bwd_queue_kernel(GridLevels lv, PartPlan pp, const uint32_t* __restrict__ qcount,
+                                                                   const float* __restrict__ queues,
+                                                                   const uint32_t* __restrict__ gmax,
+                                                                   float* __restrict__ d_table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
+  const float mx = __uint_as_float(*gmax);
+  if (!(mx > 0.f)) return;                       // all-zero upstream gradient (uniform exit)
+  int ex;
+  (void)frexpf(mx, &ex);
+  const float scale = ldexpf(1.0f, 40 - ex);     // as in the binned kernel: |w*g| * scale < 2^40
+  const double inv_scale = (double)ldexpf(1.0f, ex - 40);
+  const uint32_t qi = blockIdx.x / pp.slices, slice = blockIdx.x % pp.slices;   // queue = (level, chunk)
+  uint32_t li = 0;
+  while (li + 1 < pp.n && qi >= pp.qoff[li + 1]) ++li;
+  const uint32_t ch = qi - pp.qoff[li], l = pp.level[li], cap = pp.cap[li];
+  const uint32_t row0 = ch << pp.chunk_shift;
+  const uint32_t rows = min(1u << pp.chunk_shift, lv.size[l] - row0);
+  const uint32_t n = min(qcount[qi], cap);
+  const uint32_t lo = (uint32_t)(((uint64_t)n * slice) / pp.slices), hi = (uint32_t)(((uint64_t)n * (slice + 1)) / pp.slices);
+  if (lo >= hi) return;                          // uniform per workgroup
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) bins[i] = 0ull;
+  __syncthreads();
+  const float* q = queues + pp.qbase[li] + (size_t)ch * cap * 3u;
+  const uint32_t* qr = reinterpret_cast<const uint32_t*>(q);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const uint32_t r = qr[i];
+    const float v0 = q[cap + i], v1 = q[2u * (size_t)cap + i];
+    atomicAdd(bins + 2 * r, (unsigned long long)fixed_rn(v0 * scale));
+    atomicAdd(bins + 2 * r + 1, (unsigned long long)fixed_rn(v1 * scale));
+  }
+  __syncthreads();
+  float* out = d_table + 2 * ((size_t)lv.offset[l] + row0);
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) {
+    const long long v = (long long)bins[i];
+    if (v != 0) atomicAdd(out + i, (float)((double)v * inv_scale));
+  }
+}
+
+// Levels with at least PART_MIN_CHUNKS chunks go through the partition form; hashed levels get the uniform-hash
+// expectation + 1/8 slack per queue, dense levels (spatially clustered points) twice the expectation.
+constexpr uint32_t PART_MIN_CHUNKS = 16;
+
+static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, PartPlan& pp) {
+  pp.n = 0;
+  pp.chunk_shift = 13;
+  uint32_t queues = 0;
+  uint64_t floats = 0;
+  for (uint32_t l = 0; l < lv.n_levels; ++l) {
+    const uint32_t chunks = (lv.size[l] + 8191u) >> 13;
+    if (chunks < min_chunks || chunks > PART_MAX_CHUNKS) continue;
+    if (lv.hashed[l] && (lv.size[l] & (lv.size[l] - 1u))) continue;
+    const uint64_t expect = ((uint64_t)P * 8u + chunks - 1) / chunks;
+    uint64_t cap = (lv.hashed[l] ? expect + expect / 8u : 2u * expect) + 4096u;
+    cap = (cap + 3u) & ~3ull;
+    if (cap > 0x7FFFFFFFull) return false;
+    const uint32_t i = pp.n++;
+    pp.level[i] = l;
+    pp.chunks[i] = chunks;
+    pp.qoff[i] = queues;
+    pp.cap[i] = (uint32_t)cap;
+    pp.qbase[i] = floats;
+    queues += chunks;
+    floats += (uint64_t)chunks * cap * 3u;
+  }
+  pp.qoff[pp.n] = queues;
+  for (uint32_t i = pp.n; i < DNS_MAX_LEVELS; ++i) {
+    pp.level[i] = 0;
+    pp.chunks[i] = 0;
+    pp.cap[i] = 0;
+    pp.qbase[i] = floats;
+    pp.qoff[i + 1] = queues;
+  }
+  if (!pp.n) return false;
+  pp.slices = (1024u + queues - 1) / queues;
+  if (pp.slices < 1) pp.slices = 1;
+  return true;
+}
+
+static uint64_t part_floats(const PartPlan& pp) {
+  uint64_t f = 0;
+  for (uint32_t i = 0; i < pp.n; ++i) f += (uint64_t)pp.chunks[i] * pp.cap[i] * 3u;
+  return f;
+}
+
+static uint32_t part_min_chunks() {
+  static const char* force = getenv("DNS_SCATTER");
+  if (force && force[0] == 'q') return 2u;                   // A/B: every multi-chunk level through the queues
+  if (force && force[0] == 'b') return PART_MAX_CHUNKS + 1u;  // A/B: none
+  return PART_MIN_CHUNKS;
+}
+
 }  // namespace dns
 
 using namespace dns;
@@ -595,12 +821,23 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     plan.xcd_major = (order_env && order_env[0] == 'l') ? 0u : 1u;
     static const char* walk = getenv("DNS_SCATTER_WALK");
     plan.strided_dense = (walk && walk[0] == 'c') ? 0u : 1u;
+    // levels of large tables: partition form (DNS_SCATTER=q sends every multi-chunk level there, =b none, for A/B)
+    PartPlan pp;
+    const bool part = plan.chunk_rows == 8192u && part_plan(lv, P, part_min_chunks(), pp);
+    bool in_part[DNS_MAX_LEVELS] = {};
+    if (part)
+      for (uint32_t i = 0; i < pp.n; ++i) in_part[pp.level[i]] = true;
     uint32_t total_chunks = 0, chunk_of[DNS_MAX_LEVELS];
     for (uint32_t l = 0; l < lv.n_levels; ++l) {
-      chunk_of[l] = (lv.size[l] + plan.chunk_rows - 1) / plan.chunk_rows;
+      chunk_of[l] = in_part[l] ? 0u : (lv.size[l] + plan.chunk_rows - 1) / plan.chunk_rows;
       total_chunks += chunk_of[l];
     }
-    uint32_t ns = ns_env ? (uint32_t)atoi(ns_env) : (512u + total_chunks - 1) / total_chunks;
+    if (total_chunks == 0) total_chunks = 1;
+    // ~512 workgroups in all: a dense level's jobs are sliced 4x (one chunk) / 2x finer, see below
+    uint32_t weight = 0;
+    for (uint32_t l = 0; l < lv.n_levels; ++l) weight += chunk_of[l] * (lv.hashed[l] ? 1u : (chunk_of[l] == 1 ? 4u : 2u));
+    if (weight == 0) weight = 1;
+    uint32_t ns = ns_env ? (uint32_t)atoi(ns_env) : (512u + weight - 1) / weight;
     if (ns < 1) ns = 1;
     const uint32_t max_ns = (P + 1023) / 1024;                 // at least ~one point per thread
     if (ns > max_ns) ns = max_ns ? max_ns : 1;
@@ -640,7 +877,25 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     }
     DNS_REQUIRE(lv.n_levels <= 16, "dns_encode_bwd: binned scatter supports <= 16 levels");
     hipLaunchKernelGGL(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
-    hipLaunchKernelGGL(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);
+    if (jobs)
+      hipLaunchKernelGGL(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);
+    if (part) {
+      uint32_t* qcount = gmax + 4;
+      float* queues = reinterpret_cast<float*>(qcount + DNS_MAX_LEVELS * PART_MAX_CHUNKS);
+      if (hipMemsetAsync(qcount, 0, sizeof(uint32_t) * pp.qoff[pp.n], st) != hipSuccess) {
+        set_error("dns_encode_bwd: memset failed");
+        return DNS_E_LAUNCH;
+      }
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)hashgrid_bwd_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 2 * (int)sizeof(unsigned long long));
+        attr2 = true;
+      }
+      hipLaunchKernelGGL(hashgrid_bwd_partition_kernel, dim3((P + PART_THREADS - 1) / PART_THREADS), dim3(PART_THREADS), 0, st, x, P, lv,
+                         pp, (const float2*)ws, qcount, queues, d_table);
+      hipLaunchKernelGGL(hashgrid_bwd_queue_kernel, dim3(pp.qoff[pp.n] * pp.slices), dim3(1024), lds_bytes, st, lv, pp,
+                         qcount, queues, gmax, d_table);
+    }
   }
   return check_launch("dns_encode_bwd");
 }
@@ -654,5 +909,11 @@ extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMet
 }
 
 extern "C" uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta) {
-  return meta ? (uint64_t)P * meta->n_levels * 2 + 2 : 0;   // level-major d_grid copy + max|d_grid| word
+  if (!meta) return 0;
+  // level-major d_grid copy + max|d_grid| word (+pad) + queue counters + the partition form's queues
+  uint64_t n = (uint64_t)P * meta->n_levels * 2 + 4;
+  const GridLevels lv = to_levels(meta);
+  PartPlan pp;
+  if (part_plan(lv, P, part_min_chunks(), pp)) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS + part_floats(pp);
+  return n;
 }

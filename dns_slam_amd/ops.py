@@ -149,7 +149,8 @@ class _EncodeFn(torch.autograd.Function):
         d_table = torch.zeros_like(table) if need_t else None
         d_pe = ptr(d_out) if ctx.pe_dim else None
         d_grid = C.c_void_p(d_out.data_ptr() + 4 * ctx.pe_dim) if ctx.g_dim else None
-        ws = torch.empty(P * ctx.g_dim + 2, device=x.device, dtype=torch.float32) if need_t else None
+        ws = torch.empty(int(lib.dns_encode_bwd_ws_floats(P, C.byref(ctx.meta.c))), device=x.device,
+                         dtype=torch.float32) if need_t else None
         check(lib.dns_encode_bwd(ptr(x), ctx.b6, P, ctx.n_bins, ptr(table) if ctx.g_dim else None,
                                  C.byref(ctx.meta.c) if ctx.g_dim else None, d_pe, ld, d_grid, ld,
                                  ptr(d_table), ptr(d_x), ptr(ws), stream_ptr()), "dns_encode_bwd")
