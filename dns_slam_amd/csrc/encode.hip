@@ -708,6 +708,8 @@ static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, Par
     if (lv.hashed[l] && (lv.size[l] & (lv.size[l] - 1u))) continue;
     const uint64_t expect = ((uint64_t)P * 8u + chunks - 1) / chunks;
     uint64_t cap = (lv.hashed[l] ? expect + expect / 8u : 2u * expect) + 4096u;
+    const char* cap_env = getenv("DNS_PART_CAP");                 // tests: force the queue-overflow fallback
+    if (cap_env && atoi(cap_env) > 0) cap = (uint64_t)atoi(cap_env);
     cap = (cap + 3u) & ~3ull;
     if (cap > 0x7FFFFFFFull) return false;
     const uint32_t i = pp.n++;
@@ -740,7 +742,7 @@ static uint64_t part_floats(const PartPlan& pp) {
 }
 
 static uint32_t part_min_chunks() {
-  static const char* force = getenv("DNS_SCATTER");
+  const char* force = getenv("DNS_SCATTER");                 // read per call: tests switch it
   if (force && force[0] == 'q') return 2u;                   // A/B: every multi-chunk level through the queues
   if (force && force[0] == 'b') return PART_MAX_CHUNKS + 1u;  // A/B: none
   return PART_MIN_CHUNKS;
@@ -792,7 +794,7 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
   hipStream_t st = (hipStream_t)stream;
   const uint32_t blocks = (P + 255) / 256;
   // table gradient: LDS-binned scatter (DNS_SCATTER=atomic forces the per-corner global atomics, for comparison)
-  static const char* force = getenv("DNS_SCATTER");
+  const char* force = getenv("DNS_SCATTER");
   bool binned = d_table && d_grid && ws && meta->n_levels <= 16;   // measured faster at T=2^16 (17x) and T=2^20 (2.5x)
   if (force && force[0] == 'a') binned = false;
   if (force && force[0] == 'b') binned = d_table && d_grid && ws;

@@ -39,8 +39,19 @@ def test_hashgrid_rows_bit_exact(hash_size, res):
     assert torch.equal(rows_o, rows_p)
 
 
-@pytest.mark.parametrize("hash_size,res,P", [(16, 592, 5000), (12, 64, 777)])
-def test_encode_forward_backward(hash_size, res, P):
+@pytest.mark.parametrize("hash_size,res,P,scatter,cap", [
+    (16, 592, 5000, None, None),      # binned scatter (8 chunks per hashed level)
+    (12, 64, 777, None, None),
+    (20, 231, 4000, None, None),      # T = 2^20: partition form picked by the host (128 chunks per hashed level)
+    (16, 592, 3000, "q", None),       # partition form forced on every multi-chunk level (dense ones included)
+    (16, 592, 3000, "q", "64"),       # ... with 64-entry queues: most contributions take the overflow fallback
+    (16, 592, 3000, "a", None),       # per-corner global atomics
+])
+def test_encode_forward_backward(hash_size, res, P, scatter, cap, monkeypatch):
+    if scatter:
+        monkeypatch.setenv("DNS_SCATTER", scatter)
+    if cap:
+        monkeypatch.setenv("DNS_PART_CAP", cap)
     ops = _ops()
     om, pm = tr.grid_meta(hash_size, res), ops.GridMeta(hash_size, res)
     g = torch.Generator().manual_seed(1)
