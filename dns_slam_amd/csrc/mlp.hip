@@ -379,8 +379,6 @@ __device__ __forceinline__ void relu(f32x16 (&a)[NT]) {
     for (int r = 0; r < 16; ++r) a[t][r] = fmaxf(a[t][r], 0.f);
 }
 
-__device__ __forceinline__ uint32_t param_off_hidden(uint32_t nn, uint32_t n_in) { return nn * n_in; }
-
 // ---- row-coalesced global I/O of accumulator-layout tiles through a wave-private LDS staging tile ----
 // In the accumulator layout a lane owns ONE point, so a direct float4 store (or load) instruction touches 64 different
 // cache lines for 1 KB of payload; the texture-addresser retires ~1 line per 2 cycles, and at 16 waves per CU those
@@ -686,31 +684,6 @@ __device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ d
     }
   }
   wave_lds_fence();
-}
-
-template <int NT>
-__device__ __forceinline__ void store_acc_rows(float* __restrict__ dst, const f32x16 (&a)[NT], uint32_t h) {
-  // dst = row base of a [NN]-wide slot row; 4 contiguous floats per (tile, quad)
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 v = make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
-      *reinterpret_cast<float4*>(dst + t * 32 + 8 * q + 4 * h) = v;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void load_acc_rows(const float* __restrict__ src, f32x16 (&a)[NT], uint32_t h, bool ok) {
-  // inverse of store_acc_rows: a slot row of [NN] floats -> accumulator layout
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(src + t * 32 + 8 * q + 4 * h);
-      a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w;
-    }
 }
 
 // LDS layout helpers (floats)
