@@ -119,7 +119,8 @@ class Out(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, pe, features):
-        x = torch.cat((pe, features), -1)          # built once; the reference builds it twice (:123-124)
-        color = self.sigmoid(self.color_decoder(x))
-        logit = self.logit_decoder(x)
+        # the reference builds cat((pe, features)) twice (:123-124); here both networks read the two column blocks in place
+        c, l = self.color_decoder, self.logit_decoder
+        color = self.sigmoid(ops.mlp_cat(pe, features, c.params, c.n_output_dims, c.n_neurons, c.n_hidden_layers, c.fp16))
+        logit = ops.mlp_cat(pe, features, l.params, l.n_output_dims, l.n_neurons, l.n_hidden_layers, l.fp16)
         return color, logit

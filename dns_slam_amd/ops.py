@@ -245,6 +245,57 @@ class _MlpFn(torch.autograd.Function):
         return d_x, d_p, None, None, None, None
 
 
+class _MlpCatFn(torch.autograd.Function):
+    """y = MLP(cat(x1, x2, -1); params) without building the concatenation: the kernels read the two column segments in
+    place (dns_mlp_fwd/bwd two-segment input) and write the two input gradients separately."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, params, shape):
+        n_in, n_out, nn, nl = shape[:4]
+        fp16 = MLP_FP16_FLAG if (len(shape) > 4 and shape[4]) else 0
+        require_cuda(params)
+        if not (x1.is_cuda and x2.is_cuda):
+            raise ValueError("dns_slam_amd ops run on the GPU only (got a non-CUDA tensor); there is no CPU fallback")
+        x1, x2 = _row_major_2d(x1.float()), _row_major_2d(x2.float())
+        P, n1 = x1.shape
+        y = torch.empty(P, n_out, device=x1.device, dtype=torch.float32)
+        h_save = torch.empty(nl * P * nn, device=x1.device, dtype=torch.float32)     # two-segment backward needs it
+        check(lib.dns_mlp_fwd(ptr(x1), x1.stride(0), ptr(x2), x2.stride(0), n1, ptr(params), n_in, n_out, nn, nl, ptr(y),
+                              n_out, P, None, None, 0, ptr(h_save), fp16, stream_ptr()), "dns_mlp_fwd")
+        ctx.save_for_backward(x1, x2, params, h_save)
+        ctx.shape, ctx.fp16 = shape[:4], fp16
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, params, h_save = ctx.saved_tensors
+        n_in, n_out, nn, nl = ctx.shape
+        dy = dy.contiguous()
+        P, n1 = x1.shape
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d1 = torch.empty(P, n1, device=x1.device, dtype=torch.float32) if need_x else None
+        d2 = torch.empty(P, n_in - n1, device=x1.device, dtype=torch.float32) if need_x else None
+        d_p = torch.zeros_like(params) if ctx.needs_input_grad[2] else None
+        ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(P, nn, nl)), device=x1.device, dtype=torch.float32)
+        check(lib.dns_mlp_bwd(ptr(x1), x1.stride(0), ptr(x2), x2.stride(0), n1, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl,
+                              ptr(d1), n1, ptr(d2), n_in - n1, ptr(d_p), ptr(ws), P, None, None, 0, ptr(h_save), ctx.fp16,
+                              stream_ptr()), "dns_mlp_bwd")
+        return (d1 if ctx.needs_input_grad[0] else None), (d2 if ctx.needs_input_grad[1] else None), d_p, None
+
+
+def mlp_cat(x1: torch.Tensor, x2: torch.Tensor, params: torch.Tensor, n_out: int, n_neurons: int = 32,
+            n_hidden_layers: int = 1, fp16: bool = False) -> torch.Tensor:
+    """``mlp(torch.cat((x1, x2), -1), ...)`` with the concatenation left implicit (models/decoder.py:73,123-124).  Falls
+    back to the explicit cat when a segment is not a multiple of 4 columns / 16-byte addressable or wider than 64."""
+    n1, n2 = x1.shape[-1], x2.shape[-1]
+    ok = (n1 % 4 == 0 and n2 % 4 == 0 and 0 < n1 <= 64 and 0 < n2 <= 64 and x1.dim() == 2 and x2.dim() == 2
+          and x1.stride(-1) == 1 and x2.stride(-1) == 1 and x1.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0
+          and x1.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and x1.dtype == torch.float32 and x2.dtype == torch.float32)
+    if not ok:
+        return mlp(torch.cat((x1, x2), -1), params, n1 + n2, n_out, n_neurons, n_hidden_layers, fp16)
+    return _MlpCatFn.apply(x1, x2, params, (n1 + n2, n_out, n_neurons, n_hidden_layers, bool(fp16)))
+
+
 def mlp(x: torch.Tensor, params: torch.Tensor, n_in: int, n_out: int, n_neurons: int = 32,
         n_hidden_layers: int = 1, fp16: bool = False) -> torch.Tensor:
     """Bias-free ReLU MLP on the matrix cores (tcnn CutlassMLP replacement): exact fp32, or with ``fp16`` tcnn's own
