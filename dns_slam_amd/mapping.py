@@ -168,9 +168,15 @@ class Mapper:
             b = torch.addcmul(torch.addcmul(c_mar, r[:3], c_off), r[3:], c_vox)
             pts = torch.addcmul(b, self._lattice, c_vox)
             pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
-            coarse = self.decoder.coarse_fn(pe, features=grid_pts)
             if self.fused_losses:
-                return ops.tv_smoothness(coarse, n, sample_points)
+                # Only the occupancy logit (output row 0, mapping.py:152) enters the TV term: the coarse network runs as an
+                # (80 -> ... -> 1) network on the SAME parameter tensor (row 0 of W_out is the first row stored), so the other
+                # 32 output rows are neither computed nor written, and no [n^3, 33] gradient full of zeros is built.
+                net = self.decoder.coarse_fn.decoder
+                occ = ops.mlp(fused_cat(pe, grid_pts), net.params, net.n_input_dims, 1, net.n_neurons, net.n_hidden_layers,
+                              fp16=getattr(net, "fp16", False))
+                return ops.tv_smoothness(occ, n, sample_points)
+            coarse = self.decoder.coarse_fn(pe, features=grid_pts)
             occ = coarse[:, 0:1].reshape(n, n, n, 1)
             tv_x = torch.pow(occ[1:, ...] - occ[:-1, ...], 2).sum()
             tv_y = torch.pow(occ[:, 1:, ...] - occ[:, :-1, ...], 2).sum()

@@ -348,6 +348,30 @@ def test_mapper_iteration_in_fp16_mlp_mode_tracks_fp32():
     assert abs(out["fp16"][-1][0] - out["fp32"][-1][0]) <= 0.1 * abs(out["fp32"][-1][0])
 
 
+def test_sync_free_smoothness_path_equals_reference_formulation():
+    """static_shapes smoothness (fp64 affine lattice map, coarse network evaluated for its occupancy row only) vs the
+    reference-ordered formulation (slams/mapping.py:133-157) on the same random offsets: value and gradients."""
+    cfg, bound, cam, frames, dec, mapper = _setup(n_neurons=64, n_hidden_layers=2)
+    ps = [dec.pe_fn.grid_fn.params, dec.coarse_fn.decoder.params]
+    out = []
+    for static in (True, False):
+        for p in ps:
+            p.grad = None
+        mapper.static_shapes = static
+        torch.cuda.manual_seed(77)
+        if static:
+            val = mapper.smoothness(sample_points=cfg["training"]["smooth_pts"])
+        else:
+            r = torch.rand(6, device=DEV)                      # what the sync-free path draws: [offset | jitter]
+            val = mapper.smoothness(sample_points=cfg["training"]["smooth_pts"], u_offset=r[:3], u_jitter=r[3:].reshape(1, 1, 1, 3))
+        val.backward()
+        out.append((float(val), [p.grad.clone() for p in ps]))
+    mapper.static_shapes = False
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert_close(a.cpu(), b.cpu(), rtol=2e-5, what="sync-free vs reference-ordered smoothness gradient")
+
+
 def test_static_shapes_masking_equals_ray_dropping():
     """Rays whose depth leaves the box: dropped by the reference (slams/mapping.py:576-586, host sync) vs kept with
     valid=0 in the sync-free path -- same loss and gradients (per_ray label layout)."""
