@@ -463,6 +463,54 @@ class Mapper:
         pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)
         return pred_color, pred_depth, pred_depth_var, pred_logits, fine_latents, coarse_latents
 
+    # ------------------------------------------------------------------ slams/meshing.py:461-503
+    @torch.no_grad()
+    def eval_points(self, pts, pixel_pts=None, gt_label_pts=None, stage="fine", n_pts_batch=1 << 20):
+        """``Mesher.eval_points`` (the meshing / evaluation query; decoders = this mapper's): world points [P,3] ->
+        (values [P,4] = sigmoid colour + occupancy logit, -100 outside the open bound; labels [P] = argmax of the logit
+        network, -1 outside; ``None`` for ``stage='coarse'``).  ``gt_label_pts`` routes the fine decoders exactly like
+        the reference (an unknown class raises ValueError, classes with a single point give zeros).  Forward only; runs
+        in chunks of ``n_pts_batch`` points (the reference's marching-cubes driver sends 500 000 at a time)."""
+        dev = self.device
+        pts = pts.to(dev).float()
+        P = pts.shape[0]
+        pixel = torch.zeros(P, self.hidden_dim, device=dev) if pixel_pts is None else pixel_pts.to(dev).float()
+        if stage != "coarse" and gt_label_pts is None:
+            raise ValueError("eval_points(stage='fine') needs gt_label_pts")
+        classes = None if stage == "coarse" else gt_label_pts.to(dev).long().reshape(-1)
+        b = self.bound_dev
+        p64 = pts.to(torch.float64)
+        mask = ((p64[:, 0] < b[0, 1]) & (p64[:, 0] > b[0, 0]) & (p64[:, 1] < b[1, 1]) & (p64[:, 1] > b[1, 0]) &
+                (p64[:, 2] < b[2, 1]) & (p64[:, 2] > b[2, 0]))
+        if classes is not None:
+            slot_all = self._class_slots(classes, True)       # unknown class -> ValueError, like meshing.py:451
+        values, labels = [], []
+        for s0 in range(0, P, n_pts_batch):
+            s1 = min(s0 + n_pts_batch, P)
+            buf = self.decoder.pe_fn.forward_world(pts[s0:s1], self.bound)
+            pe, grid_pts = buf[:, :self.pe_dim], buf[:, self.pe_dim:]
+            if classes is None:
+                lat = self.decoder.coarse_fn(pe, features=grid_pts)
+            else:
+                pool = self.fine_decoders
+                # the > 1 point rule is per CALL in the reference: count over all points, not per chunk
+                cnt = torch.bincount(slot_all.clamp_min(0), minlength=max(len(pool), 1))
+                slot = torch.where((slot_all[s0:s1] >= 0) & (cnt[slot_all[s0:s1].clamp_min(0)] > 1), slot_all[s0:s1],
+                                   torch.full_like(slot_all[s0:s1], -1))
+                lat = ops.mlp_grouped(fused_cat(pe, grid_pts), pool.pool[:max(len(pool), 1)], slot, self.pe_dim + self.grid_dim,
+                                      self.hidden_dim + 1, pool.nn_, pool.nl, min_count=1, fp16=getattr(pool, "fp16", False))
+            color, logits = self.decoder.out_fn(pe, torch.cat((lat[:, 1:], pixel[s0:s1]), -1))
+            values.append(torch.cat((color, lat[:, 0:1]), -1))
+            if classes is not None:
+                labels.append(torch.argmax(logits, dim=-1))
+        values = torch.cat(values) if len(values) != 1 else values[0]
+        values[~mask, 3] = -100
+        if classes is None:
+            return values, None
+        labels = torch.cat(labels) if len(labels) != 1 else labels[0]
+        labels[~mask] = -1
+        return values, labels
+
     # ------------------------------------------------------------------ slams/mapping.py:638-724 (without the plotting)
     @torch.no_grad()
     def render_frame(self, cur_gt_color, cur_gt_depth, cur_gt_label, cur_c2w, features=None, n_pts_batch=None, jitter=None):

@@ -153,6 +153,29 @@ def tracker_renderer(model: OracleModel, samples: dict):
     return rgb, depth, var, pred_logits
 
 
+def eval_points(model: OracleModel, pts: torch.Tensor, pixel_pts: torch.Tensor, gt_label_pts=None, stage: str = "fine"):
+    """slams/meshing.py:461-503 (``Mesher.eval_points``, the live branch): colour + occupancy logit of arbitrary world
+    points, -100 occupancy outside the (open) bound; ``stage='fine'`` routes every point through the fine decoder of
+    its label (meshing.py:447-458, same > 1 point rule as Mapper.fine_fn) and also returns argmax labels (-1 outside)."""
+    b = model.bound
+    mask = ((pts[:, 0] < b[0, 1]) & (pts[:, 0] > b[0, 0]) & (pts[:, 1] < b[1, 1]) & (pts[:, 1] > b[1, 0]) &
+            (pts[:, 2] < b[2, 1]) & (pts[:, 2] > b[2, 0]))
+    x = rm.normalise_points(pts, b)
+    pe, grid = model.pe_fn(x)
+    if stage == "coarse":
+        lat = model.coarse_fn(pe, grid)
+    else:
+        lat = model.fine_fn(pe, gt_label_pts, grid)
+    color, logits = model.out_fn(pe, torch.cat((lat[:, 1:], pixel_pts), -1))
+    values = torch.cat((color, lat[:, 0:1]), -1)
+    values[~mask, 3] = -100
+    if stage == "coarse":
+        return values, None
+    labels = torch.argmax(logits, dim=-1)
+    labels[~mask] = -1
+    return values, labels
+
+
 def frame_samples(image5, quad, T, cam, bound, indices, t_surf, t_zero, n_samples, n_surface,
                   window=None, features=None, pixel_dim_half=32):
     """One target frame of ``get_target_samples`` (slams/mapping.py:487-572 /

@@ -496,6 +496,37 @@ def test_render_frame_matches_oracle_chunks():
     assert float(agree) > 0.995          # argmax may flip where two logits tie to 1e-4
 
 
+def test_eval_points_matches_oracle():
+    """Meshing / evaluation query (slams/meshing.py:461-503): colour + occupancy of arbitrary world points, -100 outside
+    the open bound, fine-decoder routing by label with the > 1 point rule, argmax labels; chunked evaluation."""
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    g = torch.Generator().manual_seed(8)
+    P = 3000
+    ext = (bound[:, 1] - bound[:, 0]).float()
+    pts = (torch.rand(P, 3, generator=g) * 1.2 - 0.1) * ext + bound[:, 0].float()        # ~40 % outside
+    pix = torch.rand(P, cfg["model"]["hidden_dim"], generator=g) * 2 - 1
+    known = sorted(mapper.fine_decoders.keys())
+    lab = torch.tensor(known)[torch.randint(0, len(known) - 1, (P,), generator=g)]
+    lab[17] = known[-1]                                   # a class with exactly one point -> zeros from the fine stage
+    for stage in ("coarse", "fine"):
+        vp, lp = mapper.eval_points(pts, pixel_pts=pix, gt_label_pts=lab, stage=stage, n_pts_batch=1024)
+        vo, lo = sr.eval_points(om, pts, pix, lab, stage)
+        assert_close(vp.cpu(), vo.detach(), what=f"eval_points values ({stage})")
+        inside = vo[:, 3] != -100
+        assert 0.3 < float(inside.float().mean()) < 0.9
+        if stage == "fine":
+            agree = (lp.cpu() == lo).float().mean()
+            assert float(agree) > 0.995                   # argmax may flip where two logits tie to 1e-4
+            assert bool((lp.cpu()[~inside] == -1).all())
+            assert float(vp[17, 3]) in (0.0, -100.0)      # single-point class: occupancy logit 0 (or outside)
+        else:
+            assert lp is None
+    lab[5] = 999
+    with pytest.raises(ValueError):
+        mapper.eval_points(pts, pixel_pts=pix, gt_label_pts=lab, stage="fine")
+
+
 def test_tracker_track_frame_eager_and_graphed_reduce_pose_error():
     """Per-frame tracking loop (slams/tracking.py:313-340): from a perturbed pose, both the eager loop and the
     hipGraph-replayed loop lower the loss and return the best-loss camera."""
