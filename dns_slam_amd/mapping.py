@@ -15,8 +15,7 @@ Keyframe selection, visualisation, meshing, checkpointing and the process loop (
 """
 from __future__ import annotations
 
-import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F

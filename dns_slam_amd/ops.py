@@ -6,7 +6,7 @@ happens in libdns_hip.so; nothing in this module has a CPU or eager-torch fallba
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch

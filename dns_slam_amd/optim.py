@@ -4,7 +4,6 @@ replays from a hipGraph.  Same constructor shape as ``torch.optim.Adam`` for wha
 ``{'params': [...], 'lr': ...}`` groups, default betas (0.9, 0.999) and eps 1e-8, no weight decay, no amsgrad."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import List
 
 import torch

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .common import feature_matching, get_quad_from_c2w, get_rotation_from_quad
+from .common import feature_matching, get_quad_from_c2w
 
 
 class Tracker:
