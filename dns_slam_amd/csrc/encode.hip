@@ -333,9 +333,18 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
     for (uint32_t l = 0; l < n_levels; ++l)
       dg_t[(size_t)l * P + p] = make_float2(tile[threadIdx.x * LDT + 2 * l], tile[threadIdx.x * LDT + 2 * l + 1]);
   }
+  // max |d_grid|: wave reduce, then ONE conditional atomic per workgroup -- 4096 unconditional same-address atomics
+  // serialised into ~40 us of this kernel's 56; a (possibly stale) read of the running max lets all but the first few
+  // workgroups skip theirs (staleness only costs a redundant atomic, never a wrong maximum)
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63u) == 0 && m > 0.f && m < INFINITY) atomicMax(gmax, __float_as_uint(m));
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63u) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float bm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (bm > 0.f && bm < INFINITY && bm > __uint_as_float(__atomic_load_n(gmax, __ATOMIC_RELAXED))) atomicMax(gmax, __float_as_uint(bm));
+  }
 }
 
 // round-to-nearest-even of an fp32 value with |v| < 2^40 to a 64-bit integer: v = hi * 2^16 + lo exactly (hi = trunc(v /
