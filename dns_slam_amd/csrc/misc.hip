@@ -142,7 +142,7 @@ extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sa
     return DNS_E_LAUNCH;
   }
   const uint32_t total = n * n * n;
-  const uint32_t blocks = (total + 255) / 256 < 512 ? (total + 255) / 256 : 512;
+  const uint32_t blocks = (total + 255) / 256 < 256 ? (total + 255) / 256 : 256;   // each ends in one atomic on ONE word
   const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
   hipLaunchKernelGGL(tv_fwd_kernel, dim3(blocks), dim3(256), 0, st, lat, ld, n, inv, out);
   return check_launch("dns_tv_fwd");

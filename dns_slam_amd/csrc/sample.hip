@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void raygen_sample_kernel(
 // Stand-alone sample_along_rays(gt_depth, n_samples, n_surface, far_bb) (utils/common.py:561): far_bb is an input.
 __global__ void depth_max_flat_kernel(const float* __restrict__ depth, int n, uint32_t* __restrict__ ws) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && depth[i] > 0.f) atomicMax(ws, __float_as_uint(depth[i]));
+  float m = (i < n && depth[i] > 0.f) ? depth[i] : 0.f;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));     // one atomic per wave, not per ray, on this one word
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(ws, __float_as_uint(m));
 }
 
 template <int E>
