@@ -350,7 +350,10 @@ class Mapper:
         rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = res
         N, S = z.shape
         if features is None:
-            code = torch.zeros(N, S, self.hidden_dim, device=self.device)
+            # no 2-D branch: one read-only block of zeros, made once per shape instead of a 33 MB fill per iteration
+            code = getattr(self, "_zero_code", None)
+            if code is None or code.shape != (N, S, self.hidden_dim):
+                code = self._zero_code = torch.zeros(N, S, self.hidden_dim, device=self.device)
         else:
             if features.dim() == 5:
                 # stem feature maps [n_target, n_refer, C, h, w] + refer_frames: the 2-D branch of :533-551
@@ -446,18 +449,19 @@ class Mapper:
             slot = self._class_slots(classes, strict)
             dec, pool = self.decoder, self.fine_decoders
             net = lambda m: (m.n_input_dims, m.n_output_dims, m.n_neurons, m.n_hidden_layers)
-            coarse_latents, fine_latents, color_raw, logits_pts = ops.render_nets(
-                buf, pixel_pts, dec.coarse_fn.decoder.params, pool.pool[:max(len(pool), 1)],
+            coarse_latents, fine_latents, values_pts, logits_pts = ops.render_nets(
+                buf, pixel_pts, dec.coarse_fn.decoder.params, pool.pool,
                 dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, slot, self.pe_dim,
                 net(dec.coarse_fn.decoder), (self.pe_dim + self.grid_dim, self.hidden_dim + 1, pool.nn_, pool.nl),
                 net(dec.out_fn.color_decoder), net(dec.out_fn.logit_decoder),
-                fp16=getattr(dec.coarse_fn.decoder, "fp16", False))
-            color_pts = torch.sigmoid(color_raw)
+                fp16=getattr(dec.coarse_fn.decoder, "fp16", False), n_groups=max(len(pool), 1))
+            # values_pts = (sigmoid colour | occupancy)
         else:
             coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts)
             fine_latents = self.fine_fn(pe, classes=classes, features=grid_pts, strict=strict)
             color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((fine_latents[:, 1:], pixel_pts), -1))
-        values_pts = torch.cat((color_pts, fine_latents[:, 0:1]), -1).reshape(n_pts, n_samples, -1)
+            values_pts = torch.cat((color_pts, fine_latents[:, 0:1]), -1)
+        values_pts = values_pts.reshape(n_pts, n_samples, -1)
         logits_pts = logits_pts.reshape(n_pts, n_samples, -1)
         pred_depth, pred_depth_var, pred_color, weights, pred_logits = ops.composite(values_pts, z_vals, logits_pts)
         return pred_color, pred_depth, pred_depth_var, pred_logits, fine_latents, coarse_latents

@@ -339,12 +339,15 @@ class _RenderNetsFn(torch.autograd.Function):
       * the colour / logit input ``cat(pe, cat(fine[:, 1:], pixel))`` (models/decoder.py:123-124) is never built: the
         networks read the pe columns of ``buf`` and the [P, 64] feature block as a two-segment input;
       * in the backward every network adds its input gradient in place (accumulate_dx) into one d_buf / d_feat pair
-        instead of autograd materialising one [P, 80] / [P, 112] gradient per consumer and summing them.
+        instead of autograd materialising one [P, 80] / [P, 112] gradient per consumer and summing them;
+      * the compositing input ``cat(sigmoid(colour), fine[:, 0:1])`` (slams/mapping.py:622-627) is an output of the node
+        (the colour network writes into its rows), so neither the cat nor the [P, h+1] zero-padded gradient of the
+        ``fine[:, 0:1]`` slice and its sum with the losses' gradient exist.
     buf: [P, pe_dim + grid_dim] (OneBlob | hash grid), pixel: [P, C] 2-D feature code."""
 
     @staticmethod
     def forward(ctx, buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg):
-        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count, fp16 = cfg
+        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count, fp16, n_groups = cfg
         fp16 = MLP_FP16_FLAG if fp16 else 0
         require_cuda(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point)
         buf = _row_major_2d(buf.float())
@@ -363,29 +366,38 @@ class _RenderNetsFn(torch.autograd.Function):
 
         coarse = torch.empty(P, shp_c[1], device=dev, dtype=torch.float32)
         h_c = run(buf, None, 0, coarse_p, shp_c, coarse, None, None, P, 0)
-        ri, tg, n_slots = group_slots(slot_of_point, fine_pool.shape[0], min_count)
+        ri, tg, n_slots = group_slots(slot_of_point, n_groups or fine_pool.shape[0], min_count)
         fine = torch.zeros(P, shp_f[1], device=dev, dtype=torch.float32)
         h_f = run(buf, None, 0, fine_pool, shp_f, fine, ri, tg, n_slots, fine_pool.shape[-1])
         feat = torch.cat((fine[:, 1:], pixel), -1)                        # [P, hidden + C]
-        color = torch.empty(P, shp_col[1], device=dev, dtype=torch.float32)
+        # raw = (sigmoid(colour) | occupancy) = the compositing kernel's input (slams/mapping.py:622-627): the colour
+        # network writes its three columns straight into the [P, 4] rows
+        raw = torch.empty(P, 4, device=dev, dtype=torch.float32)
         logit = torch.empty(P, shp_log[1], device=dev, dtype=torch.float32)
-        h_col = run(buf, feat, pe_dim, color_p, shp_col, color, None, None, P, 0)
+        h_col = run(buf, feat, pe_dim, color_p, shp_col, raw, None, None, P, 0)
         h_log = run(buf, feat, pe_dim, logit_p, shp_log, logit, None, None, P, 0)
-        ctx.save_for_backward(buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log)
+        raw.sigmoid_()                                                    # column 3 is not written yet
+        raw[:, 3] = fine[:, 0]
+        ctx.save_for_backward(buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log, raw)
         ctx.cfg, ctx.n_slots, ctx.pixel_dim = cfg, n_slots, pixel.shape[1]
-        return coarse, fine, color, logit
+        ctx.set_materialize_grads(False)
+        return coarse, fine, raw, logit
 
     @staticmethod
-    def backward(ctx, d_coarse, d_fine, d_color, d_logit):
-        buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log = ctx.saved_tensors
-        pe_dim, shp_c, shp_f, shp_col, shp_log, _, fp16 = ctx.cfg
+    def backward(ctx, d_coarse, d_fine, d_raw, d_logit):
+        buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log, raw = ctx.saved_tensors
+        pe_dim, shp_c, shp_f, shp_col, shp_log, _, fp16, _ = ctx.cfg
         fp16 = MLP_FP16_FLAG if fp16 else 0
         P, dev = buf.shape[0], buf.device
         st = stream_ptr()
         need_buf = ctx.needs_input_grad[0]
         need_pix = ctx.needs_input_grad[1]
         d_buf = torch.empty_like(buf)
-        d_feat = torch.empty_like(feat)
+        # [P, 4 + hidden + C]: column 3 = d occupancy (from raw), columns 4.. = the feature-block gradient of the colour
+        # and logit networks, so that columns 3..3+hidden are the fine network's output gradient in ONE strided view
+        n_f = shp_f[1]
+        d_featx = torch.empty(P, 4 + feat.shape[1], device=dev, dtype=torch.float32)
+        d_feat = d_featx[:, 4:]
 
         # one zero-fill for the four parameter gradients (they are views of one buffer)
         need = [ctx.needs_input_grad[i] for i in (2, 3, 4, 5)]
@@ -411,25 +423,37 @@ class _RenderNetsFn(torch.autograd.Function):
         # 1. coarse: writes all columns of d_buf
         d_cp = run(buf, None, 0, grad(d_coarse, shp_c[1]), coarse_p, shp_c, d_buf, None, ctx.needs_input_grad[2],
                    None, None, P, 0, h_c, 0)
-        # 2./3. colour then logit: pe columns of d_buf (+=), feature block d_feat (=, then +=)
-        d_colp = run(buf, feat, pe_dim, grad(d_color, shp_col[1]), color_p, shp_col, d_buf, d_feat,
+        # 2./3. colour then logit: pe columns of d_buf (+=), feature block d_feat (=, then +=).  The colour network's
+        # output gradient is the sigmoid's: d_raw * s * (1 - s) on the whole [P, 4] rows (column 3 is not read, lddy 4)
+        if d_raw is None:
+            d_col = torch.zeros(P, 4, device=dev)
+            d_featx[:, 3] = 0
+        else:
+            d_raw = d_raw.contiguous().float()
+            d_col = torch.ops.aten.sigmoid_backward(d_raw, raw)
+            d_featx[:, 3] = d_raw[:, 3]
+        d_colp = run(buf, feat, pe_dim, d_col, color_p, shp_col, d_buf, d_feat,
                      ctx.needs_input_grad[4], None, None, P, 0, h_col, 1)
         d_logp = run(buf, feat, pe_dim, grad(d_logit, shp_log[1]), logit_p, shp_log, d_buf, d_feat,
                      ctx.needs_input_grad[5], None, None, P, 0, h_log, 3)
-        # 4. fine: its output gradient = the caller's + what colour / logit sent back through the feature block
-        d_ft = grad(d_fine, shp_f[1]).clone() if d_fine is not None else torch.zeros(P, shp_f[1], device=dev)
-        d_ft[:, 1:] += d_feat[:, :shp_f[1] - 1]
+        # 4. fine: its output gradient = the caller's + d occupancy + what colour / logit sent back through the features
+        d_ft = d_featx[:, 3:3 + n_f]
+        if d_fine is not None:
+            d_ft = d_fine.float() + d_ft
         d_fp = run(buf, None, 0, d_ft, fine_pool, shp_f, d_buf, None, ctx.needs_input_grad[3], ri, tg, ctx.n_slots,
                    fine_pool.shape[-1], h_f, 1)
-        d_pix = d_feat[:, shp_f[1] - 1:] if need_pix else None
+        d_pix = d_feat[:, n_f - 1:] if need_pix else None
         return (d_buf if need_buf else None), d_pix, d_cp, d_fp, d_colp, d_logp, None, None
 
 
 def render_nets(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, pe_dim, shp_coarse, shp_fine,
-                shp_color, shp_logit, min_count=2, fp16=False):
-    """-> (coarse [P, h+1], fine [P, h+1], colour (pre-sigmoid) [P, 3], logits [P, n_class]); shapes are
-    (n_in, n_out, n_neurons, n_hidden_layers) tuples."""
-    cfg = (int(pe_dim), tuple(shp_coarse), tuple(shp_fine), tuple(shp_color), tuple(shp_logit), int(min_count), bool(fp16))
+                shp_color, shp_logit, min_count=2, fp16=False, n_groups=None):
+    """-> (coarse [P, h+1], fine [P, h+1], raw [P, 4] = (sigmoid(colour), fine[:, 0]) -- the compositing input --,
+    logits [P, n_class]); shapes are (n_in, n_out, n_neurons, n_hidden_layers) tuples (colour n_out = 3).  n_groups: only
+    the first n_groups weight sets of fine_pool are in use (slot_of_point < n_groups) -- pass the whole pool rather than
+    a slice of it and autograd has no [capacity, n_params] slice gradient to zero-fill and copy into."""
+    cfg = (int(pe_dim), tuple(shp_coarse), tuple(shp_fine), tuple(shp_color), tuple(shp_logit), int(min_count), bool(fp16),
+           None if n_groups is None else int(n_groups))
     return _RenderNetsFn.apply(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg)
 
 
@@ -454,6 +478,7 @@ class _CompositeFn(torch.autograd.Function):
                                     ptr(weights), ptr(sem), stream_ptr()), "dns_composite_fwd")
         ctx.save_for_backward(raw, z, logits)
         ctx.dims = (N, S, Cn)
+        ctx.set_materialize_grads(False)                  # unused outputs (var, weights, ...) arrive as None, not zeros
         if sem is None:
             sem = raw.new_zeros(N, 0)
         return depth, var, rgb, weights, sem
@@ -512,6 +537,7 @@ class _RaygenFn(torch.autograd.Function):
                                     ptr(inside), ptr(z), ptr(pts), stream_ptr()), "dns_raygen_sample")
         ctx.save_for_backward(pix_idx, quat, z)
         ctx.misc = (camv, window, K, npf, S)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(gt_color, gt_depth, gt_label, inside, z)
         return rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z
 

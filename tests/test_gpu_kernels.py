@@ -251,12 +251,14 @@ def test_mlp_fp16_mode(n_in, n_out, nn, nl):
     assert all(bool(torch.isfinite(t).all()) for t in den), "denormal-small output gradients produced inf / nan"
 
 
-@pytest.mark.parametrize("nn,nl,P", [(64, 2, 1500), (32, 1, 333)])
-def test_render_nets_two_segment_input_and_in_place_gradient_sums(nn, nl, P):
-    """ops.render_nets vs the oracle MLPs wired like Mapper.renderer (slams/mapping.py:616-626, models/decoder.py:
-    123-124): coarse(buf), per-class fine(buf), colour / logit(cat(pe, fine[:, 1:], pixel)).  Covers the two-segment
-    input of dns_mlp_fwd/bwd (48 | 64 columns), accumulate_dx bits 0 and 1, the grouped network adding into the same
-    input gradient, and the pixel-feature gradient."""
+@pytest.mark.parametrize("nn,nl,P,fine_used", [(64, 2, 1500, True), (32, 1, 333, True), (64, 2, 700, False)])
+def test_render_nets_two_segment_input_and_in_place_gradient_sums(nn, nl, P, fine_used):
+    """ops.render_nets vs the oracle MLPs wired like Mapper.renderer (slams/mapping.py:616-627, models/decoder.py:
+    123-124): coarse(buf), per-class fine(buf), colour / logit(cat(pe, fine[:, 1:], pixel)), raw = cat(sigmoid(colour),
+    fine[:, 0:1]).  Covers the two-segment input of dns_mlp_fwd/bwd (48 | 64 columns), accumulate_dx bits 0 and 1, the
+    grouped network adding into the same input gradient, the pixel-feature gradient, the colour network writing into
+    the [P, 4] compositing rows (ldy 4) and -- fine_used False: no loss on the latents, as in the tracker -- the fine
+    network's output gradient read as a strided view (lddy 68) of the feature-gradient buffer."""
     ops = _ops()
     g = torch.Generator().manual_seed(9)
     G, pe_dim, hid, C, n_class = 3, 48, 32, 32, 8
@@ -268,7 +270,10 @@ def test_render_nets_two_segment_input_and_in_place_gradient_sums(nn, nl, P):
     buf, pix = torch.randn(P, 80, generator=g), torch.randn(P, C, generator=g)
     slot = torch.randint(0, G, (P,), generator=g)
     slot[5] = -1
-    gw = [torch.randn(P, n, generator=g) for n in (hid + 1, hid + 1, 3, n_class)]
+    gw = [torch.randn(P, n, generator=g) for n in (hid + 1, hid + 1, 4, n_class)]
+    if not fine_used:
+        gw[1] = None
+    total = lambda outs, dev: sum((o * w.to(dev)).sum() for o, w in zip(outs, gw) if w is not None)
 
     # oracle wiring
     bo, xo = buf.clone().requires_grad_(True), pix.clone().requires_grad_(True)
@@ -280,14 +285,15 @@ def test_render_nets_two_segment_input_and_in_place_gradient_sums(nn, nl, P):
         if idx.numel() > 1:
             fine = fine.index_put((idx,), tr.mlp_forward(bo[idx], po[1][c], *shp_f))
     xin = torch.cat((bo[:, :pe_dim], fine[:, 1:], xo), -1)
-    outs_o = [coarse, fine, tr.mlp_forward(xin, po[2], *shp_col), tr.mlp_forward(xin, po[3], *shp_log)]
-    sum((o * w).sum() for o, w in zip(outs_o, gw)).backward()
+    raw = torch.cat((torch.sigmoid(tr.mlp_forward(xin, po[2], *shp_col)), fine[:, 0:1]), -1)
+    outs_o = [coarse, fine, raw, tr.mlp_forward(xin, po[3], *shp_log)]
+    total(outs_o, "cpu").backward()
 
     bp, xp = buf.to(DEV).requires_grad_(True), pix.to(DEV).requires_grad_(True)
     pp = [t.to(DEV).requires_grad_(True) for t in (cp, pool, colp, logp)]
     outs_p = ops.render_nets(bp, xp, pp[0], pp[1], pp[2], pp[3], slot.to(DEV), pe_dim, shp_c, shp_f, shp_col, shp_log)
-    sum((o * w.to(DEV)).sum() for o, w in zip(outs_p, gw)).backward()
-    for a, b, name in zip(outs_p, outs_o, ("coarse", "fine", "colour", "logit")):
+    total(outs_p, DEV).backward()
+    for a, b, name in zip(outs_p, outs_o, ("coarse", "fine", "raw", "logit")):
         assert_close(a.cpu(), b, what=f"render_nets {name}")
     assert_close(bp.grad.cpu(), bo.grad, what="render_nets d_buf")
     assert_close(xp.grad.cpu(), xo.grad, what="render_nets d_pixel")
