@@ -292,6 +292,19 @@ def main():
                 roofline["traffic_source"] = pmc["source"]
         except Exception:
             pass
+    # whole-iteration rooflines of SURVEY 8d (per ray-sample and per GPU): HBM with the algorithmic 1024 B gathered + 2048 B
+    # scattered + the 12-byte point, fp32 MFMA with 3 x the forward flops of the four render networks
+    nn_, nl_ = wl["nn"], wl["nl"]
+    macs_ = lambda n_in, n_out: n_in * nn_ + (nl_ - 1) * nn_ * nn_ + nn_ * n_out
+    flops_sample = 3 * 2 * (2 * macs_(80, 33) + macs_(112, 3) + macs_(112, 8))
+    bytes_sample = 3 * 16 * 8 * 2 * 4 + 12
+    per_gpu = value / ctx.world_size
+    iteration_roofline = {
+        "hbm": {"bytes_per_ray_sample": bytes_sample, "achieved": per_gpu * bytes_sample / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": per_gpu * bytes_sample / 1e9 / HBM_PEAK_GBS},
+        "mfma": {"flops_per_ray_sample": flops_sample, "achieved": per_gpu * flops_sample / 1e12,
+                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per_gpu * flops_sample / 1e12 / F32_MFMA_PEAK_TFLOPS},
+        "note": "per GPU, whole mapping iteration incl. the smoothness lattice, losses and Adam (not counted in the numerators)"}
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -299,6 +312,7 @@ def main():
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
                    "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
         "roofline": roofline,
+        "iteration_roofline": iteration_roofline,
         "kernel_breakdown": breakdown,
     }
     # secondary line: forward-only full-image render of one 640x480 frame (frame_vis path), rays/s
