@@ -588,3 +588,50 @@ def test_optimize_driver_and_decoder_init():
     assert all(float(v) == float(v) for v in terms1.values())
     assert not torch.equal(fr["est_c2w"][1], frames["est_c2w"][1])      # BA pose write-back (idx >= start_optimize_idx)
     assert torch.equal(fr["est_c2w"][0], frames["est_c2w"][0])          # the oldest frame stays fixed (:457)
+
+
+def test_optimise_trajectory_matches_oracle_adam():
+    """Five complete optimise iterations (sample -> render -> seven losses -> backward -> Adam on grid, every network, the
+    per-class fine decoders and the poses of frames 1-3; slams/mapping.py:868-911) of the HIP path with its fused Adam
+    against the oracle stepped by torch.optim.Adam on the SAME pixel / jitter / lattice draws: the loss of every
+    iteration within 1e-4 relative -- iteration k sees the parameters k updates produced -- and the poses after the run.
+    Parameters themselves are compared through the loss: an element whose gradient is rounding noise moves by +-lr under
+    Adam's normalisation in either implementation."""
+    cfg, bound, cam, frames, dec, mapper = _setup(64, 2)
+    mapper.is_BA = True
+    opt, ql, Tl = mapper.set_optimizer(frames, fused=True)
+    lr, cam_lr = 2e-3, 1e-3
+    for grp, v in zip(opt.param_groups, (lr, cam_lr, cam_lr)):
+        grp["lr"] = v
+    prep = mapper.prepare_frames(frames)
+
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    qo = [q.detach().cpu().clone().requires_grad_(q.requires_grad) for q in ql]
+    To = [t.detach().cpu().clone().requires_grad_(t.requires_grad) for t in Tl]
+    opt_o = torch.optim.Adam([{"params": [om.table, om.coarse, om.color, om.logit] + list(om.fine.values()), "lr": lr},
+                              {"params": qo[1:], "lr": cam_lr}, {"params": To[1:], "lr": cam_lr}])
+    lc = sr.LossCfg(smooth_pts=cfg["training"]["smooth_pts"])
+    for it in range(5):
+        torch.manual_seed(100 + it)
+        pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+        g = torch.Generator().manual_seed(200 + it)
+        u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+
+        opt.zero_grad()
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
+        loss, _ = mapper.iteration_loss(s, lambda_lt=10.0, smooth=True, u_offset=u_off, u_jitter=u_jit, strict=True)
+        loss.backward()
+        opt.step()
+
+        opt_o.zero_grad()
+        npf = pix.numel() // 4
+        so = _oracle_samples(frames, qo, To, cam, bound, pix.cpu(), (jit[0].cpu(), jit[1].cpu()), npf, 32, 15)
+        so["features"] = torch.zeros(so["z_vals"].shape[0], so["z_vals"].shape[1], 32)
+        lo, _, _ = sr.mapping_loss(om, so, lc, u_off, u_jit, label_layout="reference_tiled")
+        lo.backward()
+        opt_o.step()
+        a, b = float(loss.detach()), float(lo.detach())
+        assert abs(a - b) <= 1e-4 * abs(b), f"iteration {it}: {a} vs {b}"
+    for f in range(1, 4):
+        assert_close(ql[f].detach().cpu(), qo[f].detach(), rtol=1e-4, what=f"quat[{f}] after 5 steps")
+        assert_close(Tl[f].detach().cpu(), To[f].detach(), rtol=1e-4, what=f"T[{f}] after 5 steps")
