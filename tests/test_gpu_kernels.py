@@ -525,3 +525,48 @@ def test_group_slots_layout():
             assert int(tg[t]) == (int(grp) if int((slot == int(grp)).sum()) >= 2 else -1)
         else:
             assert int(tg[t]) == -1 or int((slot == int(tg[t])).sum()) >= 2
+
+
+# ----------------------------------------------------------------------------------------- degenerate sizes, argument errors
+def test_empty_batches_and_argument_errors():
+    """Zero points / rays / slots pass through every op (empty outputs, zero parameter gradients, no launch fault), a
+    batch whose points all miss a fine decoder gives zeros, and malformed arguments come back as an error code with a
+    message from dns_last_error -- nothing is launched on bad shapes (the reference's tcnn modules raise likewise)."""
+    ops = _ops()
+    from dns_slam_amd import _lib
+    lib = _lib.lib
+    m = ops.GridMeta(12, 64)
+    table = torch.rand(m.total_rows * 2, device=DEV, requires_grad=True)
+    # P = 0
+    y = ops.encode(torch.empty(0, 3, device=DEV), table, m, None, 16, True, True)
+    assert y.shape == (0, 48 + 2 * m.n_levels)
+    y.sum().backward()
+    assert table.grad is not None and float(table.grad.abs().max()) == 0.0
+    w = (torch.randn(ops.mlp_param_count(80, 33, 64, 2), device=DEV) * 0.1).requires_grad_(True)
+    out = ops.mlp(torch.empty(0, 80, device=DEV), w, 80, 33, 64, 2)
+    assert out.shape == (0, 33)
+    out.sum().backward()
+    assert float(w.grad.abs().max()) == 0.0
+    # one point (a single ragged tile), and a grouped call where no point has a network
+    x1 = torch.randn(1, 80, device=DEV)
+    assert_close(ops.mlp(x1, w.detach(), 80, 33, 64, 2).cpu(), tr.mlp_forward(x1.cpu(), w.detach().cpu(), 80, 33, 64, 2),
+                 what="one-point MLP")
+    pool = torch.randn(3, ops.mlp_param_count(80, 33, 64, 2), device=DEV) * 0.1
+    none = ops.mlp_grouped(torch.randn(200, 80, device=DEV), pool, torch.full((200,), -1, device=DEV, dtype=torch.int64),
+                           80, 33, 64, 2)
+    assert none.shape == (200, 33) and float(none.abs().max()) == 0.0
+    # N = 0 rays
+    d, v, rgb, wts, sem = ops.composite(torch.empty(0, 64, 4, device=DEV), torch.empty(0, 64, device=DEV),
+                                        torch.empty(0, 64, 8, device=DEV))
+    assert d.shape == (0,) and rgb.shape == (0, 3) and wts.shape == (0, 64) and sem.shape == (0, 8)
+    # argument errors: unsupported width, misaligned two-segment input, a level table that does not fit
+    x = torch.randn(256, 80, device=DEV)
+    yb = torch.empty(256, 33, device=DEV)
+    p = lambda t: _lib.ptr(t)
+    rc = lib.dns_mlp_fwd(p(x), 80, None, 0, 0, p(w), 80, 33, 48, 2, p(yb), 33, 256, None, None, 0, None, 0, None)
+    assert rc != 0 and b"unsupported shape" in lib.dns_last_error()
+    rc = lib.dns_mlp_fwd(p(x), 80, p(x[:, 1:]), 80, 48, p(w), 80, 33, 64, 2, p(yb), 33, 256, None, None, 0, None, 0, None)
+    assert rc != 0 and b"x2 must be 16-byte aligned" in lib.dns_last_error()
+    rc = lib.dns_mlp_fwd(p(x), 80, None, 0, 0, p(w), 80, 33, 64, 2, p(yb), 16, 256, None, None, 0, None, 0, None)
+    assert rc != 0 and b"ldy" in lib.dns_last_error()
+    torch.cuda.synchronize()                         # nothing faulted
