@@ -1284,7 +1284,7 @@ struct GemmRoles {
 // The loop body is branch-free around its loads on purpose: every load is unconditional on a clamped address (and
 // the A operand zeroed at use when the point is not real), so the compiler's vmcnt bookkeeping keeps D steps of data
 // loads plus the NEXT round's index loads in flight instead of draining the queue at a conditional.
-template <bool AIDX, bool BIDX, bool AVEC>
+template <bool AIDX, bool BIDX, bool AVEC, bool BLOCKRED = false>
 __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slots, uint32_t bt0, uint32_t tstride, uint32_t ntl,
                                               const int* __restrict__ grp_lds, float* __restrict__ wlds, uint32_t c_stride) {
   constexpr int D = 8;                       // load steps in flight (measured: 8 beats 4 and 2 here, 263 vs 283 us)
@@ -1360,7 +1360,11 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
     __builtin_amdgcn_wave_barrier();
     float* C = u.C + (size_t)grp * c_stride;
     const uint32_t col = lane, cb = col & 3u, j = col >> 2;
-    for (uint32_t row = 0; row < M; ++row) {
+    // every wave of a unit adds into the same M rows when the launch ends: start each wave at its own row so that
+    // the 2 x 256 waves spread over all rows at any moment instead of queueing on the same addresses
+    const uint32_t rot = (blockIdx.x * 29u) % M;
+    for (uint32_t r0 = 0; r0 < M; ++r0) {
+      const uint32_t row = r0 + rot < M ? r0 + rot : r0 + rot - M;
       const uint32_t ca = row & 3u, i = row >> 2;
       const float v = wlds[(((ca * 4u + cb) * 64u + (i >> 2) * 16u + j) * 4u) + (i & 3u)];
       if (col < N && v != 0.f) atomicAdd(C + (size_t)row * u.ldc + col, v);
@@ -1410,7 +1414,15 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
   }
-  flush(cur);
+  if (BLOCKRED) {                            // one weight set: the workgroup adds its four waves' blocks up before the atomics
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        reinterpret_cast<float4*>(wlds)[(a * 4 + b) * 64 + lane] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+  } else {
+    flush(cur);
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_roles_kernel(GemmRoles r) {
@@ -1437,6 +1449,51 @@ __global__ __launch_bounds__(256, 2) void gemm_roles_kernel(GemmRoles r) {
     case 0: gemm_unit_run<false, false, false>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
     case 1: gemm_unit_run<true, false, false>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
     default: break;                          // host never launches other kinds
+  }
+}
+
+// One weight set (every launch but the per-class fine decoders): a workgroup's four waves work on the SAME unit, each on
+// its own tiles (wave gw of the unit takes tiles gw, gw + n_gw, ... -- the dealing of gemm_roles_kernel with one wave per
+// unit and workgroup), and their four 64x64 blocks are added in LDS before the global atomics: 4x fewer of them.  The
+// atomics were 25-34 us of a 133 us launch (measured by compiling them out): 2048 waves x 4096 lane-atomics on 13 k
+// addresses shared by every wave of a unit, all issued when the launch ends.
+constexpr uint32_t GEMM_UNIT_WAVES = 4;     // waves of a workgroup that share a unit (8: one 128 KB workgroup per CU, no faster)
+__global__ __launch_bounds__(64 * GEMM_UNIT_WAVES, 2) void gemm_units_kernel(GemmRoles r) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* grp_lds = reinterpret_cast<int*>(lds);
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n_btiles = (r.n_slots + 127u) / 128u;
+  const uint32_t unit = blockIdx.x % r.n_units, ub = blockIdx.x / r.n_units;
+  const uint32_t n_gw = (gridDim.x / r.n_units) * GEMM_UNIT_WAVES;              // waves per unit
+  const uint32_t gw = ub * GEMM_UNIT_WAVES + wave;
+  const uint32_t ntl = gw < n_btiles ? (n_btiles - gw + n_gw - 1u) / n_gw : 0u;
+  for (uint32_t t = threadIdx.x; t < GEMM_MAX_TPB; t += blockDim.x) grp_lds[t] = 0;
+  __syncthreads();
+  const GemmUnit& u = r.u[unit];
+  float* wl = lds + GEMM_MAX_TPB;
+  float* wlds = wl + wave * 4096u;
+  switch (u.kind) {                          // uniform per workgroup
+    case 4: gemm_unit_run<false, false, true, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
+    case 6: gemm_unit_run<false, true, true, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
+    case 5: gemm_unit_run<true, false, true, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
+    case 0: gemm_unit_run<false, false, false, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
+    case 1: gemm_unit_run<true, false, false, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
+    default: break;
+  }
+  __syncthreads();
+  // D tile (ca, cb), lane (i>>2)*16 + j, register i&3 holds dW[4i+ca][4j+cb]; rows start at a per-workgroup offset so
+  // that the workgroups of a unit do not queue on the same addresses
+  const uint32_t M = u.M, N = u.N;
+  const uint32_t col = threadIdx.x & 63u, cb = col & 3u, j = col >> 2;
+  const uint32_t rot = (ub * 29u) % M;
+  for (uint32_t r0 = threadIdx.x >> 6; r0 < M; r0 += GEMM_UNIT_WAVES) {
+    const uint32_t row = r0 + rot < M ? r0 + rot : r0 + rot - M;
+    const uint32_t ca = row & 3u, i = row >> 2;
+    const uint32_t idx = (((ca * 4u + cb) * 64u + (i >> 2) * 16u + j) * 4u) + (i & 3u);
+    float v = 0.f;
+#pragma unroll
+    for (uint32_t w = 0; w < GEMM_UNIT_WAVES; ++w) v += wl[w * 4096u + idx];
+    if (col < N && v != 0.f) atomicAdd(u.C + (size_t)row * u.ldc + col, v);
   }
 }
 
@@ -1652,8 +1709,23 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
     nb = (n_btiles + roles.tiles_per_block - 1) / roles.tiles_per_block;
     static const char* order_env = getenv("DNS_GEMM_ORDER");     // 'c' contiguous / 's' strided, for A/B
     roles.strided = order_env ? (order_env[0] == 's') : (roles.tile_group == nullptr);
-    const size_t roles_lds = (GEMM_MAX_TPB + (size_t)roles.n_units * 4096) * sizeof(float);
-    hipLaunchKernelGGL(gemm_roles_kernel, dim3(nb), dim3(64 * roles.n_units), roles_lds, st, roles);
+    static const char* form_env = getenv("DNS_GEMM_FORM");        // 'w': one unit per wave everywhere (A/B)
+    if (roles.tile_group == nullptr && roles.strided && !(form_env && form_env[0] == 'w')) {
+      // one weight set: four waves of a workgroup share a unit and reduce in LDS (nb = waves per unit, as above)
+      uint32_t nbu = (nb + GEMM_UNIT_WAVES - 1u) / GEMM_UNIT_WAVES;
+      const uint32_t nbu_min = (n_btiles + GEMM_UNIT_WAVES * GEMM_MAX_TPB - 1) / (GEMM_UNIT_WAVES * GEMM_MAX_TPB);
+      if (nbu < nbu_min) nbu = nbu_min;
+      const size_t units_lds = (GEMM_MAX_TPB + (size_t)GEMM_UNIT_WAVES * 4096) * sizeof(float);
+      static bool units_attr = false;
+      if (!units_attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_units_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)units_lds);
+        units_attr = true;
+      }
+      hipLaunchKernelGGL(gemm_units_kernel, dim3(nbu * roles.n_units), dim3(64 * GEMM_UNIT_WAVES), units_lds, st, roles);
+    } else {
+      const size_t roles_lds = (GEMM_MAX_TPB + (size_t)roles.n_units * 4096) * sizeof(float);
+      hipLaunchKernelGGL(gemm_roles_kernel, dim3(nb), dim3(64 * roles.n_units), roles_lds, st, roles);
+    }
   }
   return check_launch("dns_mlp_bwd(weights)");
 }
