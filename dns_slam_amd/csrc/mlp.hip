@@ -1460,40 +1460,65 @@ __global__ __launch_bounds__(256, 2) void gemm_roles_kernel(GemmRoles r) {
 constexpr uint32_t GEMM_UNIT_WAVES = 4;     // waves of a workgroup that share a unit (8: one 128 KB workgroup per CU, no faster)
 __global__ __launch_bounds__(64 * GEMM_UNIT_WAVES, 2) void gemm_units_kernel(GemmRoles r) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  int* grp_lds = reinterpret_cast<int*>(lds);
+  int* live_lds = reinterpret_cast<int*>(lds);                     // all zero: every tile handed to a wave is live
+  int* tg = live_lds + GEMM_MAX_TPB;                               // weight-set ids of this workgroup's tile range
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t n_btiles = (r.n_slots + 127u) / 128u;
   const uint32_t unit = blockIdx.x % r.n_units, ub = blockIdx.x / r.n_units;
-  const uint32_t n_gw = (gridDim.x / r.n_units) * GEMM_UNIT_WAVES;              // waves per unit
-  const uint32_t gw = ub * GEMM_UNIT_WAVES + wave;
-  const uint32_t ntl = gw < n_btiles ? (n_btiles - gw + n_gw - 1u) / n_gw : 0u;
-  for (uint32_t t = threadIdx.x; t < GEMM_MAX_TPB; t += blockDim.x) grp_lds[t] = 0;
-  __syncthreads();
+  const uint32_t nbu = gridDim.x / r.n_units;
   const GemmUnit& u = r.u[unit];
-  float* wl = lds + GEMM_MAX_TPB;
+  float* wl = lds + 2u * GEMM_MAX_TPB;
   float* wlds = wl + wave * 4096u;
-  switch (u.kind) {                          // uniform per workgroup
-    case 4: gemm_unit_run<false, false, true, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
-    case 6: gemm_unit_run<false, true, true, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
-    case 5: gemm_unit_run<true, false, true, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
-    case 0: gemm_unit_run<false, false, false, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
-    case 1: gemm_unit_run<true, false, false, true>(u, r.n_slots, gw, n_gw, ntl, grp_lds, wlds, r.c_stride); break;
-    default: break;
+  // per-class launch: contiguous tile range (few weight sets per workgroup); one weight set: the whole launch is one run
+  const bool grouped = r.tile_group != nullptr;
+  const uint32_t t_lo = grouped ? ub * r.tiles_per_block : 0u;
+  const uint32_t t_hi = grouped ? min(t_lo + r.tiles_per_block, n_btiles) : n_btiles;
+  for (uint32_t t = threadIdx.x; t < GEMM_MAX_TPB; t += blockDim.x) {
+    live_lds[t] = 0;
+    tg[t] = (grouped && t_lo + t < t_hi) ? r.tile_group[t_lo + t] : 0;
   }
   __syncthreads();
-  // D tile (ca, cb), lane (i>>2)*16 + j, register i&3 holds dW[4i+ca][4j+cb]; rows start at a per-workgroup offset so
-  // that the workgroups of a unit do not queue on the same addresses
   const uint32_t M = u.M, N = u.N;
   const uint32_t col = threadIdx.x & 63u, cb = col & 3u, j = col >> 2;
   const uint32_t rot = (ub * 29u) % M;
-  for (uint32_t r0 = threadIdx.x >> 6; r0 < M; r0 += GEMM_UNIT_WAVES) {
-    const uint32_t row = r0 + rot < M ? r0 + rot : r0 + rot - M;
-    const uint32_t ca = row & 3u, i = row >> 2;
-    const uint32_t idx = (((ca * 4u + cb) * 64u + (i >> 2) * 16u + j) * 4u) + (i & 3u);
-    float v = 0.f;
+  uint32_t s0 = t_lo;
+  while (s0 < t_hi) {                          // runs of one weight set (uniform over the workgroup)
+    int g = 0;
+    uint32_t s1 = t_hi;
+    if (grouped) {
+      g = tg[s0 - t_lo];
+      s1 = s0 + 1u;
+      while (s1 < t_hi && tg[s1 - t_lo] == g) ++s1;
+    }
+    if (g >= 0) {
+      // wave w of the run: tiles first, first + stride, ...  (one weight set: wave gw of the unit's nbu * W waves)
+      const uint32_t stride = grouped ? GEMM_UNIT_WAVES : nbu * GEMM_UNIT_WAVES;
+      const uint32_t first = grouped ? s0 + wave : ub * GEMM_UNIT_WAVES + wave;
+      const uint32_t ntl = first < s1 ? (s1 - first + stride - 1u) / stride : 0u;
+      switch (u.kind) {                        // uniform per workgroup
+        case 4: gemm_unit_run<false, false, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
+        case 6: gemm_unit_run<false, true, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
+        case 5: gemm_unit_run<true, false, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
+        case 0: gemm_unit_run<false, false, false, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
+        case 1: gemm_unit_run<true, false, false, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
+        default: break;
+      }
+      __syncthreads();
+      // D tile (ca, cb), lane (i>>2)*16 + j, register i&3 holds dW[4i+ca][4j+cb]; rows start at a per-workgroup offset
+      // so that the workgroups of a unit do not queue on the same addresses
+      float* C = u.C + (size_t)g * r.c_stride;
+      for (uint32_t r0 = threadIdx.x >> 6; r0 < M; r0 += GEMM_UNIT_WAVES) {
+        const uint32_t row = r0 + rot < M ? r0 + rot : r0 + rot - M;
+        const uint32_t ca = row & 3u, i = row >> 2;
+        const uint32_t idx = (((ca * 4u + cb) * 64u + (i >> 2) * 16u + j) * 4u) + (i & 3u);
+        float v = 0.f;
 #pragma unroll
-    for (uint32_t w = 0; w < GEMM_UNIT_WAVES; ++w) v += wl[w * 4096u + idx];
-    if (col < N && v != 0.f) atomicAdd(u.C + (size_t)row * u.ldc + col, v);
+        for (uint32_t w = 0; w < GEMM_UNIT_WAVES; ++w) v += wl[w * 4096u + idx];
+        if (col < N && v != 0.f) atomicAdd(C + (size_t)row * u.ldc + col, v);
+      }
+      __syncthreads();
+    }
+    s0 = s1;
   }
 }
 
@@ -1709,13 +1734,16 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
     nb = (n_btiles + roles.tiles_per_block - 1) / roles.tiles_per_block;
     static const char* order_env = getenv("DNS_GEMM_ORDER");     // 'c' contiguous / 's' strided, for A/B
     roles.strided = order_env ? (order_env[0] == 's') : (roles.tile_group == nullptr);
-    static const char* form_env = getenv("DNS_GEMM_FORM");        // 'w': one unit per wave everywhere (A/B)
-    if (roles.tile_group == nullptr && roles.strided && !(form_env && form_env[0] == 'w')) {
-      // one weight set: four waves of a workgroup share a unit and reduce in LDS (nb = waves per unit, as above)
+    static const char* form_env = getenv("DNS_GEMM_FORM");        // 'w': one unit per wave (the earlier form, for A/B)
+    if (!(form_env && form_env[0] == 'w')) {
+      // GEMM_UNIT_WAVES waves of a workgroup share a unit and reduce in LDS (nb = waves per unit, as above)
       uint32_t nbu = (nb + GEMM_UNIT_WAVES - 1u) / GEMM_UNIT_WAVES;
-      const uint32_t nbu_min = (n_btiles + GEMM_UNIT_WAVES * GEMM_MAX_TPB - 1) / (GEMM_UNIT_WAVES * GEMM_MAX_TPB);
+      const uint32_t nbu_min = roles.tile_group ? (n_btiles + GEMM_MAX_TPB - 1) / GEMM_MAX_TPB
+                                                : (n_btiles + GEMM_UNIT_WAVES * GEMM_MAX_TPB - 1) / (GEMM_UNIT_WAVES * GEMM_MAX_TPB);
       if (nbu < nbu_min) nbu = nbu_min;
-      const size_t units_lds = (GEMM_MAX_TPB + (size_t)GEMM_UNIT_WAVES * 4096) * sizeof(float);
+      if (nbu < 1) nbu = 1;
+      roles.tiles_per_block = (n_btiles + nbu - 1) / nbu;          // per-class launch: contiguous tile range per workgroup
+      const size_t units_lds = (2 * GEMM_MAX_TPB + (size_t)GEMM_UNIT_WAVES * 4096) * sizeof(float);
       static bool units_attr = false;
       if (!units_attr) {
         (void)hipFuncSetAttribute((const void*)gemm_units_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)units_lds);

@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, workload, tag = sys.argv[1:5]
 ENTRY = {  # C-ABI entry point -> kernels it launches
-    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_data_kernel", "gemm_tn_kernel", "gemm_roles_kernel"],
+    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_data_kernel", "gemm_tn_kernel", "gemm_roles_kernel", "gemm_units_kernel"],
     "dns_encode_fwd": ["encode_fwd_kernel"], "dns_encode_bwd": ["encode_bwd_kernel", "dgrid_transpose_kernel", "hashgrid_bwd_binned_kernel"],
     "dns_composite_fwd": ["composite_fwd_kernel"], "dns_composite_bwd": ["composite_bwd_kernel"],
     "dns_loss_sums": ["loss_ray_sums_kernel", "loss_point_sums_kernel"], "dns_loss_bwd": ["loss_ray_bwd_kernel", "loss_point_bwd_kernel"],
