@@ -1286,7 +1286,10 @@ struct GemmRoles {
 // loads plus the NEXT round's index loads in flight instead of draining the queue at a conditional.
 template <bool AIDX, bool BIDX, bool AVEC, bool BLOCKRED = false>
 __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slots, uint32_t bt0, uint32_t tstride, uint32_t ntl,
-                                              const int* __restrict__ grp_lds, float* __restrict__ wlds, uint32_t c_stride) {
+                                              const int* __restrict__ grp_lds, float* __restrict__ wlds, uint32_t c_stride,
+                                              uint32_t sshift = 5u, uint32_t soff = 0u) {
+  // sshift / soff: this wave's share of a tile's 32 steps -- all of them (5, 0), or the 8 steps [soff, soff + 8) of EVERY
+  // tile (3, 8 * wave): the waves of a workgroup then split each tile and carry exactly the same load (per-class launch)
   constexpr int D = 8;                       // load steps in flight (measured: 8 beats 4 and 2 here, 263 vs 283 us)
   const uint32_t lane = threadIdx.x & 63u;
   const float* __restrict__ A = u.A;
@@ -1294,7 +1297,8 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
   const int32_t* __restrict__ ai = u.a_index;
   const int32_t* __restrict__ bi = u.b_index;
   const uint32_t lda = u.lda, ldb = u.ldb, M = u.M, N = u.N;
-  const uint32_t nsteps = ntl * 32u;         // 32 steps of 4 points per 128-slot tile
+  const uint32_t nsteps = ntl << sshift;     // 32 (or 8) steps of 4 points per 128-slot tile
+  const uint32_t smask = (1u << sshift) - 1u;
   const uint32_t k = lane >> 4, c4 = 4u * (lane & 15u);
   // Columns past M / N are CLAMPED, not zeroed: D[i][j] depends on A row i and B column j only, so whatever such a lane
   // reads lands in output rows >= M / columns >= N, which the flush never writes.  Invalid POINTS (K axis: padding
@@ -1314,9 +1318,9 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
   bool rv[D];                                // this lane's point of the step is real
   // liveness of a step's tile is looked up ONCE per group of D steps (D divides 32: a group never straddles tiles): a
   // per-step LDS read + s_waitcnt lgkmcnt(0) would put an LDS round trip into every 16-MFMA step of the in-order stream
-  auto tile_live = [&](uint32_t q) -> bool { return q < nsteps && grp_lds[min(q >> 5, ntl - 1u)] >= 0; };   // uniform
+  auto tile_live = [&](uint32_t q) -> bool { return q < nsteps && grp_lds[min(q >> sshift, ntl - 1u)] >= 0; };   // uniform
   auto slot_ok = [&](uint32_t q, bool live, uint32_t& slot) -> bool {
-    slot = (bt0 + (q >> 5) * tstride) * 128u + (q & 31u) * 4u + k;
+    slot = (bt0 + (q >> sshift) * tstride) * 128u + ((q & smask) + soff) * 4u + k;
     return live && slot < n_slots;
   };
   auto issue_idx = [&](int& xa, int& xb, uint32_t q, bool live) {
@@ -1391,8 +1395,8 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
   int cur = -2;
   for (uint32_t q0 = 0; q0 < nsteps; q0 += D) {
     const bool live_d = tile_live(q0 + D), live_i = tile_live(q0 + 2 * D);
-    if ((q0 & 31u) == 0) {
-      const int grp = grp_lds[q0 >> 5];
+    if ((q0 & smask) == 0) {
+      const int grp = grp_lds[q0 >> sshift];
       if (grp >= 0 && grp != cur) {
         flush(cur);
         cur = grp;
@@ -1492,15 +1496,19 @@ __global__ __launch_bounds__(64 * GEMM_UNIT_WAVES, 2) void gemm_units_kernel(Gem
     }
     if (g >= 0) {
       // wave w of the run: tiles first, first + stride, ...  (one weight set: wave gw of the unit's nbu * W waves)
-      const uint32_t stride = grouped ? GEMM_UNIT_WAVES : nbu * GEMM_UNIT_WAVES;
-      const uint32_t first = grouped ? s0 + wave : ub * GEMM_UNIT_WAVES + wave;
+      // one weight set: wave gw of the unit's nbu * W waves takes tiles gw, gw + nbu * W, ...; per-class launch: every
+      // wave takes 8 of the 32 steps of each tile of the run, so the waves of a workgroup finish together
+      const uint32_t stride = grouped ? 1u : nbu * GEMM_UNIT_WAVES;
+      const uint32_t first = grouped ? s0 : ub * GEMM_UNIT_WAVES + wave;
       const uint32_t ntl = first < s1 ? (s1 - first + stride - 1u) / stride : 0u;
+      const uint32_t sshift = grouped ? 3u : 5u, soff = grouped ? 8u * wave : 0u;
+      static_assert(GEMM_UNIT_WAVES == 4, "the per-class split gives each of 4 waves 8 of a tile's 32 steps");
       switch (u.kind) {                        // uniform per workgroup
-        case 4: gemm_unit_run<false, false, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
-        case 6: gemm_unit_run<false, true, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
-        case 5: gemm_unit_run<true, false, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
-        case 0: gemm_unit_run<false, false, false, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
-        case 1: gemm_unit_run<true, false, false, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride); break;
+        case 4: gemm_unit_run<false, false, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride, sshift, soff); break;
+        case 6: gemm_unit_run<false, true, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride, sshift, soff); break;
+        case 5: gemm_unit_run<true, false, true, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride, sshift, soff); break;
+        case 0: gemm_unit_run<false, false, false, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride, sshift, soff); break;
+        case 1: gemm_unit_run<true, false, false, true>(u, r.n_slots, first, stride, ntl, live_lds, wlds, r.c_stride, sshift, soff); break;
         default: break;
       }
       __syncthreads();
@@ -1737,7 +1745,9 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
     static const char* form_env = getenv("DNS_GEMM_FORM");        // 'w': one unit per wave (the earlier form, for A/B)
     if (!(form_env && form_env[0] == 'w')) {
       // GEMM_UNIT_WAVES waves of a workgroup share a unit and reduce in LDS (nb = waves per unit, as above)
-      uint32_t nbu = (nb + GEMM_UNIT_WAVES - 1u) / GEMM_UNIT_WAVES;
+      const uint32_t nb_req = gb_env ? (uint32_t)atoi(gb_env) : 512u;
+      uint32_t nbu = ((roles.tile_group ? nb_req : nb) + GEMM_UNIT_WAVES - 1u) / GEMM_UNIT_WAVES;
+      if (nbu > n_btiles) nbu = n_btiles;
       const uint32_t nbu_min = roles.tile_group ? (n_btiles + GEMM_MAX_TPB - 1) / GEMM_MAX_TPB
                                                 : (n_btiles + GEMM_UNIT_WAVES * GEMM_MAX_TPB - 1) / (GEMM_UNIT_WAVES * GEMM_MAX_TPB);
       if (nbu < nbu_min) nbu = nbu_min;
