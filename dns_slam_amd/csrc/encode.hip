@@ -170,25 +170,33 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
                                                          float* __restrict__ d_table, float* __restrict__ d_x) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t pe_dim = 3 * n_bins;
-  const uint32_t ldt = ld_dpe + 1;
-  if (TILED) {
+  const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
+  // TILED: the workgroup's gradient rows come in through an LDS tile (coalesced row reads instead of one 320-byte-strided
+  // row per lane), in TWO phases like the forward -- OneBlob columns, then grid columns -- so that the tile holds
+  // max(pe_dim, g_dim) + 1 floats per point (25 KB, 12 waves per CU) instead of the whole row (41 KB, 6 waves): this
+  // kernel is latency-bound (dependent LDS reads, 8-byte gathers), occupancy is what it lacked.
+  const uint32_t ldt = max(pe_dim, g_dim) + 1;
+  const bool live = p < P;
+  auto stage = [&](uint32_t col0, uint32_t nc) {         // columns [col0, col0 + nc) of the workgroup's rows -> tile
+    __syncthreads();
     const uint32_t p0 = blockIdx.x * blockDim.x;
     const uint32_t rows = min(blockDim.x, P - p0);
-    const float* src = d_pe + (size_t)p0 * ld_dpe;
-    for (uint32_t i = threadIdx.x; i < rows * ld_dpe; i += blockDim.x) {
-      const uint32_t r = i / ld_dpe, c = i - r * ld_dpe;
-      tile[r * ldt + c] = src[i];
+    const float* src = d_pe + (size_t)p0 * ld_dpe + col0;
+    for (uint32_t i = threadIdx.x; i < rows * nc; i += blockDim.x) {
+      const uint32_t r = i / nc, c = i - r * nc;
+      tile[r * ldt + c] = src[(size_t)r * ld_dpe + c];
     }
     __syncthreads();
+  };
+  float x[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    x[0] = xin[(size_t)p * 3 + 0];
+    x[1] = xin[(size_t)p * 3 + 1];
+    x[2] = xin[(size_t)p * 3 + 2];
   }
-  if (p >= P) return;
-  float x[3];
-  x[0] = xin[(size_t)p * 3 + 0];
-  x[1] = xin[(size_t)p * 3 + 1];
-  x[2] = xin[(size_t)p * 3 + 2];
+  if (TILED) stage(0, pe_dim);
   float dx[3] = {0.f, 0.f, 0.f};
-  if (d_pe && d_x) {
+  if (live && d_pe && d_x) {
     const float n = (float)n_bins;
     const float* row = TILED ? tile + threadIdx.x * ldt : d_pe + (size_t)p * ld_dpe;
 #pragma unroll
@@ -210,8 +218,9 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
       dx[a] += acc;
     }
   }
-  if (d_grid) {
-    const float* row = TILED ? tile + threadIdx.x * ldt + pe_dim : d_grid + (size_t)p * ld_dgrid;
+  if (TILED) stage(pe_dim, g_dim);
+  if (live && d_grid) {
+    const float* row = TILED ? tile + threadIdx.x * ldt : d_grid + (size_t)p * ld_dgrid;
 #pragma unroll 2
     for (uint32_t l = 0; l < lv.n_levels; ++l) {
       const float g0 = row[2 * l], g1 = row[2 * l + 1];
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
       }
     }
   }
-  if (d_x) {
+  if (live && d_x) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       float v = dx[a];
@@ -813,7 +822,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     const bool tiled = d_pe && d_grid && d_x && ld_dpe == ld_dgrid && d_grid == d_pe + 3 * n_bins &&
                        ld_dpe == 3 * n_bins + 2 * lv.n_levels;
     if (tiled) {
-      hipLaunchKernelGGL(encode_bwd_kernel<true>, dim3(blocks128), dim3(128), (size_t)128 * (ld_dpe + 1) * sizeof(float), st, x,
+      hipLaunchKernelGGL(encode_bwd_kernel<true>, dim3(blocks128), dim3(128),
+                         (size_t)128 * ((3 * n_bins > 2 * lv.n_levels ? 3 * n_bins : 2 * lv.n_levels) + 1) * sizeof(float), st, x,
                          make_bound(bound), bound ? 1 : 0, P, n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid,
                          d_table_direct, d_x);
     } else {
