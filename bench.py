@@ -77,6 +77,8 @@ def build(wl, device, seed, dist_ctx, overlap=False):
     mapper.is_BA = True
     mapper.static_shapes = True                              # sync-free iteration: capturable in a hipGraph
     mapper.overlap_smooth = overlap
+    # the next iteration's pixel / jitter / lattice draws are enqueued on the side stream (same generator order)
+    mapper.prefetch_draws = overlap and os.environ.get("DNS_PREFETCH_DRAWS", "1") != "0"
     mapper.set_decoder(frames)
     optimizer, quad_list, T_list = mapper.set_optimizer(frames, fused=True)     # csrc/adam.hip: one launch, step count on device
     for grp, lr in zip(optimizer.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):

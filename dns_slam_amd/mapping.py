@@ -163,7 +163,11 @@ class Mapper:
                 d = bd[:, 1] - bd[:, 0]
                 self._lattice_consts = (key, voxel_size / d, self._offset_max / d, margin / d)
             _, c_vox, c_off, c_mar = self._lattice_consts
-            r = torch.rand(6, device=self.device).to(torch.float64)            # [offset(3) | jitter(3)], as float32 draws
+            r = getattr(self, "_lattice_r6", None) if getattr(self, "prefetch_draws", False) else None
+            self._lattice_r6 = None
+            if r is None:
+                r = torch.rand(6, device=self.device)
+            r = r.to(torch.float64)                                            # [offset(3) | jitter(3)], as float32 draws
             b = torch.addcmul(torch.addcmul(c_mar, r[:3], c_off), r[3:], c_vox)
             pts = torch.addcmul(b, self._lattice, c_vox)
             pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
@@ -282,6 +286,42 @@ class Mapper:
                 "sorted_flat": torch.stack(sorted_pix).reshape(-1), "starts_flat": torch.stack(starts) + offs,
                 "counts_f64": cnt_all.to(torch.float64), "counts_m1": cnt_all - 1}
 
+    # ------------------------------------------------------------------ draws one iteration ahead
+    def _draw_all(self, prep):
+        """The random draws of one static-shape iteration in the reference's order: pixels, surface jitter, lattice
+        offset / jitter (mapping.py:498-505, common.py:571-582, mapping.py:137-143)."""
+        return {"pix": self.draw_pixels(prep), "jitter": self.draw_jitter(), "r6": torch.rand(6, device=self.device)}
+
+    def _take_draws(self, prep):
+        """``prefetch_draws``: the dozen tiny generator / index launches of iteration k+1 are enqueued on the side
+        stream while iteration k runs, instead of heading k+1's critical path (same generator, same order, same
+        values -- the host issues them in sequence either way).  Needs ``static_shapes`` and a smoothness term in every
+        iteration (the lattice draw is taken with the others)."""
+        main = torch.cuda.current_stream()
+        pend = getattr(self, "_pending_draws", None)
+        if pend is None:
+            cur = self._draw_all(prep)
+        else:
+            cur, ev = pend
+            main.wait_event(ev)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        # Every burst of side-stream work starts by waiting for the main stream's tail: tensors the side stream allocated
+        # earlier and the main stream consumed (the smoothness loss, gradients) carry no record_stream, so their memory
+        # may only be handed out again once the main stream is past its reads.  (Without this wait the draws landed in
+        # such blocks while the main stream was still a step behind: measured as run-to-run different losses.)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nxt = self._draw_all(prep)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in (nxt["pix"], nxt["jitter"][0], nxt["jitter"][1], nxt["r6"]):
+            t.record_stream(main)
+        self._pending_draws = (nxt, ev)
+        self._lattice_r6 = cur["r6"]
+        return cur
+
     def draw_pixels(self, prep):
         """Indices of one iteration: per frame n1 uniform picks (select_uv, common.py:274) then n2 class-balanced
         picks (select_by_class :313-328), concatenated in the reference's order."""
@@ -322,6 +362,9 @@ class Mapper:
         if prep is None:
             prep = self.prepare_frames(target_frames)
         K = self.n_target_frame
+        if pix_idx is None and jitter is None and getattr(self, "prefetch_draws", False) and self.static_shapes:
+            d = self._take_draws(prep)
+            pix_idx, jitter = d["pix"], d["jitter"]
         if pix_idx is None:
             pix_idx = self.draw_pixels(prep)
         npf = pix_idx.numel() // K

@@ -48,10 +48,12 @@ def test_fullsize_properties(workload):
     table = dec.pe_fn.grid_fn.params
     g_all, = torch.autograd.grad(loss, table, retain_graph=False)
     assert bool(torch.isfinite(g_all).all()) and float(g_all.abs().max()) > 0
-    # linearity of the scatter in the upstream gradient: grad(2 * loss) == 2 * grad(loss) bit for bit (fixed point sums)
+    # linearity of the scatter in the upstream gradient: grad(2 * loss) == 2 * grad(loss).  Every step up to the per-chunk
+    # fixed-point sums scales exactly; what remains is the order of the float atomics that add the <= 24 slice sums of a
+    # chunk into the table gradient (a few ulp of the largest partial sums: measured 2-3e-7 of max |g|)
     loss2, _ = mapper.iteration_loss(s, smooth=False)
     g2, = torch.autograd.grad(2.0 * loss2, table)
-    assert float((g2 - 2.0 * g_all).abs().max()) <= 2e-6 * float(g_all.abs().max())
+    assert float((g2 - 2.0 * g_all).abs().max()) <= 1e-5 * float(g_all.abs().max())
 
 
 def test_cfg2_fullsize_matches_oracle():
@@ -91,3 +93,26 @@ def test_cfg2_fullsize_matches_oracle():
     assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what="d table (full size)")
     n = 64 * 80 + 64 * 64 + 33 * 64
     assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:n], om.coarse.grad[:n], what="d coarse (full size)")
+
+
+def test_cfg2_prefetched_draws_same_trajectory_without_host_syncs(monkeypatch):
+    """Mapper.prefetch_draws (the benchmark's default with two streams: iteration k+1's pixel / jitter / lattice draws are
+    enqueued on the side stream during iteration k): same generator order, so the losses of 16 full-size iterations
+    launched WITHOUT any host synchronisation equal the unprefetched run's up to the run-to-run noise of the float
+    atomics.  At this size the main stream runs a step behind the host: a missing stream dependency (side-stream blocks
+    recycled while the main stream still read them) moved the losses by 2e-3 within four iterations when measured."""
+    import bench
+    from dns_slam_amd import dist as dd
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    runs = []
+    for prefetch in ("0", "1", "1"):
+        monkeypatch.setenv("DNS_PREFETCH_DRAWS", prefetch)
+        cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS["cfg2"], DEV, seed=100, dist_ctx=dd.DistCtx(),
+                                                            overlap=True)
+        assert mapper.prefetch_draws == (prefetch == "1")
+        losses = [step().detach() for _ in range(16)]
+        torch.cuda.synchronize()
+        runs.append(torch.stack(losses).cpu())
+    for r in runs[1:]:
+        err = float(((r - runs[0]).abs() / runs[0].abs()).max())
+        assert err <= 5e-4, f"prefetched draws changed the loss trajectory: max relative difference {err:.2e}"

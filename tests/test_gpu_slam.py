@@ -635,3 +635,4 @@ def test_optimise_trajectory_matches_oracle_adam():
     for f in range(1, 4):
         assert_close(ql[f].detach().cpu(), qo[f].detach(), rtol=1e-4, what=f"quat[{f}] after 5 steps")
         assert_close(Tl[f].detach().cpu(), To[f].detach(), rtol=1e-4, what=f"T[{f}] after 5 steps")
+
