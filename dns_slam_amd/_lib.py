@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class DnsGridMeta(C.Structure):
@@ -37,14 +37,16 @@ _I = C.c_int
 SIGNATURES = {
     "dns_abi_version": (C.c_int, []),
     "dns_last_error": (C.c_char_p, []),
+    "dns_init": (C.c_int, []),
     "dns_grid_meta_init": (C.c_int, [C.POINTER(DnsGridMeta), _U, _U, _U, _U, C.c_double]),
-    "dns_raygen_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I,
+    "dns_raygen_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I,
                                     _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dns_rays_from_pixels": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dns_sample_along_rays": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "dns_raygen_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_encode_fwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _P, _U, _P, _U, _P]),
-    "dns_encode_bwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _U, _P, _U, _P, _P, _P, _P]),
-    "dns_encode_bwd_ws_floats": (C.c_uint64, [_U, C.POINTER(DnsGridMeta)]),
+    "dns_encode_bwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _U, _P, _U, _P, _P, _P, _U, _U, _P]),
+    "dns_encode_bwd_ws_floats": (C.c_uint64, [_U, C.POINTER(DnsGridMeta), _U, _U]),
     "dns_hashgrid_indices": (C.c_int, [_P, _U, C.POINTER(DnsGridMeta), _P, _P]),
     "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P, _U, _P]),
     "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P, _I, _P]),
@@ -85,8 +87,24 @@ def _load():
 lib = _load()
 
 
+_ready_devices = set()
+
+
+def ensure_init() -> None:
+    """dns_init() once per device, outside any stream capture (include/dns_hip.h): called by stream_ptr(), i.e. ahead of
+    every launch, so that no kernel attribute is ever set lazily inside a hipGraph capture."""
+    import torch
+    d = torch.cuda.current_device()
+    if d not in _ready_devices:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("dns_slam_amd: first use on this device inside a hipGraph capture; run one op (or "
+                               "dns_slam_amd._lib.ensure_init()) before capturing")
+        check(lib.dns_init(), "dns_init")
+        _ready_devices.add(d)
+
+
 def check(rc: int, what: str = "") -> None:
-    """Raise on a negative return code: -1 -> ValueError (argument), others -> RuntimeError (launch)."""
+    """Raise on a negative return code: -1 -> ValueError (argument), others -> RuntimeError (launch / state)."""
     if rc == 0:
         return
     msg = lib.dns_last_error().decode("utf-8", "replace")
@@ -102,6 +120,7 @@ def ptr(t):
 
 def stream_ptr():
     import torch
+    ensure_init()
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

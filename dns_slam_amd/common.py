@@ -2,15 +2,86 @@
 
 Same names and argument meaning where the reference function is itself a call site of the hot path:
 ``quad2rotation`` (:406), ``get_rotation_from_quad`` (:447), ``get_camera_from_tensor`` (:432),
-``raw2nerf_color`` (:506), ``get_opacity_loss`` (:769).  Ray generation and depth-guided sampling
-(``get_samples`` :296, ``sample_along_rays`` :561) are fused into one launch, ``ops.raygen_sample``; the drawn
-pixel indices and jitter vectors are explicit inputs there.
+``raw2nerf_color`` (:506), ``get_opacity_loss`` (:769), ``get_samples`` (:296), ``get_samples_by_class`` (:353),
+``get_samples_by_uniq_class`` (:364), ``get_all_rays`` (:540), ``sample_along_rays`` (:561), ``feature_matching`` (:645).
+Inside the optimise steps ray generation and depth-guided sampling are fused into one launch, ``ops.raygen_sample``; the
+drawn pixel indices and jitter vectors are explicit inputs there.
 """
 import math
 
 import torch
 
 from . import ops
+
+
+# ----------------------------------------------------------------------------- pixel sampling + rays (a1 - a3)
+def _class_pick(label_flat, n, device, class_list=None):
+    """The index draws of select_by_class (utils/common.py:313-328) / get_samples_by_uniq_class (:378-394), in the
+    reference's order and with the reference's shapes -- per class, ascending: ``torch.randint(k, (m,), device=device)``
+    over the class's k pixels (ascending pixel order, as ``nonzero``), the first class takes the remainder
+    ``n - (n // n_class) * (n_class - 1)``, a class with exactly ONE pixel is repeated without a draw, and (uniq variant) a
+    class of ``class_list`` that is absent from the image is skipped -- so the same generator state yields the same indices.
+    One host sync (the per-class pixel counts), where the reference syncs once per class."""
+    order = torch.argsort(label_flat, stable=True)                       # pixels grouped by class, ascending inside a class
+    classes, cnt = torch.unique_consecutive(label_flat[order], return_counts=True)
+    cls_host, cnt_host = classes.tolist(), cnt.tolist()
+    start_of = {}
+    o = 0
+    for c, k in zip(cls_host, cnt_host):
+        start_of[float(c)] = (o, k)
+        o += k
+    wanted = cls_host if class_list is None else [float(c) for c in class_list]
+    n_class = len(wanted)
+    n_k = n // n_class
+    parts = []
+    for i, c in enumerate(wanted):
+        m = n - n_k * (n_class - 1) if i == 0 else n_k
+        st, k = start_of.get(float(c), (0, 0))
+        if k == 1:
+            parts.append(order[st:st + 1].repeat(m))
+        elif k > 1:
+            parts.append(order[st + torch.randint(k, (m,), device=device)])
+    return torch.cat(parts, dim=-1)
+
+
+def _rays_for(indices, H0, H1, W0, W1, H, W, fx, fy, cx, cy, R, T, color, device):
+    R = torch.as_tensor(R, device=device)
+    T = torch.as_tensor(T, device=device)
+    img = color.to(device)
+    rays_o, rays_d, sample, _ = ops.rays_from_pixels(R, T, indices, img, (fx, fy, cx, cy), (img.shape[0], img.shape[1]),
+                                                     (H0, H1, W0, W1))
+    return rays_o, rays_d, sample
+
+
+def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, R, T, color, device):
+    """utils/common.py:296-304, same signature: n uniformly drawn pixels of the window [H0,H1)x[W0,W1) of ``color``
+    [H,W,C] (rgb | depth | label) -> (rays_o [n,3], rays_d [n,3], sample [n,C]).  The draw is the reference's
+    (``torch.randint(HW_window, (n,), device=device)``, :274); gather and rays are one HIP launch."""
+    indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=device)
+    return _rays_for(indices, H0, H1, W0, W1, H, W, fx, fy, cx, cy, R, T, color, device)
+
+
+def get_samples_by_class(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, R, T, color, device):
+    """utils/common.py:353-361 (select_by_class :307-338), same signature: n pixels drawn class-balanced over the labels
+    present in the window (last channel of ``color``)."""
+    label = color[H0:H1, W0:W1, -1].to(device).reshape(-1)
+    indices = _class_pick(label, n, device)
+    return _rays_for(indices, H0, H1, W0, W1, H, W, fx, fy, cx, cy, R, T, color, device)
+
+
+def get_samples_by_uniq_class(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, R, T, color, class_dict, device):
+    """utils/common.py:364-403, same signature: class-balanced over the classes of ``class_dict`` only (decoder warm-up,
+    slams/mapping.py:787); a class absent from the window is skipped (its quota is NOT redistributed, as in the reference)."""
+    label = color[H0:H1, W0:W1, -1].to(device).reshape(-1)
+    indices = _class_pick(label, n, device, class_list=list(class_dict))
+    return _rays_for(indices, H0, H1, W0, W1, H, W, fx, fy, cx, cy, R, T, color, device)
+
+
+def get_all_rays(H, W, fx, fy, cx, cy, c2w, device):
+    """utils/common.py:540-559, same signature: (rays_o, rays_d) [H,W,3] of every pixel."""
+    c2w = torch.as_tensor(c2w).to(device).float()
+    rays_o, rays_d, _, _ = ops.rays_from_pixels(c2w[:3, :3], c2w[:3, 3], None, None, (fx, fy, cx, cy), (H, W), (0, H, 0, W))
+    return rays_o.reshape(H, W, 3), rays_d.reshape(H, W, 3)
 
 
 def quad2rotation(quad):

@@ -29,6 +29,18 @@ inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 
+// One-time per-device kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize for every kernel that takes more than
+// 64 KB of dynamic LDS).  hipFuncSetAttribute is a context-level call: it must not run while a stream is being captured
+// into a hipGraph and it is not something to repeat on every launch, so each source file registers ONE function that
+// sets the attributes of its kernels, dns_init() (host.cpp) runs them once per device, and the launch wrappers call
+// ensure_ready(): a no-op after dns_init(), an implicit dns_init() on first use outside capture, DNS_E_STATE under capture.
+typedef int (*AttrInitFn)();
+struct AttrRegistrar {
+  explicit AttrRegistrar(AttrInitFn fn);
+};
+int ensure_ready(hipStream_t st, const char* who);
+constexpr int MAX_DYN_LDS = 160 * 1024;      // gfx950: 160 KiB of LDS per CU, all of it available to one workgroup
+
 // Device-side copy of the level table, passed by value as a kernel argument.
 struct GridLevels {
   uint32_t n_levels;

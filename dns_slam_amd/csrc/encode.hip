@@ -11,7 +11,6 @@
 // Arithmetic contract shared with oracle/tcnn_ref.py: pos = x*scale + 0.5 is two IEEE roundings
 // (__fmul_rn/__fadd_rn, never contracted), the cell is (uint32)(int)floorf(pos); hash primes
 // {1, 2654435761, 805459861}; index % level size.  Those make the table rows bit-exact.
-#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 
@@ -317,6 +316,7 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
   const uint32_t nf = n_levels * 2;                  // floats per row (<= 32 with the supported 16 levels)
   const bool vec = ((ld & 3u) == 0) && ((((uintptr_t)d_grid) & 15u) == 0) && ((nf & 3u) == 0);
   float m = 0.f;
+  bool bad = false;                                  // a NaN / Inf in the upstream gradient
   for (uint32_t e = threadIdx.x; e < 256u * 8u; e += 256u) {
     const uint32_t r = e >> 3, q = e & 7u;
     const uint32_t p = p0 + r;
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
     float* d = tile + r * LDT + 4 * q;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    bad = bad || !(fabsf(v.x) < INFINITY) || !(fabsf(v.y) < INFINITY) || !(fabsf(v.z) < INFINITY) || !(fabsf(v.w) < INFINITY);
   }
   __syncthreads();
   const uint32_t p = p0 + threadIdx.x;
@@ -354,6 +355,10 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
     const float bm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     if (bm > 0.f && bm < INFINITY && bm > __uint_as_float(__atomic_load_n(gmax, __ATOMIC_RELAXED))) atomicMax(gmax, __float_as_uint(bm));
   }
+  // The fixed-point bins cannot carry NaN / Inf (fmaxf drops a NaN, the integer conversion of a non-finite product is
+  // undefined): a non-finite upstream gradient raises gmax[1] instead and the scatter kernels then write NaN into every
+  // row they own, so a diverged step shows up in d_table exactly as it does with per-corner float atomics.
+  if (__any(bad) && (threadIdx.x & 63u) == 0 && __atomic_load_n(gmax + 1, __ATOMIC_RELAXED) == 0u) atomicOr(gmax + 1, 1u);
 }
 
 // round-to-nearest-even of an fp32 value with |v| < 2^40 to a 64-bit integer: v = hi * 2^16 + lo exactly (hi = trunc(v /
@@ -372,7 +377,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
                                                                     float* __restrict__ d_table) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
   const float mx = __uint_as_float(*gmax);
-  if (!(mx > 0.f)) return;                       // all-zero upstream gradient: nothing to add (uniform exit)
+  const bool poisoned = gmax[1] != 0u;           // NaN / Inf upstream (dgrid_transpose_kernel): NaN into the owned rows
+  if (!(mx > 0.f) && !poisoned) return;          // all-zero upstream gradient: nothing to add (uniform exit)
   int ex;
   (void)frexpf(mx, &ex);                         // mx < 2^ex
   const float scale = ldexpf(1.0f, 40 - ex);     // |w*g| * scale < 2^40; 2^22 contributions stay below 2^62
@@ -410,6 +416,11 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
   const uint32_t base = chunk * plan.chunk_rows;
   const uint32_t size = lv.size[l];
   const uint32_t rows = min(plan.chunk_rows, size - base);
+  if (poisoned) {                                // uniform
+    float* out = d_table + 2 * ((size_t)lv.offset[l] + base);
+    for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
   for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) bins[i] = 0ull;
   __syncthreads();
   const float s = lv.scale[l];
@@ -679,7 +690,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_queue_kernel(GridLevels lv,
                                                                    float* __restrict__ d_table) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
   const float mx = __uint_as_float(*gmax);
-  if (!(mx > 0.f)) return;                       // all-zero upstream gradient (uniform exit)
+  const bool poisoned = gmax[1] != 0u;           // NaN / Inf upstream: NaN into the queue's rows (see the binned kernel)
+  if (!(mx > 0.f) && !poisoned) return;          // all-zero upstream gradient (uniform exit)
   int ex;
   (void)frexpf(mx, &ex);
   const float scale = ldexpf(1.0f, 40 - ex);     // as in the binned kernel: |w*g| * scale < 2^40
@@ -690,6 +702,11 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_queue_kernel(GridLevels lv,
   const uint32_t ch = qi - pp.qoff[li], l = pp.level[li], cap = pp.cap[li];
   const uint32_t row0 = ch << pp.chunk_shift;
   const uint32_t rows = min(1u << pp.chunk_shift, lv.size[l] - row0);
+  if (poisoned) {                                // uniform
+    float* out = d_table + 2 * ((size_t)lv.offset[l] + row0);
+    for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
   const uint32_t n = min(qcount[qi], cap);
   const uint32_t lo = (uint32_t)(((uint64_t)n * slice) / pp.slices), hi = (uint32_t)(((uint64_t)n * (slice + 1)) / pp.slices);
   if (lo >= hi) return;                          // uniform per workgroup
@@ -715,7 +732,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_queue_kernel(GridLevels lv,
 // expectation + 1/8 slack per queue, dense levels (spatially clustered points) twice the expectation.
 constexpr uint32_t PART_MIN_CHUNKS = 16;
 
-static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, PartPlan& pp) {
+static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, uint32_t queue_cap, PartPlan& pp) {
   pp.n = 0;
   pp.chunk_shift = 13;
   uint32_t queues = 0;
@@ -726,8 +743,7 @@ static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, Par
     if (lv.hashed[l] && (lv.size[l] & (lv.size[l] - 1u))) continue;
     const uint64_t expect = ((uint64_t)P * 8u + chunks - 1) / chunks;
     uint64_t cap = (lv.hashed[l] ? expect + expect / 8u : 2u * expect) + 4096u;
-    const char* cap_env = getenv("DNS_PART_CAP");                 // tests: force the queue-overflow fallback
-    if (cap_env && atoi(cap_env) > 0) cap = (uint64_t)atoi(cap_env);
+    if (queue_cap) cap = queue_cap;                               // caller-chosen capacity (tests: the overflow fallback)
     cap = (cap + 3u) & ~3ull;
     if (cap > 0x7FFFFFFFull) return false;
     const uint32_t i = pp.n++;
@@ -759,12 +775,23 @@ static uint64_t part_floats(const PartPlan& pp) {
   return f;
 }
 
-static uint32_t part_min_chunks() {
-  const char* force = getenv("DNS_SCATTER");                 // read per call: tests switch it
-  if (force && force[0] == 'q') return 2u;                   // A/B: every multi-chunk level through the queues
-  if (force && force[0] == 'b') return PART_MAX_CHUNKS + 1u;  // A/B: none
+static uint32_t part_min_chunks(uint32_t flags) {
+  const uint32_t form = flags & DNS_SCATTER_MASK;
+  if (form == DNS_SCATTER_QUEUES) return 2u;                   // every multi-chunk level through the queues
+  if (form == DNS_SCATTER_BINNED) return PART_MAX_CHUNKS + 1u;  // none
   return PART_MIN_CHUNKS;
 }
+
+static int encode_init_attrs() {
+  const int bytes = 8192 * 2 * (int)sizeof(unsigned long long);   // one 8192-row chunk of 64-bit bins: 128 KB
+  if (hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+      hipFuncSetAttribute((const void*)hashgrid_bwd_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    set_error("dns_init: hipFuncSetAttribute failed for the hash-grid scatter kernels");
+    return DNS_E_LAUNCH;
+  }
+  return DNS_OK;
+}
+static AttrRegistrar encode_attr_registrar(encode_init_attrs);
 
 }  // namespace dns
 
@@ -799,9 +826,11 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
 
 extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
                               const DnsGridMeta* meta, const float* d_pe, uint32_t ld_dpe, const float* d_grid,
-                              uint32_t ld_dgrid, float* d_table, float* d_x, float* ws, void* stream) {
+                              uint32_t ld_dgrid, float* d_table, float* d_x, float* ws, uint32_t flags, uint32_t queue_cap,
+                              void* stream) {
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
+  DNS_REQUIRE((flags & ~DNS_SCATTER_MASK) == 0, "dns_encode_bwd: unknown flags 0x%x", flags);
   GridLevels lv = {};
   if (d_grid) {
     DNS_REQUIRE(meta && table, "dns_encode_bwd: d_grid given without table/meta");
@@ -811,11 +840,13 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
   if (d_pe) DNS_REQUIRE(n_bins >= 1 && n_bins <= 64 && ld_dpe >= 3 * n_bins, "dns_encode_bwd: n_bins %u / ld %u", n_bins, ld_dpe);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t blocks = (P + 255) / 256;
-  // table gradient: LDS-binned scatter (DNS_SCATTER=atomic forces the per-corner global atomics, for comparison)
-  const char* force = getenv("DNS_SCATTER");
-  bool binned = d_table && d_grid && ws && meta->n_levels <= 16;   // measured faster at T=2^16 (17x) and T=2^20 (2.5x)
-  if (force && force[0] == 'a') binned = false;
-  if (force && force[0] == 'b') binned = d_table && d_grid && ws;
+  // table gradient: LDS-binned scatter unless the caller asks for the per-corner global atomics (or passes no workspace)
+  const bool binned = d_table && d_grid && ws && meta->n_levels <= 16 &&   // measured faster at T=2^16 (17x) and T=2^20 (2.5x)
+                      (flags & DNS_SCATTER_MASK) != DNS_SCATTER_ATOMIC;
+  if (binned) {
+    const int rc = ensure_ready(st, "dns_encode_bwd");
+    if (rc != DNS_OK) return rc;
+  }
   float* d_table_direct = binned ? nullptr : d_table;
   if (d_x || d_table_direct) {
     const uint32_t blocks128 = (P + 127) / 128;
@@ -832,19 +863,14 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     }
   }
   if (binned) {
-    static const char* ns_env = getenv("DNS_SCATTER_SLICES");
     BinPlan plan;
     plan.n_levels = lv.n_levels;
-    static const char* rows_env = getenv("DNS_SCATTER_ROWS");
-    plan.chunk_rows = rows_env ? (uint32_t)atoi(rows_env) : 8192u;
-    DNS_REQUIRE(plan.chunk_rows >= 256 && plan.chunk_rows <= 8192, "DNS_SCATTER_ROWS must be in [256, 8192]");
-    static const char* order_env = getenv("DNS_SCATTER_ORDER");
-    plan.xcd_major = (order_env && order_env[0] == 'l') ? 0u : 1u;
-    static const char* walk = getenv("DNS_SCATTER_WALK");
-    plan.strided_dense = (walk && walk[0] == 'c') ? 0u : 1u;
-    // levels of large tables: partition form (DNS_SCATTER=q sends every multi-chunk level there, =b none, for A/B)
+    plan.chunk_rows = 8192u;
+    plan.xcd_major = 1u;
+    plan.strided_dense = 1u;
+    // levels of large tables: partition form (DNS_SCATTER_QUEUES sends every multi-chunk level there, _BINNED none)
     PartPlan pp;
-    const bool part = plan.chunk_rows == 8192u && part_plan(lv, P, part_min_chunks(), pp);
+    const bool part = part_plan(lv, P, part_min_chunks(flags), queue_cap, pp);
     bool in_part[DNS_MAX_LEVELS] = {};
     if (part)
       for (uint32_t i = 0; i < pp.n; ++i) in_part[pp.level[i]] = true;
@@ -858,7 +884,7 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     uint32_t weight = 0;
     for (uint32_t l = 0; l < lv.n_levels; ++l) weight += chunk_of[l] * (lv.hashed[l] ? 1u : (chunk_of[l] == 1 ? 4u : 2u));
     if (weight == 0) weight = 1;
-    uint32_t ns = ns_env ? (uint32_t)atoi(ns_env) : (512u + weight - 1) / weight;
+    uint32_t ns = (512u + weight - 1) / weight;
     if (ns < 1) ns = 1;
     const uint32_t max_ns = (P + 1023) / 1024;                 // at least ~one point per thread
     if (ns > max_ns) ns = max_ns ? max_ns : 1;
@@ -886,13 +912,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       jobs = 8u * mx;                                          // padded: workgroups past an XCD's last job exit at once
     }
     const size_t lds_bytes = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 2 * (int)sizeof(unsigned long long));
-      attr_set = true;
-    }
     uint32_t* gmax = (uint32_t*)(ws + (size_t)P * lv.n_levels * 2);
-    if (hipMemsetAsync(gmax, 0, sizeof(uint32_t), st) != hipSuccess) {
+    if (hipMemsetAsync(gmax, 0, 4 * sizeof(uint32_t), st) != hipSuccess) {   // max word, non-finite flag, pad
       set_error("dns_encode_bwd: memset failed");
       return DNS_E_LAUNCH;
     }
@@ -906,11 +927,6 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       if (hipMemsetAsync(qcount, 0, sizeof(uint32_t) * pp.qoff[pp.n], st) != hipSuccess) {
         set_error("dns_encode_bwd: memset failed");
         return DNS_E_LAUNCH;
-      }
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)hashgrid_bwd_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 2 * (int)sizeof(unsigned long long));
-        attr2 = true;
       }
       hipLaunchKernelGGL(hashgrid_bwd_partition_kernel, dim3((P + PART_THREADS - 1) / PART_THREADS), dim3(PART_THREADS), 0, st, x, P, lv,
                          pp, (const float2*)ws, qcount, queues, d_table);
@@ -929,12 +945,12 @@ extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMet
   return check_launch("dns_hashgrid_indices");
 }
 
-extern "C" uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta) {
+extern "C" uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta, uint32_t flags, uint32_t queue_cap) {
   if (!meta) return 0;
   // level-major d_grid copy + max|d_grid| word (+pad) + queue counters + the partition form's queues
   uint64_t n = (uint64_t)P * meta->n_levels * 2 + 4;
   const GridLevels lv = to_levels(meta);
   PartPlan pp;
-  if (part_plan(lv, P, part_min_chunks(), pp)) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS + part_floats(pp);
+  if (part_plan(lv, P, part_min_chunks(flags), queue_cap, pp)) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS + part_floats(pp);
   return n;
 }

@@ -1,6 +1,8 @@
 // Host-only pieces of the C ABI: error slot, ABI version, hash-grid level table.
 #include <math.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include "common.hpp"
 
 namespace dns {
@@ -11,8 +13,50 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- one-time kernel attributes (see common.hpp) ----
+static AttrInitFn g_attr_fns[16];
+static int g_n_attr_fns = 0;                       // filled by static constructors at load time (single-threaded)
+static std::atomic<uint64_t> g_ready_devices{0};   // bit d: device d has its attributes
+static std::mutex g_init_mutex;
+
+AttrRegistrar::AttrRegistrar(AttrInitFn fn) {
+  if (g_n_attr_fns < 16) g_attr_fns[g_n_attr_fns++] = fn;
+}
+
+static int init_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    set_error("dns_init: no current HIP device");
+    return DNS_E_STATE;
+  }
+  if (g_ready_devices.load(std::memory_order_acquire) & (1ull << dev)) return DNS_OK;
+  std::lock_guard<std::mutex> lock(g_init_mutex);
+  if (g_ready_devices.load(std::memory_order_acquire) & (1ull << dev)) return DNS_OK;
+  for (int i = 0; i < g_n_attr_fns; ++i) {
+    const int rc = g_attr_fns[i]();
+    if (rc != DNS_OK) return rc;
+  }
+  g_ready_devices.fetch_or(1ull << dev, std::memory_order_release);
+  return DNS_OK;
+}
+
+int ensure_ready(hipStream_t st, const char* who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
+      (g_ready_devices.load(std::memory_order_acquire) & (1ull << dev)))
+    return DNS_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    set_error("%s: first use of the library on this device inside a stream capture; call dns_init() before capturing", who);
+    return DNS_E_STATE;
+  }
+  (void)hipGetLastError();
+  return init_current_device();
+}
 }  // namespace dns
 
+extern "C" int dns_init(void) { return dns::init_current_device(); }
 extern "C" int dns_abi_version(void) { return DNS_ABI_VERSION; }
 extern "C" const char* dns_last_error(void) { return dns::g_err; }
 

@@ -1429,33 +1429,6 @@ __device__ __forceinline__ void gemm_unit_run(const GemmUnit& u, uint32_t n_slot
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_roles_kernel(GemmRoles r) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int* grp_lds = reinterpret_cast<int*>(lds);
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t n_btiles = (r.n_slots + 127u) / 128u;
-  // One weight set: tiles are dealt round-robin (tile = blockIdx + t * gridDim), so that at any moment the whole grid
-  // reads one dense window of each matrix (DRAM pages are consumed by neighbouring workgroups together).  Grouped
-  // launches keep contiguous tile ranges instead: a workgroup then meets few weight sets and flushes rarely.
-  const bool strided = r.strided != 0;
-  const uint32_t bt0 = strided ? blockIdx.x : blockIdx.x * r.tiles_per_block;
-  const uint32_t tstride = strided ? gridDim.x : 1u;
-  if (bt0 >= n_btiles) return;               // uniform per workgroup
-  const uint32_t ntl = strided ? (n_btiles - bt0 + tstride - 1u) / tstride : min(r.tiles_per_block, n_btiles - bt0);
-  for (uint32_t t = threadIdx.x; t < ntl; t += blockDim.x) grp_lds[t] = r.tile_group ? r.tile_group[bt0 + t * tstride] : 0;
-  __syncthreads();                           // the only workgroup barrier: waves are independent from here on
-  const GemmUnit& u = r.u[wave];             // blockDim.x = 64 * n_units
-  float* wlds = lds + GEMM_MAX_TPB + wave * 4096u;
-  switch (u.kind) {
-    case 4: gemm_unit_run<false, false, true>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
-    case 6: gemm_unit_run<false, true, true>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
-    case 5: gemm_unit_run<true, false, true>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
-    case 0: gemm_unit_run<false, false, false>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
-    case 1: gemm_unit_run<true, false, false>(u, r.n_slots, bt0, tstride, ntl, grp_lds, wlds, r.c_stride); break;
-    default: break;                          // host never launches other kinds
-  }
-}
-
 // One weight set (every launch but the per-class fine decoders): a workgroup's four waves work on the SAME unit, each on
 // its own tiles (wave gw of the unit takes tiles gw, gw + n_gw, ... -- the dealing of gemm_roles_kernel with one wave per
 // unit and workgroup), and their four 64x64 blocks are added in LDS before the global atomics: 4x fewer of them.  The
@@ -1560,15 +1533,37 @@ static bool shape_ok(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
          n_out <= 64;
 }
 
-static uint32_t pick_tiles_per_block(uint32_t n_btiles, uint32_t target_blocks, const char* env_name) {
+static uint32_t pick_tiles_per_block(uint32_t n_btiles, uint32_t target_blocks) {
   // contiguous tile ranges, one wave of workgroups: the forward holds 2 workgroups of 4 waves per CU (LDS: weight
   // images + staging ~ 72 KB), the backward 1 workgroup of 8 waves (~ 98 KB) that takes tiles in pairs
-  const char* e = getenv(env_name);
-  if (e && atoi(e) > 0) target_blocks = (uint32_t)atoi(e);
   uint32_t tpb = (n_btiles + target_blocks - 1) / target_blocks;
   if (tpb < 1) tpb = 1;
   return tpb;
 }
+
+template <int NN, int NL>
+static bool set_mlp_attrs() {
+  bool ok = true;
+  auto set = [&](const void* f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess; };
+  set((const void*)mlp_fwd_kernel<NN, NL, false>);
+  set((const void*)mlp_fwd_kernel<NN, NL, true>);
+  set((const void*)mlp_bwd_data_kernel<NN, NL, true, true>);
+  set((const void*)mlp_bwd_data_kernel<NN, NL, true, false>);
+  set((const void*)mlp_bwd_data_kernel<NN, NL, false, false>);
+  return ok;
+}
+
+static int mlp_init_attrs() {
+  bool ok = set_mlp_attrs<32, 1>() && set_mlp_attrs<32, 2>() && set_mlp_attrs<64, 1>() && set_mlp_attrs<64, 2>();
+  ok = ok && hipFuncSetAttribute((const void*)gemm_units_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess;
+  if (!ok) {
+    set_error("dns_init: hipFuncSetAttribute failed for the MLP kernels");
+    return DNS_E_LAUNCH;
+  }
+  return DNS_OK;
+}
+static AttrRegistrar mlp_attr_registrar(mlp_init_attrs);
 
 }  // namespace dns
 
@@ -1610,14 +1605,16 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   const XSeg seg = {x2, ldx2, x2 ? n_in1 : n_in};
   const MlpShape sh = make_shape(n_in, n_out);
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
-  const uint32_t tpb = pick_tiles_per_block(n_btiles, 512, "DNS_MLP_FWD_BLOCKS");
+  const uint32_t tpb = pick_tiles_per_block(n_btiles, 512);
   const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = ensure_ready(st, "dns_mlp_fwd");
+    if (rc != DNS_OK) return rc;
+  }
 #define LAUNCH_FWD2(NN, NL, H)                                                                                     \
   {                                                                                                                \
     const size_t lds_bytes = ((size_t)FwdLds<NN, NL>::total(n_in, sh.mt, sh.vr) + 4 * STG_WAVE_FLOATS) * sizeof(float); \
-    (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, H>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              (int)lds_bytes);                                                                     \
     hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL, H>), dim3(blocks), dim3(256), lds_bytes, st, x, ldx, seg, params, sh, y, \
                        ldy, n_slots, row_index, tile_group, param_stride, tpb, h_save);                            \
   }
@@ -1660,17 +1657,19 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   if (d_x && x2) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd: lddx2 < n_in - n_in1");
   const MlpShape sh = make_shape(n_in, n_out);
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = ensure_ready(st, "dns_mlp_bwd");
+    if (rc != DNS_OK) return rc;
+  }
   const uint32_t NNr = n_neurons;
-  static const char* gb_env = getenv("DNS_GEMM_BLOCKS");
+  const char* gb_env = nullptr;
   const DxSeg dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)(accumulate_dx & 1), (uint32_t)((accumulate_dx >> 1) & 1)};
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
-  const uint32_t tpb = pick_tiles_per_block(n_btiles, 256, "DNS_MLP_BWD_BLOCKS");
+  const uint32_t tpb = pick_tiles_per_block(n_btiles, 256);
   const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
 #define LAUNCH_BWD2(NN, NL, SV, H)                                                                                  \
   {                                                                                                                 \
     const size_t lds_bytes = ((size_t)BwdLds<NN, NL, SV>::total(n_in, n_out, d_x != nullptr) + 8 * STG_WAVE_FLOATS) * sizeof(float); \
-    (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel<NN, NL, SV, H>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds_bytes);                                                                      \
     hipLaunchKernelGGL((mlp_bwd_data_kernel<NN, NL, SV, H>), dim3(blocks), dim3(512), lds_bytes, st, x, ldx, dy, lddy, \
                        params, sh, d_x, lddx, dseg, n_in1, ws, n_slots, row_index, tile_group, param_stride, tpb,   \
                        h_saved, n_slots);                                                                           \
@@ -1715,9 +1714,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   }
   add(dy, lddy, row_index, n_out, (n_hidden_layers == 2) ? wsH2 : wsH1, NNr, nullptr, NNr, dwo, NNr);
   for (int k = ng; k < 4; ++k) batch.g[k] = batch.g[0];
-  static const char* gemm_env = getenv("DNS_GEMM");
   GemmRoles roles;
-  const bool staged = (gemm_env && gemm_env[0] == 's') || !make_roles(batch.g, ng, roles);
+  const bool staged = !make_roles(batch.g, ng, roles);
   DNS_REQUIRE(!(staged && x2), "dns_mlp_bwd: this two-segment input shape is not supported by the weight-gradient kernel");
   if (staged) {                               // LDS-staged 32x32x2 form: operand shapes the direct form does not take, or A/B
     const uint32_t max_cols = ((n_in + 31u) / 32u) * 32u + NNr > 2 * NNr ? ((n_in + 31u) / 32u) * 32u + NNr : 2 * NNr;
@@ -1740,10 +1738,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
     if (nb < 1) nb = 1;
     roles.tiles_per_block = (n_btiles + nb - 1) / nb;
     nb = (n_btiles + roles.tiles_per_block - 1) / roles.tiles_per_block;
-    static const char* order_env = getenv("DNS_GEMM_ORDER");     // 'c' contiguous / 's' strided, for A/B
-    roles.strided = order_env ? (order_env[0] == 's') : (roles.tile_group == nullptr);
-    static const char* form_env = getenv("DNS_GEMM_FORM");        // 'w': one unit per wave (the earlier form, for A/B)
-    if (!(form_env && form_env[0] == 'w')) {
+    roles.strided = roles.tile_group == nullptr;
+    {
       // GEMM_UNIT_WAVES waves of a workgroup share a unit and reduce in LDS (nb = waves per unit, as above)
       const uint32_t nb_req = gb_env ? (uint32_t)atoi(gb_env) : 512u;
       uint32_t nbu = ((roles.tile_group ? nb_req : nb) + GEMM_UNIT_WAVES - 1u) / GEMM_UNIT_WAVES;
@@ -1754,15 +1750,7 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
       if (nbu < 1) nbu = 1;
       roles.tiles_per_block = (n_btiles + nbu - 1) / nbu;          // per-class launch: contiguous tile range per workgroup
       const size_t units_lds = (2 * GEMM_MAX_TPB + (size_t)GEMM_UNIT_WAVES * 4096) * sizeof(float);
-      static bool units_attr = false;
-      if (!units_attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_units_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)units_lds);
-        units_attr = true;
-      }
       hipLaunchKernelGGL(gemm_units_kernel, dim3(nbu * roles.n_units), dim3(64 * GEMM_UNIT_WAVES), units_lds, st, roles);
-    } else {
-      const size_t roles_lds = (GEMM_MAX_TPB + (size_t)roles.n_units * 4096) * sizeof(float);
-      hipLaunchKernelGGL(gemm_roles_kernel, dim3(nb), dim3(64 * roles.n_units), roles_lds, st, roles);
     }
   }
   return check_launch("dns_mlp_bwd(weights)");

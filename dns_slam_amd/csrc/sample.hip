@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void raygen_sample_kernel(
     const int64_t* __restrict__ pix_idx, const float* __restrict__ color, const float* __restrict__ depth,
     const float* __restrict__ label, const float* __restrict__ quat, const float* __restrict__ trans, Cam cam,
     BoundD bd, int H, int W, int H0, int W0, int wwin, int n_frames, int npf, const float* __restrict__ t_uniform,
-    const float* __restrict__ t_surf, const float* __restrict__ t_zero, int nu, int ns,
+    const float* __restrict__ t_surf, const float* __restrict__ t_zero, int nu, int ns, int jstride,
     const uint32_t* __restrict__ dmax_ws, float* __restrict__ rays_o, float* __restrict__ rays_d,
     float* __restrict__ gt_color, float* __restrict__ gt_depth, int64_t* __restrict__ gt_label,
     uint8_t* __restrict__ inside, float* __restrict__ z_out, float* __restrict__ pts_out) {
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void raygen_sample_kernel(
   far += 0.01;
   const float dmax = __uint_as_float(dmax_ws[f]);
   uint32_t key[E];
-  sample_and_sort<E>(gd, far, dmax, t_uniform, t_surf, t_zero, nu, ns, lane, key);
+  // jstride = n_surface: frame f has its own jitter rows (the reference draws them per frame, utils/common.py:571,582)
+  sample_and_sort<E>(gd, far, dmax, t_uniform, t_surf + (size_t)f * jstride, t_zero + (size_t)f * jstride, nu, ns, lane, key);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int s = e * 64 + (int)lane;
@@ -221,6 +222,35 @@ __global__ __launch_bounds__(256) void raygen_sample_kernel(
   }
 }
 
+
+// get_sample_uv / select_uv gather + get_rays_from_uv (utils/common.py:248-304), and get_all_rays (:540-559), for a
+// rotation given as a MATRIX (the free functions' signature): one thread per ray.  image [H, W, C] rows are gathered for the
+// drawn pixels (C <= 8: rgb | depth | label).  Same un-fused arithmetic as raygen_sample_kernel (sum(dirs * R, -1)).
+__global__ __launch_bounds__(256) void rays_from_pixels_kernel(const int64_t* __restrict__ pix_idx, const float* __restrict__ image,
+                                                               int C, const float* __restrict__ R, const float* __restrict__ T,
+                                                               Cam cam, int W, int H0, int W0, int wwin, int n,
+                                                               float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                               float* __restrict__ sample, float* __restrict__ ij) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int row, col;
+  float dir[3];
+  pixel_dir(pix_idx ? pix_idx[r] : (int64_t)r, H0, W0, wwin, cam, row, col, dir);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    rays_o[(size_t)r * 3 + a] = T[a];
+    rays_d[(size_t)r * 3 + a] =
+        __fadd_rn(__fadd_rn(__fmul_rn(dir[0], R[3 * a]), __fmul_rn(dir[1], R[3 * a + 1])), __fmul_rn(dir[2], R[3 * a + 2]));
+  }
+  if (sample) {
+    const float* src = image + ((size_t)row * W + col) * C;
+    for (int c = 0; c < C; ++c) sample[(size_t)r * C + c] = src[c];
+  }
+  if (ij) {
+    ij[2 * (size_t)r] = (float)col;
+    ij[2 * (size_t)r + 1] = (float)row;
+  }
+}
 
 // Stand-alone sample_along_rays(gt_depth, n_samples, n_surface, far_bb) (utils/common.py:561): far_bb is an input.
 __global__ void depth_max_flat_kernel(const float* __restrict__ depth, int n, uint32_t* __restrict__ ws) {
@@ -356,7 +386,8 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
                                  const float* quat, const float* trans, const double* cam, const double* bound, int H,
                                  int W, int H0, int H1, int W0, int W1, int n_frames, int n_per_frame,
                                  const float* t_uniform, const float* t_surf, const float* t_zero, int n_uniform,
-                                 int n_surface, uint32_t* depth_max_ws, int depth_max_given, float* rays_o, float* rays_d, float* gt_color,
+                                 int n_surface, int jitter_stride, uint32_t* depth_max_ws, int depth_max_given, float* rays_o,
+                                 float* rays_d, float* gt_color,
                                  float* gt_depth, int64_t* gt_label, uint8_t* inside, float* z, float* pts,
                                  void* stream) {
   DNS_REQUIRE(pix_idx && color && depth && label && quat && trans && cam && bound, "dns_raygen_sample: NULL input");
@@ -365,6 +396,7 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
   DNS_REQUIRE(n_uniform >= 0 && n_surface >= 1 && n_uniform + n_surface <= 256, "dns_raygen_sample: samples per ray %d+%d out of range", n_uniform, n_surface);
   DNS_REQUIRE(n_uniform == 0 || t_uniform, "dns_raygen_sample: t_uniform is NULL");
   DNS_REQUIRE(t_surf && t_zero, "dns_raygen_sample: jitter vectors are NULL");
+  DNS_REQUIRE(jitter_stride == 0 || jitter_stride >= n_surface, "dns_raygen_sample: jitter_stride %d (0 = one pair shared by all frames, else >= n_surface)", jitter_stride);
   const int n = n_frames * n_per_frame;
   if (n <= 0) return DNS_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -384,7 +416,7 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
 #define LAUNCH_RS(E)                                                                                                   \
   hipLaunchKernelGGL(raygen_sample_kernel<E>, grid, block, 0, st, pix_idx, color, depth, label, quat, trans, c, bd, H, \
                      W, H0, W0, wwin, n_frames, n_per_frame, t_uniform, t_surf, t_zero, n_uniform, n_surface,          \
-                     depth_max_ws, rays_o, rays_d, gt_color, gt_depth, gt_label, inside, z, pts)
+                     jitter_stride, depth_max_ws, rays_o, rays_d, gt_color, gt_depth, gt_label, inside, z, pts)
   if (S <= 64) LAUNCH_RS(1);
   else if (S <= 128) LAUNCH_RS(2);
   else LAUNCH_RS(4);
@@ -431,4 +463,19 @@ extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const d
                      n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);
   hipLaunchKernelGGL(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
   return check_launch("dns_raygen_bwd");
+}
+
+extern "C" int dns_rays_from_pixels(const int64_t* pix_idx, const float* image, int C, const float* R, const float* T,
+                                    const double* cam, int H, int W, int H0, int H1, int W0, int W1, int n, float* rays_o,
+                                    float* rays_d, float* sample, float* ij, void* stream) {
+  if (n <= 0) return DNS_OK;
+  DNS_REQUIRE(R && T && cam && rays_o && rays_d, "dns_rays_from_pixels: NULL argument");
+  DNS_REQUIRE(H0 >= 0 && W0 >= 0 && H1 <= H && W1 <= W && H1 > H0 && W1 > W0, "dns_rays_from_pixels: window [%d,%d)x[%d,%d) outside %dx%d", H0, H1, W0, W1, H, W);
+  DNS_REQUIRE(pix_idx || n <= (H1 - H0) * (W1 - W0), "dns_rays_from_pixels: n exceeds the window (pix_idx == NULL means pixel r = ray r)");
+  DNS_REQUIRE(!sample || (image && C >= 1 && C <= 8), "dns_rays_from_pixels: sample rows need image and 1 <= C <= 8");
+  Cam c;
+  c.fx = (float)cam[0]; c.fy = (float)cam[1]; c.cx = (float)cam[2]; c.cy = (float)cam[3];
+  hipLaunchKernelGGL(rays_from_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pix_idx, image, C, R, T,
+                     c, W, H0, W0, W1 - W0, n, rays_o, rays_d, sample, ij);
+  return check_launch("dns_rays_from_pixels");
 }

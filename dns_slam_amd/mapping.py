@@ -74,6 +74,7 @@ class FineDecoderPool(nn.Module):
             self.pool[s].copy_(init.to(self.pool.device))
         self.slot[class_id] = s
         self._lut = None
+        self.lut(0)                                       # host -> device copy NOW: never lazily inside a captured iteration
 
     def lut(self, max_class: int) -> torch.Tensor:
         """class id -> pool row (-1 = no decoder), on device."""
@@ -118,6 +119,9 @@ class Mapper:
         self.pe_dim, self.grid_dim = decoder.pe_dim, decoder.grid_dim
         self.label_layout = label_layout
         self.is_BA = True
+        self.keyframe_dict, self.keyframe_list = [], []  # filled by the caller's frame loop (reference Mapper.run :975,1085)
+        self.keyframe_selector = None                    # optional host-side keyframe choice (set_target_refer_frames)
+        self.encoder = None                              # frozen image stem (dns_slam_amd.encoder.ResNet) or None
         self.dist = None                                 # dns_slam_amd.dist.DistCtx for ray-batch data parallelism
         self.static_shapes = False                       # True: sync-free iteration (hipGraph-capturable)
         self.fused_losses = True                         # one HIP loss pass instead of ~60 torch launches
@@ -126,6 +130,33 @@ class Mapper:
         self.exist_decoders: Dict[int, int] = {}
         self.class2label_dict = cfg.get("class2label_dict", None)
         self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
+        # Device constants of the sync-free iteration are built HERE, not lazily in the first iteration: a pageable
+        # host -> device copy (tensor.to(device)) is not capturable -- issued by the first iteration inside a hipGraph
+        # capture it invalidates the capture (round-1 segfault in capture_end, DESIGN.md section 4 "stream capture").
+        if str(device) != "cpu":
+            self._jitter_consts()
+            self._ensure_lattice(tr.get("smooth_pts", 64), 0.1, 0.05)
+
+    def _jitter_consts(self):
+        ns = self.n_surface_ray
+        if getattr(self, "_force_mask", None) is None or self._force_mask.numel() != ns:
+            self._force_mask = torch.arange(ns, device=self.device) == (ns // 2 + 1)
+            self._half = torch.full((ns,), 0.5, device=self.device)
+
+    def _ensure_lattice(self, sample_points, voxel_size, margin):
+        n = sample_points - 1
+        key = (n, voxel_size, margin, str(self.device))
+        if getattr(self, "_lattice_key", None) != key:
+            bd = self.bound_dev
+            grid_size = (sample_points - 1) * voxel_size
+            self._offset_max = bd[:, 1] - bd[:, 0] - grid_size - 2 * margin                              # float64, on device
+            ar = torch.arange(0, n, dtype=torch.long, device=self.device)
+            gx, gy, gz = torch.meshgrid(ar, ar, ar, indexing="ij")
+            self._lattice = torch.stack([gx, gy, gz], dim=-1).to(torch.float64)
+            d = bd[:, 1] - bd[:, 0]
+            self._lattice_consts = (key, voxel_size / d, self._offset_max / d, margin / d)
+            self._lattice_key = key
+        return key
 
     # ------------------------------------------------------------------ losses (slams/mapping.py:110-126)
     def compute_photometric_loss(self, gt_color, pred_color):
@@ -146,22 +177,10 @@ class Mapper:
     # ------------------------------------------------------------------ slams/mapping.py:129-159
     def smoothness(self, sample_points=64, voxel_size=0.1, margin=0.05, u_offset=None, u_jitter=None):
         n = sample_points - 1
-        key = (n, voxel_size, margin, str(self.device))
-        if getattr(self, "_lattice_key", None) != key:
-            bound = self.bound
-            grid_size = (sample_points - 1) * voxel_size
-            self._offset_max = (bound[:, 1] - bound[:, 0] - grid_size - 2 * margin).to(self.device)     # float64
-            ar = torch.arange(0, n, dtype=torch.long)
-            gx, gy, gz = torch.meshgrid(ar, ar, ar, indexing="ij")
-            self._lattice = torch.stack([gx, gy, gz], dim=-1).to(torch.float64).to(self.device)
-            self._lattice_key = key
+        self._ensure_lattice(sample_points, voxel_size, margin)
         if u_offset is None and u_jitter is None and self.static_shapes:
             # sync-free iteration: the same fp64 affine map, folded to  pts = lattice * A + B  with
             # A = voxel / (b1 - b0),  B = (jitter * voxel + offset) / (b1 - b0)  -- 6 launches instead of 14
-            if getattr(self, "_lattice_consts", None) is None or self._lattice_consts[0] != key:
-                bd = self.bound_dev
-                d = bd[:, 1] - bd[:, 0]
-                self._lattice_consts = (key, voxel_size / d, self._offset_max / d, margin / d)
             _, c_vox, c_off, c_mar = self._lattice_consts
             r = getattr(self, "_lattice_r6", None) if getattr(self, "prefetch_draws", False) else None
             self._lattice_r6 = None
@@ -299,10 +318,12 @@ class Mapper:
         iteration (the lattice draw is taken with the others)."""
         main = torch.cuda.current_stream()
         pend = getattr(self, "_pending_draws", None)
+        if pend is not None and pend[2] is not prep:
+            pend = None                                  # drawn from another optimize()'s class tables: drop them
         if pend is None:
             cur = self._draw_all(prep)
         else:
-            cur, ev = pend
+            cur, ev, _ = pend
             main.wait_event(ev)
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
@@ -318,7 +339,7 @@ class Mapper:
             ev.record(side)
         for t in (nxt["pix"], nxt["jitter"][0], nxt["jitter"][1], nxt["r6"]):
             t.record_stream(main)
-        self._pending_draws = (nxt, ev)
+        self._pending_draws = (nxt, ev, prep)
         self._lattice_r6 = cur["r6"]
         return cur
 
@@ -332,33 +353,41 @@ class Mapper:
         i2 = prep["sorted_flat"][prep["starts_flat"] + j]
         return torch.cat((i1, i2), 1).reshape(-1)
 
-    def draw_jitter(self):
-        """The two draws of sample_along_rays (utils/common.py:571-574,582), forced 0.5 included.  Reference: CPU
-        generator then .to(device); with ``static_shapes`` they come from the device generator (no host work, so
-        the whole iteration can be captured in a hipGraph) and the forced 0.5 is a device-side select."""
+    def draw_jitter(self, n_frames=None):
+        """The two draws of sample_along_rays (utils/common.py:571-574,582), forced 0.5 included, ONE PAIR PER FRAME as in
+        the reference (get_target_samples calls sample_along_rays per target frame, slams/mapping.py:530): returns
+        (t_surf, t_zero), each [n_frames, n_surface]; the K frames still sample in one launch (the kernel reads its frame's
+        rows).  ``self.shared_jitter = True`` returns one [n_surface] pair shared by the frames (round-1 behaviour, kept as
+        a benchmark option).  Reference: CPU generator then .to(device); with ``static_shapes`` the draws come from the
+        device generator (no host work: the iteration can be captured in a hipGraph) and the forced 0.5 is a select."""
         ns = self.n_surface_ray
+        K = self.n_target_frame if n_frames is None else n_frames
+        shared = getattr(self, "shared_jitter", False)
         if self.static_shapes:
-            if getattr(self, "_force_mask", None) is None or self._force_mask.numel() != ns:
-                m = torch.zeros(ns, dtype=torch.bool)
-                m[ns // 2 + 1] = True
-                self._force_mask = m.to(self.device)
-                self._half = torch.full((ns,), 0.5, device=self.device)
+            self._jitter_consts()
             # the reference forces t[ns//2+1] = 0.5 only when no draw equals 0.5 exactly (probability ~2e-6 per call with
             # float32 draws); the sync-free path always forces it: one select instead of a reduction + three more launches
-            r = torch.rand(2, ns, device=self.device)
+            if shared:
+                r = torch.rand(2, ns, device=self.device)
+                return torch.where(self._force_mask, self._half, r[0]), r[1]
+            r = torch.rand(2, K, ns, device=self.device)
             return torch.where(self._force_mask, self._half, r[0]), r[1]
-        t = torch.rand(ns)
-        if not torch.any(t == 0.5):
-            t[ns // 2 + 1] = 0.5
-        t0 = torch.rand(ns)
-        return t.to(self.device), t0.to(self.device)
+        ts, t0s = [], []
+        for _ in range(1 if shared else K):                 # per frame: rand(ns), forced 0.5, rand(ns) -- the reference's order
+            t = torch.rand(ns)
+            if not torch.any(t == 0.5):
+                t[ns // 2 + 1] = 0.5
+            ts.append(t)
+            t0s.append(torch.rand(ns))
+        if shared:
+            return ts[0].to(self.device), t0s[0].to(self.device)
+        return torch.stack(ts).to(self.device), torch.stack(t0s).to(self.device)
 
     # ------------------------------------------------------------------ slams/mapping.py:471-588
     def get_target_samples(self, target_frames, quad_list, T_list, refer_frames=None, features=None,
                            prep=None, pix_idx=None, jitter=None):
-        """All K frames in one launch.  NB ``sample_along_rays`` is called once per frame in the reference with
-        fresh jitter each time; here one jitter pair is shared by the K frames of an iteration unless ``jitter`` is
-        a list of K pairs."""
+        """All K frames in one launch.  ``jitter`` = (t_surf, t_zero), each [K, n_surface] (one pair per frame, as the
+        reference draws them) or [n_surface] (shared by the frames); a list of K pairs is accepted too."""
         if prep is None:
             prep = self.prepare_frames(target_frames)
         K = self.n_target_frame
@@ -375,21 +404,15 @@ class Mapper:
         if jitter is None:
             jitter = self.draw_jitter()
         if isinstance(jitter, (list,)) and len(jitter) == K and isinstance(jitter[0], (tuple, list)):
-            parts = []
-            for f in range(K):
-                parts.append(ops.raygen_sample(quat[f:f + 1], trans[f:f + 1], pix_idx[f * npf:(f + 1) * npf].contiguous(),
-                                               prep["color"][f:f + 1], prep["depth"][f:f + 1], prep["label"][f:f + 1],
-                                               cam, self.bound, window, npf, self.t_uniform, jitter[f][0], jitter[f][1]))
-            res = [torch.cat([p[i] for p in parts], 0) for i in range(8)]
-        else:
-            dmax = None
-            if self.dist is not None and self.dist.enabled:
-                # batch-global max(gt_depth) of sample_along_rays (utils/common.py:581,591): over ALL ranks' rays of a frame
-                dflat = prep["depth"].reshape(K, -1)
-                dmax = torch.gather(dflat, 1, pix_idx.reshape(K, npf)).amax(dim=1).clamp_min(0.0)
-                self.dist.allreduce_max(dmax)
-            res = ops.raygen_sample(quat, trans, pix_idx, prep["color"], prep["depth"], prep["label"], cam, self.bound,
-                                    window, npf, self.t_uniform, jitter[0], jitter[1], depth_max=dmax)
+            jitter = (torch.stack([j[0] for j in jitter]), torch.stack([j[1] for j in jitter]))
+        dmax = None
+        if self.dist is not None and self.dist.enabled:
+            # batch-global max(gt_depth) of sample_along_rays (utils/common.py:581,591): over ALL ranks' rays of a frame
+            dflat = prep["depth"].reshape(K, -1)
+            dmax = torch.gather(dflat, 1, pix_idx.reshape(K, npf)).amax(dim=1).clamp_min(0.0)
+            self.dist.allreduce_max(dmax)
+        res = ops.raygen_sample(quat, trans, pix_idx, prep["color"], prep["depth"], prep["label"], cam, self.bound,
+                                window, npf, self.t_uniform, jitter[0].contiguous(), jitter[1].contiguous(), depth_max=dmax)
         rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = res
         N, S = z.shape
         if features is None:
@@ -571,7 +594,7 @@ class Mapper:
         trans = cur_c2w[:3, 3].to(dev).float()[None]
         f = lambda t: t.to(dev).float().contiguous()[None]
         if jitter is None:
-            jitter = self.draw_jitter()
+            jitter = self.draw_jitter(1)
         pix = torch.arange(H * W, device=dev)
         rays_o, rays_d, pts, gt_color, gt_depth, gt_label, inside, z = ops.raygen_sample(
             quat, trans, pix, f(cur_gt_color), f(cur_gt_depth), f(cur_gt_label), (self.fx, self.fy, self.cx, self.cy),
@@ -580,7 +603,14 @@ class Mapper:
         colors, depths, labels = [], [], []
         for start in range(0, H * W, n_pts_batch):
             end = min(start + n_pts_batch, H * W)
-            code = torch.zeros(end - start, S, self.hidden_dim, device=dev) if features is None else features[start:end]
+            if features is None:
+                # one read-only block of zeros per chunk SHAPE (a fresh 537 MB fill per 65 536-ray chunk otherwise)
+                code = getattr(self, "_zero_code_rf", None)
+                if code is None or code.shape[0] < end - start or code.shape[1:] != (S, self.hidden_dim):
+                    code = self._zero_code_rf = torch.zeros(min(n_pts_batch, H * W), S, self.hidden_dim, device=dev)
+                code = code[:end - start]
+            else:
+                code = features[start:end]
             samples = {"rays_o": rays_o[start:end], "rays_d": rays_d[start:end], "gt_label": gt_label[start:end],
                        "pts": pts[start:end], "z_vals": z[start:end], "features": code}
             color, depth, _, logits, _, _ = self.renderer(samples, strict=False)
@@ -675,7 +705,7 @@ class Mapper:
             optimizer.zero_grad()
             u = torch.rand(starts.numel(), device=dev, dtype=torch.float64)
             pix = order[starts + torch.minimum((u * counts).to(torch.int64), counts - 1)]
-            jit = self.draw_jitter()
+            jit = self.draw_jitter(1)
             rays_o, rays_d, pts, gc, gd, gl, inside, z = ops.raygen_sample(
                 quat, trans, pix, color, depth, label, (self.fx, self.fy, self.cx, self.cy), self.bound,
                 (0, self.H, 0, self.W), pix.numel(), self.t_uniform, jit[0], jit[1])
@@ -689,10 +719,91 @@ class Mapper:
             optimizer.step()
         return loss
 
+    # ------------------------------------------------------------------ slams/mapping.py:329-435
+    def set_target_refer_frames(self, cur_gt_color, cur_gt_depth, cur_gt_label, cur_gt_c2w, cur_c2w):
+        """Target / reference frame bundles of one ``optimize()`` call from ``self.keyframe_dict`` / ``self.keyframe_list``
+        (filled by the caller's frame loop, reference ``Mapper.run`` :975,1085) -- the data layout of the reference's
+        function, which is what the hot path consumes.  WHICH old keyframes join is host-side control flow outside the path
+        (component 4): ``self.keyframe_selector(cur_color, cur_depth, cur_c2w, keyframe_dict[:-1], k)``
+        if set (e.g. the reference's overlap test :171-236), else the reference's 'global' mode -- k uniform draws with
+        replacement (``random_select`` :160-168).  Always joined: the latest keyframe and the current frame (index -1);
+        keyframe 0 never is (:361).  Per target frame two reference keyframes (its neighbours) plus itself (:399-419)."""
+        import numpy as np
+        kfs, n_kf = self.keyframe_dict, len(self.keyframe_list)
+        n_joint = self.cfg["mapping"]["n_joint_optimize_frames"]
+        k = min(n_joint - 2, n_kf)
+        picked = []
+        if n_kf >= 2:
+            if getattr(self, "keyframe_selector", None) is not None:
+                picked = list(self.keyframe_selector(cur_gt_color, cur_gt_depth, cur_c2w, kfs[:-1], k))
+            else:
+                picked = [int(v) for v in np.random.choice(np.arange(n_kf - 1), size=k, replace=True)] if n_kf - 1 > 0 else [0]
+            picked = sorted({int(i) for i in picked + [n_kf - 1]} - {0})
+        target_idx = picked + [-1]
+        self.n_target_frame = len(target_idx)
+        dev = self.device
+        cur = {"gt_color": cur_gt_color, "gt_depth": cur_gt_depth, "gt_label": cur_gt_label, "gt_c2w": cur_gt_c2w,
+               "est_c2w": cur_c2w}
+        tgt = {key: [] for key in cur}
+        ref_color, ref_c2w, ref_idx, labels = [], [], [], []
+        last = n_kf - 1
+        for t in target_idx:
+            src = cur if t == -1 else kfs[t]
+            for key in tgt:
+                v = src[key].to(dev)
+                tgt[key].append(v if key == "gt_label" else v.float())
+            labels.append(torch.unique(tgt["gt_label"][-1], sorted=True))
+            if t == -1:
+                pair = [max(last - 1, 0), max(last, 0)]
+            elif t == last:
+                pair = [max(last - 2, 0), max(last - 1, 0)]
+            else:
+                pair = [max(t - 1, 0), t + 1]
+            ref_color.append(torch.stack([kfs[r]["gt_color"].to(dev).float() for r in pair] + [tgt["gt_color"][-1]], 0))
+            ref_c2w.append(torch.stack([kfs[r]["est_c2w"].to(dev).float() for r in pair] + [tgt["est_c2w"][-1]], 0))
+            ref_idx.append(pair + [-1])
+        target_frames = {key: torch.stack(v, 0) for key, v in tgt.items()}
+        target_frames["label_dict"] = torch.unique(torch.cat(labels, 0), sorted=True).cpu().int().numpy()
+        target_frames["kf_idx"] = target_idx
+        refer_frames = {"gt_color": torch.stack(ref_color, 0), "est_c2w": torch.stack(ref_c2w, 0), "kf_idx": ref_idx}
+        return target_idx, target_frames, refer_frames
+
     # ------------------------------------------------------------------ slams/mapping.py:839-949
-    def optimize(self, n_iters, cur_idx, target_frames, features=None, smooth=True):
-        """Iteration driver.  ``target_frames`` is what ``set_target_refer_frames`` (:329, host-side keyframe
-        bookkeeping, out of scope) returns: gt_color/gt_depth/gt_label per frame, est_c2w, label_dict."""
+    def optimize(self, n_iters, cur_idx, cur_gt_color, cur_gt_depth=None, cur_gt_label=None, cur_gt_c2w=None, cur_c2w=None,
+                 **kw):
+        """The reference's signature and return value (slams/mapping.py:839): ``optimize(n_iters, idx, color, depth,
+        label, gt_c2w, cur_c2w) -> (cur_c2w [4,4], fine_loss_dict)`` with keys loss_camera_tensor, p_loss, d_loss,
+        l_loss, lt_loss, smooth_loss; refined keyframe poses are written back into ``self.keyframe_dict`` (:914-926).
+        The frame bundles come from ``set_target_refer_frames``; the frozen image stem ``self.encoder`` (:846) runs once
+        per call when set (else the 2-D code is zero).  ``optimize(n_iters, idx, target_frames_dict)`` -- the bundle given
+        directly -- is accepted too and is what ``optimize_frames`` takes."""
+        if isinstance(cur_gt_color, dict):
+            return self.optimize_frames(n_iters, cur_idx, cur_gt_color, **kw)
+        target_idx, target_frames, refer_frames = self.set_target_refer_frames(cur_gt_color, cur_gt_depth, cur_gt_label,
+                                                                              cur_gt_c2w, cur_c2w)
+        features = None
+        if getattr(self, "encoder", None) is not None:
+            features = self.encoder(refer_frames["gt_color"]).clone().detach()
+        c2w, terms = self.optimize_frames(n_iters, cur_idx, target_frames, features=features, refer_frames=refer_frames, **kw)
+        cam_err = 0.0
+        cam7 = lambda m: torch.cat((get_quad_from_c2w(m), torch.as_tensor(m)[:3, 3].detach().float().cpu()), 0)
+        if self.is_BA:
+            for i in range(1, len(target_idx) - 1):
+                kf = self.keyframe_dict[target_idx[i]]
+                kf["est_c2w"] = target_frames["est_c2w"][i].clone()
+                est = torch.cat((self.last_quad_list[i].detach(), self.last_T_list[i].detach()), 0).cpu()
+                cam_err += float(torch.abs(cam7(kf["gt_c2w"]) - est).mean())
+        est = torch.cat((self.last_quad_list[-1].detach(), self.last_T_list[-1].detach()), 0).cpu()
+        cam_err = (cam_err + float(torch.abs(cam7(cur_gt_c2w) - est).mean())) / len(target_idx)
+        out = {"loss_camera_tensor": cam_err}
+        out.update({key: terms[key] for key in ("p_loss", "d_loss", "l_loss", "lt_loss", "smooth_loss") if key in terms})
+        return c2w, out
+
+    def optimize_frames(self, n_iters, cur_idx, target_frames, features=None, smooth=True, refer_frames=None):
+        """Iteration driver on a given bundle: ``target_frames`` is what ``set_target_refer_frames`` returns
+        (gt_color / gt_depth / gt_label per frame, est_c2w, label_dict, kf_idx); with stem ``features``
+        [n_target, n_refer, C, h, w] and ``refer_frames`` the 2-D branch runs inside every iteration (:533-551)."""
+        self.n_target_frame = len(target_frames["gt_color"])
         self.is_BA = cur_idx >= self.start_optimize_idx
         new_decoder_idx = self.set_decoder(target_frames)
         if len(new_decoder_idx) > 0 and cur_idx > 50:                   # :857-868 (first_frame_optimized is the caller's state)
@@ -711,7 +822,8 @@ class Mapper:
         terms = {}
         for iter_ in range(n_iters):
             optimizer.zero_grad()
-            samples = self.get_target_samples(target_frames, quad_list, T_list, features=features, prep=prep)
+            samples = self.get_target_samples(target_frames, quad_list, T_list, refer_frames=refer_frames, features=features,
+                                              prep=prep)
             if len(new_decoder_idx) > 0:
                 lambda_lt = 10 if iter_ > n_iters // 2 else 0
             else:

@@ -24,7 +24,8 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._raw, name)
-        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_last_error", "dns_abi_version"):
+        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_last_error",
+                                            "dns_abi_version", "dns_init"):
             return fn
 
         ui = self._UNITS_ARG.get(name)
@@ -43,6 +44,7 @@ class _TimedLib:
     # argument index holding the number of units (points / slots / rays) a launch processes
     _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 12, "dns_mlp_bwd": 18,
                   "dns_composite_fwd": 3, "dns_composite_bwd": 3, "dns_raygen_sample": (14, 15), "dns_raygen_bwd": (7, 8),
+                  "dns_rays_from_pixels": 12,
                   "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5)}
 
     def arm(self):
@@ -114,6 +116,12 @@ def _bound6(bound) -> Optional[C.Array]:
 
 
 # ----------------------------------------------------------------------------- encoding
+# (form, queue_cap) of the table-gradient scatter, include/dns_hip.h DNS_SCATTER_*: 0 auto, 1 per-corner atomics (tcnn's
+# form), 2 LDS bins for every level, 3 per-chunk queues for every multi-chunk level; queue_cap 0 = sized by the library
+SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED, SCATTER_QUEUES = 0, 1, 2, 3
+SCATTER_FORM = (SCATTER_AUTO, 0)
+
+
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, table, meta: Optional[GridMeta], bound, n_bins: int, want_pe: bool, want_grid: bool):
@@ -149,11 +157,12 @@ class _EncodeFn(torch.autograd.Function):
         d_table = torch.zeros_like(table) if need_t else None
         d_pe = ptr(d_out) if ctx.pe_dim else None
         d_grid = C.c_void_p(d_out.data_ptr() + 4 * ctx.pe_dim) if ctx.g_dim else None
-        ws = torch.empty(int(lib.dns_encode_bwd_ws_floats(P, C.byref(ctx.meta.c))), device=x.device,
+        form, cap = SCATTER_FORM
+        ws = torch.empty(int(lib.dns_encode_bwd_ws_floats(P, C.byref(ctx.meta.c), form, cap)), device=x.device,
                          dtype=torch.float32) if need_t else None
         check(lib.dns_encode_bwd(ptr(x), ctx.b6, P, ctx.n_bins, ptr(table) if ctx.g_dim else None,
                                  C.byref(ctx.meta.c) if ctx.g_dim else None, d_pe, ld, d_grid, ld,
-                                 ptr(d_table), ptr(d_x), ptr(ws), stream_ptr()), "dns_encode_bwd")
+                                 ptr(d_table), ptr(d_x), ptr(ws), form, cap, stream_ptr()), "dns_encode_bwd")
         return d_x, d_table, None, None, None, None, None
 
 
@@ -511,7 +520,10 @@ class _RaygenFn(torch.autograd.Function):
         H0, H1, W0, W1 = window
         n = K * npf
         nu = 0 if t_uniform is None else t_uniform.numel()
-        ns = t_surf.numel()
+        ns = t_surf.shape[-1]
+        if t_surf.dim() == 2 and (t_surf.shape != (K, ns) or t_zero.shape != (K, ns)):
+            raise ValueError("per-frame jitter must be [K, n_surface] for both draws")
+        jstride = ns if t_surf.dim() == 2 else 0               # [K, ns]: frame f samples with its own jitter rows
         S = nu + ns
         dev = quat.device
         quat = quat.contiguous().float()
@@ -531,7 +543,7 @@ class _RaygenFn(torch.autograd.Function):
         camv = (C.c_double * 4)(*[float(v) for v in cam])
         b6 = _bound6(bound)
         check(lib.dns_raygen_sample(ptr(pix_idx), ptr(color), ptr(depth), ptr(label), ptr(quat), ptr(trans), camv, b6,
-                                    H, W, H0, H1, W0, W1, K, npf, ptr(t_uniform), ptr(t_surf), ptr(t_zero), nu, ns,
+                                    H, W, H0, H1, W0, W1, K, npf, ptr(t_uniform), ptr(t_surf), ptr(t_zero), nu, ns, jstride,
                                     ptr(ws), 0 if depth_max is None else 1, ptr(rays_o), ptr(rays_d), ptr(gt_color),
                                     ptr(gt_depth), ptr(gt_label),
                                     ptr(inside), ptr(z), ptr(pts), stream_ptr()), "dns_raygen_sample")
@@ -563,6 +575,60 @@ def raygen_sample(quat, trans, pix_idx, color, depth, label, cam, bound, window,
     cam=(fx,fy,cx,cy), bound [3,2] fp64, window=(H0,H1,W0,W1)."""
     return _RaygenFn.apply(quat, trans, pix_idx, color, depth, label, tuple(cam), bound, tuple(window), n_per_frame,
                            t_uniform, t_surf, t_zero, depth_max)
+
+
+class _RaysFromPixelsFn(torch.autograd.Function):
+    """rays_o, rays_d, sample rows for given pixel indices and a rotation MATRIX (get_rays_from_uv, utils/common.py:248-264).
+    The backward (dL/dR = sum_n dL/dd_n (x) dir_n, dL/dT = sum_n dL/do_n: SURVEY A1) is two [n,3]-sized reductions; they are
+    plain torch on purpose -- this node only serves callers of the reference's free functions (Mesher, eval_2d: no
+    gradient); the optimise steps differentiate the pose through dns_raygen_bwd."""
+
+    @staticmethod
+    def forward(ctx, R, T, pix_idx, image, cam, hw, window):
+        require_cuda(R, T, pix_idx, image)
+        H, W = hw
+        H0, H1, W0, W1 = window
+        dev = R.device
+        n = (H1 - H0) * (W1 - W0) if pix_idx is None else pix_idx.numel()
+        Rc, Tc = R.detach().contiguous().float(), T.detach().contiguous().float()
+        Cn = 0 if image is None else image.shape[-1]
+        rays_o = torch.empty(n, 3, device=dev)
+        rays_d = torch.empty(n, 3, device=dev)
+        sample = torch.empty(n, Cn, device=dev) if Cn else None
+        ij = torch.empty(n, 2, device=dev)
+        camv = (C.c_double * 4)(*[float(v) for v in cam])
+        check(lib.dns_rays_from_pixels(ptr(pix_idx), ptr(image), Cn, ptr(Rc), ptr(Tc), camv, H, W, H0, H1, W0, W1, n,
+                                       ptr(rays_o), ptr(rays_d), ptr(sample), ptr(ij), stream_ptr()), "dns_rays_from_pixels")
+        ctx.save_for_backward(ij)
+        ctx.cam = tuple(float(v) for v in cam)
+        ctx.mark_non_differentiable(ij)
+        if sample is None:
+            sample = rays_o.new_zeros(n, 0)
+        ctx.mark_non_differentiable(sample)
+        ctx.set_materialize_grads(False)
+        return rays_o, rays_d, sample, ij
+
+    @staticmethod
+    def backward(ctx, d_ro, d_rd, _ds, _dij):
+        ij, = ctx.saved_tensors
+        fx, fy, cx, cy = ctx.cam
+        d_R = d_T = None
+        if d_rd is not None and ctx.needs_input_grad[0]:
+            dirs = torch.stack(((ij[:, 0] - cx) / fx, -(ij[:, 1] - cy) / fy, -torch.ones_like(ij[:, 0])), -1)
+            d_R = d_rd.t() @ dirs
+        if d_ro is not None and ctx.needs_input_grad[1]:
+            d_T = d_ro.sum(0)
+        return d_R, d_T, None, None, None, None, None
+
+
+def rays_from_pixels(R, T, pix_idx, image, cam, hw, window):
+    """R [3,3], T [3] (device), pix_idx [n] int64 window-flat (None = every pixel of the window in row-major order),
+    image [H,W,C] or None, cam=(fx,fy,cx,cy), hw=(H,W), window=(H0,H1,W0,W1) -> rays_o, rays_d [n,3], sample [n,C], ij [n,2]."""
+    if image is not None:
+        image = image.contiguous().float()
+    if pix_idx is not None:
+        pix_idx = pix_idx.contiguous()
+    return _RaysFromPixelsFn.apply(R.contiguous(), T.contiguous(), pix_idx, image, tuple(cam), tuple(hw), tuple(window))
 
 
 def sample_along_rays(gt_depth, far_bb, t_uniform, t_surf, t_zero):

@@ -37,6 +37,14 @@ class Tracker:
         self.border = 20
         self.static_shapes = False        # True: device-side jitter draws, no host work per iteration (hipGraph-capturable)
         self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
+        if str(device) != "cpu":
+            self._jitter_consts()                 # built on the device now: nothing is copied host -> device inside a capture
+
+    def _jitter_consts(self):
+        ns = self.n_surface_ray
+        if getattr(self, "_force_mask", None) is None or self._force_mask.numel() != ns:
+            self._force_mask = torch.arange(ns, device=self.device) == (ns // 2 + 1)
+            self._half = torch.full((ns,), 0.5, device=self.device)
 
     # slams/tracking.py:85-96 -- masked means written as weighted sums (no boolean-mask gather / host sync)
     def compute_photometric_loss(self, gt_color, pred_color, mask):
@@ -71,11 +79,7 @@ class Tracker:
     def draw_jitter(self):
         ns = self.n_surface_ray
         if self.static_shapes:
-            if getattr(self, "_force_mask", None) is None or self._force_mask.numel() != ns:
-                m = torch.zeros(ns, dtype=torch.bool)
-                m[ns // 2 + 1] = True
-                self._force_mask = m.to(self.device)
-                self._half = torch.full((ns,), 0.5, device=self.device)
+            self._jitter_consts()
             t = torch.rand(ns, device=self.device)
             t = torch.where(self._force_mask & ~(t == 0.5).any(), self._half, t)
             return t, torch.rand(ns, device=self.device)
@@ -149,14 +153,14 @@ class Tracker:
                 p.requires_grad_(True)
 
     # slams/tracking.py:313-340
-    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None, fused=False, graph=False):
+    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None, fused=False, graph=False, graph_warmup=0):
         """Optimise (quat, T) of one frame against the frozen scene; returns the best-loss camera tensor [7].
         ``graph=True`` captures ONE iteration (sampling, render, losses, backward, fused Adam, keep-best) into a hipGraph
         and replays it n_iters times: tracking is 30-50 tiny latency-bound iterations per frame."""
         n_iters = self.n_iters if n_iters is None else n_iters
         with self.frozen_scene():
             if graph:
-                return self._track_frame_graphed(cur_frames, est_c2w, n_iters, features)
+                return self._track_frame_graphed(cur_frames, est_c2w, n_iters, features, graph_warmup)
             return self._track_frame_eager(cur_frames, est_c2w, n_iters, features, fused)
 
     def _track_frame_eager(self, cur_frames, est_c2w, n_iters, features, fused):
@@ -179,9 +183,12 @@ class Tracker:
                 best_cam = torch.where(better, torch.cat((quad, T), 0).detach(), best_cam)
             loss.backward()
             optimizer.step()
+        self.last_optimizer = optimizer
         return best_cam, best_loss
 
-    def _track_frame_graphed(self, cur_frames, est_c2w, n_iters, features):
+    def _track_frame_graphed(self, cur_frames, est_c2w, n_iters, features, warmup=0):
+        from ._lib import ensure_init
+        ensure_init()                                    # kernel attributes are set outside the capture (dns_init)
         self.static_shapes = True
         optimizer, quad, T = self.set_optimizer(est_c2w, fused=True)
         frames = dict(cur_frames)
@@ -203,23 +210,25 @@ class Tracker:
             loss.backward()
             optimizer.step()
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        saved = (quad.detach().clone(), T.detach().clone())
-        with torch.cuda.stream(side):
-            for _ in range(2):                           # warm-up (allocator, lazy kernel attributes), then rewind
-                one_iter()
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            quad.copy_(saved[0]); T.copy_(saved[1])
-            for m, v in optimizer.state.values():
-                m.zero_(); v.zero_()
-            optimizer._dev_state.zero_()
-            state["best_loss"].fill_(float("inf"))
-            state["best_cam"].copy_(torch.cat((quad, T), 0))
+        if warmup > 0:                                   # optional eager iterations on a side stream, then rewind
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            saved = (quad.detach().clone(), T.detach().clone())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    one_iter()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():
+                quad.copy_(saved[0]); T.copy_(saved[1])
+                for m, v in optimizer.state.values():
+                    m.zero_(); v.zero_()
+                optimizer._dev_state.zero_()
+                state["best_loss"].fill_(float("inf"))
+                state["best_cam"].copy_(torch.cat((quad, T), 0))
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g):                        # records one iteration; nothing executes during capture
             one_iter()
-        for _ in range(n_iters - 1):
+        for _ in range(n_iters):                         # n_iters optimiser steps, like the eager loop and the reference
             g.replay()
+        self.last_optimizer = optimizer
         return state["best_cam"], state["best_loss"]

@@ -26,12 +26,13 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 3
+#define DNS_ABI_VERSION 4
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
 #define DNS_E_ARG (-1)      /* bad argument / unsupported shape */
 #define DNS_E_LAUNCH (-2)   /* HIP launch error */
+#define DNS_E_STATE (-3)    /* call refused in the current state (first use on a device inside a stream capture) */
 
 /* Multi-resolution hash-grid level table (tcnn GridEncoding constructor; reference call site
  * models/pos_encoding.py:31-46).  Built once on the host by dns_grid_meta_init and passed by
@@ -53,6 +54,14 @@ typedef struct DnsGridMeta {
 int dns_abi_version(void);
 const char* dns_last_error(void);
 
+/* One-time set-up of the CURRENT device: raises the dynamic-LDS limit of every kernel that stages more than 64 KB
+ * (hipFuncSetAttribute -- a context-level call that is illegal while a stream is being captured and pointless per launch).
+ * Idempotent and thread-safe.  Entry points call it implicitly on their first use on a device; inside a stream capture
+ * that first use is refused with DNS_E_STATE instead, so a caller that captures hipGraphs (the reference's loops
+ * slams/mapping.py:881-910, slams/tracking.py:313-340 replayed from a graph) calls dns_init() once after selecting the
+ * device. */
+int dns_init(void);
+
 /* [host] fills *meta.  per_level_scale is the float64 value reference pos_encoding.py:33 computes. */
 int dns_grid_meta_init(DnsGridMeta* meta, uint32_t n_levels, uint32_t n_features,
                        uint32_t log2_hashmap_size, uint32_t base_resolution, double per_level_scale);
@@ -67,7 +76,9 @@ int dns_grid_meta_init(DnsGridMeta* meta, uint32_t n_levels, uint32_t n_features
  * pix_idx: flat index inside the window [H0,H1)x[W0,W1).  color [K,H,W,3], depth [K,H,W],
  * label [K,H,W] fp32.  quat [K,4] (w,x,y,z), trans [K,3].  cam = fx,fy,cx,cy [host].
  * bound [host] = 6 doubles b0x,b1x,b0y,b1y,b0z,b1z.  t_uniform [n_uniform] = linspace(0,1),
- * t_surf / t_zero [n_surface] the two jitter draws (t_surf already holds the forced 0.5).
+ * t_surf / t_zero the two jitter draws (t_surf already holds the forced 0.5): jitter_stride = 0 -> [n_surface], one
+ * pair shared by the K frames; jitter_stride >= n_surface -> [K, jitter_stride], frame f reads its own row (the reference
+ * calls sample_along_rays once per frame with fresh draws, slams/mapping.py:530).
  * depth_max_ws: K uint32 (bit patterns of the per-frame max sampled depth): scratch when depth_max_given == 0; when
  * depth_max_given != 0 the caller has filled it (multi-GPU: the max over ALL ranks' rays of the frame).  Outputs: rays_o,rays_d,gt_color [n,3], gt_depth [n],
  * gt_label [n] int64, inside [n] uint8 (far_bb >= depth, before the +0.01), z [n, n_uniform+n_surface]
@@ -76,10 +87,20 @@ int dns_raygen_sample(const int64_t* pix_idx, const float* color, const float* d
                       const float* quat, const float* trans, const double* cam, const double* bound,
                       int H, int W, int H0, int H1, int W0, int W1, int n_frames, int n_per_frame,
                       const float* t_uniform, const float* t_surf, const float* t_zero,
-                      int n_uniform, int n_surface, uint32_t* depth_max_ws, int depth_max_given,
+                      int n_uniform, int n_surface, int jitter_stride, uint32_t* depth_max_ws, int depth_max_given,
                       float* rays_o, float* rays_d, float* gt_color, float* gt_depth, int64_t* gt_label,
                       uint8_t* inside, float* z, float* pts /* [n,S,3] = o + d*z (slams/mapping.py:531), NULL = skip */,
                       void* stream);
+
+/* The free functions get_samples / get_samples_by_class / get_samples_by_uniq_class (utils/common.py:296-304,353-403:
+ * the gather of select_uv / select_by_class :266-338 + get_rays_from_uv :248-264) and get_all_rays (:540-559), which take
+ * the rotation as a MATRIX: n rays from the window [H0,H1)x[W0,W1) of ONE image.  pix_idx [n] window-flat indices (NULL:
+ * ray r = pixel r, the whole-window order of get_all_rays); image [H,W,C] fp32 (C <= 8: rgb | depth | label; NULL with
+ * sample NULL); R [9] row-major, T [3] on the DEVICE; cam [host] fx,fy,cx,cy.  Outputs rays_o, rays_d [n,3], sample [n,C]
+ * (NULL = skip), ij [n,2] = (column, row) as fp32 like the reference's i, j (NULL = skip). */
+int dns_rays_from_pixels(const int64_t* pix_idx, const float* image, int C, const float* R, const float* T,
+                         const double* cam, int H, int W, int H0, int H1, int W0, int W1, int n,
+                         float* rays_o, float* rays_d, float* sample, float* ij, void* stream);
 
 /* Stand-alone sample_along_rays(gt_depth, n_samples, n_surface, far_bb, device) (utils/common.py:561-599):
  * gt_depth [n] fp32, far_bb [n] fp64 (already carrying the +0.01), batch-global max depth taken over the n
@@ -111,12 +132,22 @@ int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_
 /* Backward.  x [P,3] normalised coordinates.  d_pe / d_grid may be NULL.  d_table (+=) [total_rows,F]
  * (NULL = skip), d_x [P,3] (overwritten; NULL = skip) = dL/dx of the NORMALISED coordinate; if
  * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point).  ws: 8-byte aligned scratch of
- * dns_encode_bwd_ws_floats(P, meta) floats for the LDS-binned table scatter (NULL = per-corner atomics). */
+ * dns_encode_bwd_ws_floats(P, meta, flags, queue_cap) floats for the LDS-binned table scatter (NULL = per-corner atomics).
+ * flags selects the form of the table scatter (tcnn kernel_grid_backward): DNS_SCATTER_AUTO = LDS bins in 64-bit fixed
+ * point, levels of >= 16 chunks through per-chunk queues; _ATOMIC = one float atomic per corner (tcnn's form);
+ * _BINNED / _QUEUES = force one binned form for every level.  queue_cap: 0, or the entry capacity of each queue (what does
+ * not fit falls back to float atomics) -- same value in both calls.  A NaN / Inf in d_grid gives a non-finite d_table in
+ * every form. */
+#define DNS_SCATTER_AUTO 0u
+#define DNS_SCATTER_ATOMIC 1u
+#define DNS_SCATTER_BINNED 2u
+#define DNS_SCATTER_QUEUES 3u
+#define DNS_SCATTER_MASK 3u
 int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins,
                    const float* table, const DnsGridMeta* meta,
                    const float* d_pe, uint32_t ld_dpe, const float* d_grid, uint32_t ld_dgrid,
-                   float* d_table, float* d_x, float* ws, void* stream);
-uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta);
+                   float* d_table, float* d_x, float* ws, uint32_t flags, uint32_t queue_cap, void* stream);
+uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta, uint32_t flags, uint32_t queue_cap);
 
 /* Debug / parity: absolute table rows of the 8 corners of every level, [P, n_levels, 8] uint32. */
 int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, uint32_t* rows, void* stream);

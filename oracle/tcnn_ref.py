@@ -148,7 +148,9 @@ def hashgrid_forward(x: torch.Tensor, table: torch.Tensor, meta: GridMeta) -> to
                 * (f[:, 2] if bz else 1 - f[:, 2])
             acc = acc + w[:, None] * table[idx]
         outs.append(acc)
-    return torch.cat(outs, -1)
+    # a float64 ``table`` (tests that need the scatter-add of the table gradient free of fp32 summation error) promotes the
+    # products; the features leave in x's dtype either way
+    return torch.cat(outs, -1).to(x.dtype)
 
 
 def _quartic_cdf(v, n_bins):

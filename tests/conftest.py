@@ -38,3 +38,20 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity figures of every assert_close of the session (scale-relative error AND worst element-wise ratio)."""
+    try:
+        import json
+        import util
+        if not util.REPORT:
+            return
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        rows = [{"what": w, "scale_rel_err": e, "elementwise_ratio": r, "rtol": t} for w, e, r, t in util.REPORT]
+        rows.sort(key=lambda d: -(d["elementwise_ratio"] if d["elementwise_ratio"] == d["elementwise_ratio"] else 0))
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump({"n": len(rows), "worst": rows[:60]}, f, indent=1)
+    except Exception:
+        pass

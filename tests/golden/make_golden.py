@@ -11,7 +11,7 @@ written next to the reference sources.  Outputs are plain arrays (inputs + expec
 outputs); no reference source text is stored.
 
 Functions exercised (all from reference utils/common.py): get_samples (:296),
-get_samples_by_class (:353), get_all_rays (:540), sample_along_rays (:561),
+get_samples_by_class (:353), get_samples_by_uniq_class (:364), get_all_rays (:540), sample_along_rays (:561),
 raw2nerf_color (:506), get_opacity_loss (:769).
 """
 import os
@@ -88,6 +88,32 @@ def golden_by_class():
                     p + "cam": np.array([H, W, fx, fy, cx, cy]), p + "n": np.array(n), p + "seed": np.array(seed),
                     p + "rays_o": ro.numpy(), p + "rays_d": rd.numpy(), p + "sample": smp.numpy()})
     np.savez_compressed(os.path.join(OUT, "get_samples_by_class.npz"), **out)
+
+
+def golden_class_picks():
+    """Pixel INDICES drawn by get_samples_by_class (:353, select_by_class :307-338) and get_samples_by_uniq_class (:364-403)
+    under a seeded CPU generator: with R = I, T = 0, fx = fy = 1, cx = cy = 0 the returned rays_d are (i, -j, -1), so the
+    drawn (column, row) pairs -- hence the flat indices -- are read off the reference's own output."""
+    out = {}
+    ci = 0
+    R, T = torch.eye(3), torch.zeros(3)
+    for (H, W, n, seed, class_dict) in [(24, 32, 50, 3, None), (12, 16, 33, 4, None), (24, 32, 50, 5, [2.0, 6.0, 0.0, 9.0]),
+                                        (12, 16, 31, 6, [6.0, 1.0]), (20, 20, 64, 7, [0.0, 1.0, 2.0, 3.0, 4.0, 5.0])]:
+        img = make_image(H, W, 60 + ci)          # label 6 has exactly one pixel (0, 0); label 9 is absent
+        torch.manual_seed(seed)
+        if class_dict is None:
+            ro, rd, smp = C.get_samples_by_class(0, H, 0, W, n, H, W, 1.0, 1.0, 0.0, 0.0, R, T, img, "cpu")
+        else:
+            ro, rd, smp = C.get_samples_by_uniq_class(0, H, 0, W, n, H, W, 1.0, 1.0, 0.0, 0.0, R, T, img, class_dict, "cpu")
+        idx = (-rd[:, 1]).round().long() * W + rd[:, 0].round().long()
+        assert torch.equal(img.reshape(-1, 5)[idx], smp)
+        p = f"c{ci}_"
+        out.update({p + "image": img.numpy(), p + "n": np.array(n), p + "seed": np.array(seed),
+                    p + "class_dict": np.array(class_dict if class_dict is not None else [], dtype=np.float64),
+                    p + "uniq": np.array(0 if class_dict is None else 1), p + "indices": idx.numpy()})
+        ci += 1
+    out["n_cases"] = np.array(ci)
+    np.savez_compressed(os.path.join(OUT, "class_picks.npz"), **out)
 
 
 def golden_all_rays():
@@ -207,6 +233,7 @@ if __name__ == "__main__":
     golden_feature_matching()
     golden_get_samples()
     golden_by_class()
+    golden_class_picks()
     golden_all_rays()
     golden_sample_along_rays()
     golden_raw2nerf()

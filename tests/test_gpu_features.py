@@ -127,7 +127,7 @@ def test_mapper_feature_branch_matches_oracle():
     for i in range(4):
         img5 = torch.cat((frames["gt_color"][i], frames["gt_depth"][i][..., None], frames["gt_label"][i][..., None]), -1)
         fs = sr.frame_samples(img5, ql[i].detach().cpu(), Tl[i].detach().cpu(), camt, bound, pix.cpu()[i * npf:(i + 1) * npf],
-                              jit[0].cpu(), jit[1].cpu(), 32, 15)
+                              jit[0][i].cpu(), jit[1][i].cpu(), 32, 15)
         first = refer["est_c2w"][i][0] if i == 0 else pose(i - 1)         # 99 is foreign -> stored pose; else a target's pose
         w2c = torch.stack([torch.inverse(first), torch.inverse(pose(i))])
         merge = lambda p_, o_, c_: fr.merge_forward(params, bound, p_, o_, c_)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import render_math as rm
 from oracle import slam_ref as sr
-from util import assert_close, oracle_from_product, randomise_, rel_err
+from util import assert_close, oracle_from_product, randomise_, rel_err, table_level_groups
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -35,8 +35,8 @@ def _oracle_samples(frames, quats, Ts, cam, bound, pix_idx, jitter, npf, ns_ray,
     out = []
     for f in range(4):
         img5 = torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
-        out.append(sr.frame_samples(img5, quats[f], Ts[f], camt, bound, pix_idx[f * npf:(f + 1) * npf], jitter[0], jitter[1],
-                                    ns_ray, nsurf))
+        j0, j1 = (jitter[0][f], jitter[1][f]) if jitter[0].dim() == 2 else jitter     # one pair per frame (reference) or shared
+        out.append(sr.frame_samples(img5, quats[f], Ts[f], camt, bound, pix_idx[f * npf:(f + 1) * npf], j0, j1, ns_ray, nsurf))
     return sr.mapper_target_samples(out)
 
 
@@ -108,7 +108,7 @@ def test_mapper_renderer_loss_and_gradients(nn, nl, layout):
         assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), f"{k_p}: {a} vs {b}"
     assert abs(float(loss) - float(lo)) <= 1e-4 * abs(float(lo))
 
-    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what="d table")
+    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what="d table", groups=table_level_groups(om.meta))
     used = lambda n_in, n_out: nn * n_in + (nl - 1) * nn * nn + n_out * nn
     assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:used(80, 33)], om.coarse.grad[:used(80, 33)], what="d coarse")
     assert_close(dec.out_fn.color_decoder.params.grad.cpu()[:used(112, 3)], om.color.grad[:used(112, 3)], what="d color")
@@ -476,7 +476,7 @@ def test_render_frame_matches_oracle_chunks():
         dec.pe_fn.grid_fn.params.mul_(2000.0)
     randomise_([mapper.fine_decoders.pool], 6)
     torch.manual_seed(1)
-    jit = mapper.draw_jitter()
+    jit = mapper.draw_jitter(1)                       # one frame: [1, n_surface]
     c2w = frames["est_c2w"][2]
     col, dep, lab = mapper.render_frame(frames["gt_color"][2], frames["gt_depth"][2], frames["gt_label"][2], c2w,
                                         n_pts_batch=200, jitter=jit)
@@ -484,7 +484,7 @@ def test_render_frame_matches_oracle_chunks():
     from dns_slam_amd.common import get_quad_from_c2w
     img5 = torch.cat((frames["gt_color"][2], frames["gt_depth"][2][..., None], frames["gt_label"][2][..., None]), -1)
     so = sr.frame_samples(img5, get_quad_from_c2w(c2w), c2w[:3, 3].clone(), (24, 32, 24.0, 24.0, cam["cx"], cam["cy"]), bound,
-                          torch.arange(24 * 32), jit[0].cpu(), jit[1].cpu(), 32, 15)
+                          torch.arange(24 * 32), jit[0][0].cpu(), jit[1][0].cpu(), 32, 15)
     cols, deps, labs = [], [], []
     for st in range(0, 24 * 32, 200):
         chunk = {k: so[k][st:st + 200] for k in ("pts", "z_vals", "gt_label", "features")}
@@ -636,3 +636,44 @@ def test_optimise_trajectory_matches_oracle_adam():
         assert_close(ql[f].detach().cpu(), qo[f].detach(), rtol=1e-4, what=f"quat[{f}] after 5 steps")
         assert_close(Tl[f].detach().cpu(), To[f].detach(), rtol=1e-4, what=f"T[{f}] after 5 steps")
 
+
+
+def test_optimize_reference_signature_with_keyframes_and_stem():
+    """Mapper.optimize(n_iters, idx, color, depth, label, gt_c2w, cur_c2w) -> (c2w, loss dict): the reference's signature
+    (slams/mapping.py:839).  Keyframes come from mapper.keyframe_dict, the frozen stem feeds the 2-D branch in every
+    iteration, refined keyframe poses are written back (:914-926), and the same call through optimize_frames on the same
+    bundle gives the same result (the adapter adds no arithmetic)."""
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.encoder import ResNet
+    from dns_slam_amd.mapping import Mapper
+    cfg, bound, cam, frames, _, _ = _setup(n_pixels=400)
+    cfg["mapping"]["start_optimize_idx"] = 0
+    run = {}
+    for mode in ("reference", "frames"):
+        torch.manual_seed(3)
+        dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+        m = Mapper(cfg, dec, bound, cam, device=DEV)
+        m.encoder = ResNet(seed=1).to(DEV)
+        m.keyframe_selector = lambda color, depth, c2w, kfs, k: [1]     # host-side keyframe choice (out of scope), fixed here
+        for k in range(3):                                   # three stored keyframes, the fourth frame is the current one
+            m.keyframe_list.append(5 * k)
+            m.keyframe_dict.append({"gt_color": frames["gt_color"][k], "gt_depth": frames["gt_depth"][k],
+                                    "gt_label": frames["gt_label"][k], "gt_c2w": frames["gt_c2w"][k],
+                                    "est_c2w": frames["est_c2w"][k].clone()})
+        cur = (frames["gt_color"][3].to(DEV), frames["gt_depth"][3].to(DEV), frames["gt_label"][3].to(DEV),
+               frames["gt_c2w"][3].to(DEV), frames["est_c2w"][3].to(DEV))
+        if mode == "reference":
+            c2w, out = m.optimize(4, 20, *cur)
+            assert set(out) == {"loss_camera_tensor", "p_loss", "d_loss", "l_loss", "lt_loss", "smooth_loss"}
+            assert m.n_target_frame == 3                       # keyframes 1, 2 (0 never joins, :361) + the current frame
+            assert not torch.equal(m.keyframe_dict[2]["est_c2w"].cpu(), frames["est_c2w"][2])   # refined pose written back
+            assert torch.equal(m.keyframe_dict[0]["est_c2w"].cpu(), frames["est_c2w"][0])
+        else:
+            idx, tf, rf = m.set_target_refer_frames(*cur)
+            assert idx == [1, 2, -1] and rf["gt_color"].shape[:2] == (3, 3) and rf["kf_idx"][-1] == [1, 2, -1]
+            feats = m.encoder(rf["gt_color"])
+            c2w, out = m.optimize_frames(4, 20, tf, features=feats, refer_frames=rf)
+        assert c2w.shape == (4, 4) and bool(torch.isfinite(c2w).all())
+        run[mode] = (c2w.cpu(), float(out["p_loss"]), float(out["d_loss"]))
+    assert_close(run["reference"][0], run["frames"][0], rtol=1e-5, what="optimize adapter pose")
+    assert abs(run["reference"][1] - run["frames"][1]) <= 1e-4 * abs(run["frames"][1])

@@ -86,3 +86,67 @@ def test_synthetic_scene_is_consistent():
         ro, rd = rm.rays_from_uv(i, j, c2w[:3, :3], c2w[:3, 3], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
         far, inside = rm.box_far(ro, rd, frames["gt_depth"][f].reshape(-1), bound)
         assert bool(inside.all())
+
+
+def test_class_balanced_index_draws_replay_the_reference(golden_dir):
+    """select_by_class (utils/common.py:307-338) and get_samples_by_uniq_class (:364-403) index draws: same generator
+    state -> the IMPORTED reference's indices, bit for bit (per-class randint shapes and order, first class takes the
+    remainder, a one-pixel class is repeated without a draw, an absent class of class_dict is skipped)."""
+    from dns_slam_amd.common import _class_pick
+    gd = np.load(os.path.join(golden_dir, "class_picks.npz"))
+    for ci in range(int(gd["n_cases"])):
+        p = f"c{ci}_"
+        img = torch.from_numpy(gd[p + "image"])
+        n, seed = int(gd[p + "n"]), int(gd[p + "seed"])
+        cls = list(gd[p + "class_dict"]) if int(gd[p + "uniq"]) else None
+        torch.manual_seed(seed)
+        idx = _class_pick(img[..., -1].reshape(-1), n, "cpu", class_list=cls)
+        want = torch.from_numpy(gd[p + "indices"])
+        assert torch.equal(idx, want), f"case {ci}"
+        lab = img[..., -1].reshape(-1)[idx]
+        # quotas: n // n_class each, the first class the remainder; absent classes contribute nothing
+        wanted = sorted(set(img[..., -1].reshape(-1).tolist())) if cls is None else [float(c) for c in cls]
+        n_k = n // len(wanted)
+        for i, c in enumerate(wanted):
+            m = n - n_k * (len(wanted) - 1) if i == 0 else n_k
+            present = bool((img[..., -1] == c).any())
+            assert int((lab == c).sum()) == (m if present else 0), (ci, c)
+
+
+def test_checkpoint_repacks_cutlass_padded_mlp_tensors(tmp_path):
+    """A tinycudann CutlassMLP flat tensor pads its output rows to 8, the kernels here to 16 (dns_slam_amd/checkpoint.py):
+    a file with 8-row padding loads into the model with the SAME weights, padded rows zero, and saving with
+    mlp_granule=8 writes that layout back; a tensor that matches no padding is refused."""
+    from dns_slam_amd.checkpoint import mlp_numel, repack_mlp_params
+    from dns_slam_amd.mapping import FineDecoderPool
+    bound = synthetic.load_bound(synthetic.ROOM0_BOUND)
+    cfg = synthetic.default_cfg(hash_size=12, voxel_size=0.2)
+    dec = Decoder(cfg["model"], bound, n_class=40)
+    pool = FineDecoderPool(80, 33, dec.coarse_fn.decoder.network_config, capacity=4, device="cpu")
+    pool.add(3), pool.add(7)
+    with torch.no_grad():
+        pool.pool.copy_(torch.randn_like(pool.pool))
+    ck = Checkpoint(str(tmp_path), device="cpu", decoder=dec, fine_decoders=pool)
+    ck.save("m8.pt", mlp_granule=8, scene="room_0", keyframe_list=[0, 5])
+    raw = torch.load(os.path.join(str(tmp_path), "m8.pt"), weights_only=False)
+    assert raw["decoder"]["coarse_fn.decoder.params"].numel() == mlp_numel(80, 33, 32, 1, 8) == 80 * 32 + 40 * 32
+    assert raw["decoder"]["out_fn.color_decoder.params"].numel() == 112 * 32 + 8 * 32
+    assert raw["fine_decoders"][7].numel() == 80 * 32 + 40 * 32
+    dec2 = Decoder(cfg["model"], bound, n_class=40)
+    pool2 = FineDecoderPool(80, 33, dec.coarse_fn.decoder.network_config, capacity=4, device="cpu")
+    with torch.no_grad():
+        for prm in dec2.parameters():
+            prm.zero_()
+    rest = Checkpoint(str(tmp_path), device="cpu", decoder=dec2, fine_decoders=pool2).load("m8.pt")
+    assert rest["scene"] == "room_0" and rest["keyframe_list"] == [0, 5]
+    a, b = dec.state_dict(), dec2.state_dict()
+    used = 80 * 32 + 33 * 32
+    assert torch.equal(a["coarse_fn.decoder.params"][:used], b["coarse_fn.decoder.params"][:used])
+    assert torch.count_nonzero(b["coarse_fn.decoder.params"][used:]) == 0
+    assert torch.equal(a["pe_fn.grid_fn.params"], b["pe_fn.grid_fn.params"])
+    assert sorted(pool2.keys()) == [3, 7] and torch.equal(pool2.params_of(7)[:used], pool.params_of(7)[:used])
+    try:
+        repack_mlp_params(torch.zeros(80 * 32 + 41 * 32), 80, 33, 32, 1)
+        raise AssertionError("a tensor that matches no padding must be refused")
+    except ValueError:
+        pass
