@@ -1602,6 +1602,12 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
     const int rc = check_segments("dns_mlp_fwd", x2, ldx2, n_in1, n_in);
     if (rc != DNS_OK) return rc;
   }
+  if (!(flags & DNS_MLP_EXACT_F32)) {
+    const int rc = ensure_ready((hipStream_t)stream, "dns_mlp_fwd");
+    if (rc != DNS_OK) return rc;
+    return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
+                                row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, (hipStream_t)stream);
+  }
   const XSeg seg = {x2, ldx2, x2 ? n_in1 : n_in};
   const MlpShape sh = make_shape(n_in, n_out);
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
@@ -1650,8 +1656,9 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   }
   if (!x2) n_in1 = n_in;
   const bool fp16 = (accumulate_dx & (int)DNS_MLP_FP16) != 0;
-  DNS_REQUIRE(!fp16 || h_saved, "dns_mlp_bwd: the fp16 mode needs the hidden activations kept by dns_mlp_fwd (h_saved)");
-  DNS_REQUIRE(!x2 || h_saved, "dns_mlp_bwd: a two-segment input needs the hidden activations kept by dns_mlp_fwd (h_saved)");
+  const bool exact = (accumulate_dx & (int)DNS_MLP_EXACT_F32) != 0;
+  DNS_REQUIRE(!exact || !fp16 || h_saved, "dns_mlp_bwd: the fp16 mode needs the hidden activations kept by dns_mlp_fwd (h_saved)");
+  DNS_REQUIRE(!exact || !x2 || h_saved, "dns_mlp_bwd: a two-segment input needs the hidden activations kept by dns_mlp_fwd (h_saved)");
   DNS_REQUIRE(!x2 || !d_x || d_x2, "dns_mlp_bwd: d_x2 is required with a two-segment input when d_x is asked for");
   if (d_x) DNS_REQUIRE(lddx >= n_in1 && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
   if (d_x && x2) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd: lddx2 < n_in - n_in1");
@@ -1660,6 +1667,11 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   {
     const int rc = ensure_ready(st, "dns_mlp_bwd");
     if (rc != DNS_OK) return rc;
+  }
+  if (!(accumulate_dx & (int)DNS_MLP_EXACT_F32)) {
+    return launch_mlp_bwd_split(x, ldx, x2, ldx2, n_in1, dy, lddy, params, n_in, n_out, n_neurons, n_hidden_layers, d_x, lddx,
+                                d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride, accumulate_dx & 1,
+                                (accumulate_dx >> 1) & 1, fp16, st);
   }
   const uint32_t NNr = n_neurons;
   const char* gb_env = nullptr;

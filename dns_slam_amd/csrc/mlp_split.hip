@@ -1,0 +1,386 @@
+// Forward kernel, dW_in kernel and the host-side launchers of the split-operand MLP (device helpers: mlp_split.hpp; the
+// backward kernel: mlp_split_bwd.inc, one translation unit per (n_neurons, n_hidden_layers)).
+#include "mlp_split.hpp"
+
+namespace dns {
+namespace sp {
+
+// ---- LDS layout of the forward kernel (bytes) ----
+template <int NN, int NL>
+struct FwdLds {
+  static __host__ __device__ uint32_t ns0(uint32_t n_in) { return (n_in + 15u) / 16u; }
+  static __host__ __device__ uint32_t mt(uint32_t n_out) { return (n_out + 31u) / 32u; }
+  static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
+  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return (NN / 32) * ns0(n_in) * 2048u; }
+  static __host__ __device__ uint32_t img_out(uint32_t n_in) { return img_h(n_in) + (NL - 1) * (NN / 32) * (NN / 16) * 2048u; }
+  static __host__ __device__ uint32_t misc(uint32_t n_in, uint32_t n_out) { return img_out(n_in) + mt(n_out) * (NN / 16) * 2048u; }
+  static __host__ __device__ uint32_t stage(uint32_t n_in, uint32_t n_out) { return misc(n_in, n_out) + 256u; }   // exps + reduction
+  static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, uint32_t nwaves) {
+    return stage(n_in, n_out) + nwaves * STG_WAVE_FLOATS * 4u;
+  }
+};
+
+struct FwdArgs {
+  const float* x;
+  uint32_t ldx;
+  XSeg seg;
+  const float* params;
+  uint32_t n_in, n_out;
+  float* y;
+  uint32_t ldy, n_slots;
+  const int32_t* row_index;
+  const int32_t* tile_group;
+  uint32_t param_stride, tiles_per_block;
+  float* h_save;
+};
+
+template <int NN, int NL, int PREC>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
+  constexpr int NT = NN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using L = FwdLds<NN, NL>;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t n_in = a.n_in, n_out = a.n_out;
+  const uint32_t ns0 = L::ns0(n_in), mt = L::mt(n_out);
+  const uint32_t n_chunks = (n_in + 31u) / 32u;
+  const uint32_t n_btiles = (a.n_slots + 127u) / 128u;
+  const uint32_t bt0 = blockIdx.x * a.tiles_per_block;
+  const uint32_t bt1 = min(bt0 + a.tiles_per_block, n_btiles);
+  const _Float16* img_in = reinterpret_cast<const _Float16*>(lds + L::img_in(n_in));
+  const _Float16* img_h = reinterpret_cast<const _Float16*>(lds + L::img_h(n_in));
+  const _Float16* img_out = reinterpret_cast<const _Float16*>(lds + L::img_out(n_in));
+  int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
+  float* red = reinterpret_cast<float*>(lds + L::misc(n_in, n_out) + 64);
+  float* stg = reinterpret_cast<float*>(lds + L::stage(n_in, n_out)) + wave * STG_WAVE_FLOATS;
+  int* rows_all = reinterpret_cast<int*>(stg + STG_FLOATS);
+  XChunk xc[4];                                  // n_in <= 128: at most 4 chunks of 32 columns
+  bool have_x = false;
+  uint32_t cur_buf = 0;
+  int cur_group = -2;
+  for (uint32_t bt = bt0; bt < bt1; ++bt) {
+    const int grp = a.tile_group ? a.tile_group[bt] : 0;
+    if (grp != cur_group) {
+      __syncthreads();
+      if (grp >= 0) {
+        const float* pw = a.params + (size_t)grp * a.param_stride;
+        const float* wh = pw + NN * n_in;
+        const float* wout = wh + (NL - 1) * NN * NN;
+        ImgQuads<8> q_in;                                              // 64 x 128 / 4 / 256 threads
+        ImgQuads<4> q_h, q_out;
+        const float m_in = image_load(q_in, pw, NN, n_in);
+        const float m_h = (NL == 2) ? image_load(q_h, wh, NN, NN) : 0.f;
+        const float m_out = image_load(q_out, wout, n_out, NN);
+        lds_zero16(lds, L::misc(n_in, n_out));
+        block_scale_exps(m_in, m_h, m_out, red, wexp);                 // two barriers: the zero fill is complete
+        image_scatter(q_in, const_cast<_Float16*>(img_in), NN, n_in, false, NT, ns0, K_NAT, pow2f(wexp[0]));
+        if (NL == 2) image_scatter(q_h, const_cast<_Float16*>(img_h), NN, NN, false, NT, NN / 16, K_CHAIN, pow2f(wexp[1]));
+        image_scatter(q_out, const_cast<_Float16*>(img_out), n_out, NN, false, mt, NN / 16, K_CHAIN, pow2f(wexp[2]));
+      }
+      cur_group = grp;
+      __syncthreads();
+    }
+    if (grp < 0) continue;
+    const uint32_t slot0 = bt * 128u + wave * 32u;
+    const uint32_t nrows = slot0 < a.n_slots ? min(32u, a.n_slots - slot0) : 0u;
+    // The tile's x rows (all <= 4 chunks of 32 columns) were requested while the PREVIOUS tile ran its later layers; only
+    // a workgroup's first live tile pays the latency here.
+    if (have_x) {
+      cur_buf ^= 1u;
+    } else {
+      tile_rows_publish(rows_all + 32u * cur_buf, a.row_index, slot0, a.n_slots, lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * cur_buf, c, lane);
+    }
+    const int* rows_lds = rows_all + 32u * cur_buf;
+    float* rmax = stg + STG_FLOATS + STG_ROWS;
+    x_row_max<4>(xc, n_chunks, rmax, lane);
+    int kc = scale_exp(rmax[lane & 31u]);          // cumulative exponent: accumulators hold 2^kc * (true value)
+    const float sx = pow2f(kc);
+    kc += wexp[0];
+    f32x16 a0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a0[t] = zero16();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if ((uint32_t)c < n_chunks) {                // uniform
+        float xs[16];
+        x_chunk_commit(xc[c], stg, lane);
+        x_chunk_read(xs, stg, lane);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const uint32_t ks = 2u * c + s;
+          if (ks < ns0) {                          // uniform
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = xs[8 * s + j];
+            const Frag b = split8(v, sx);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a0[t] = mma<PREC>(load_frag<PREC>(img_in, ns0, t, ks, lane), b, a0[t]);
+          }
+        }
+      }
+    }
+    // request the next live tile's rows now: they arrive while this tile runs its later layers
+    have_x = false;
+    for (uint32_t nbt = bt + 1; nbt < bt1; ++nbt) {
+      if ((a.tile_group ? a.tile_group[nbt] : 0) < 0) continue;
+      int* nrows_lds = rows_all + 32u * (cur_buf ^ 1u);
+      tile_rows_publish(nrows_lds, a.row_index, nbt * 128u + wave * 32u, a.n_slots, lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, nrows_lds, c, lane);
+      have_x = true;
+      break;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a0[t][r] = fmaxf(a0[t][r], 0.f);
+    if (a.h_save) {                                // kept for callers that want the hidden activations
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x16 hv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = ldexpf(a0[t][r], -kc);
+        store_tile_staged(a.h_save + (size_t)slot0 * NN + t * 32, NN, nrows, hv, stg, lane);
+      }
+    }
+    f32x16 a1[NT];
+    if (NL == 2) {
+      const int kf = scale_exp(tile_max<NT>(a0)) ;
+      layer_chain<PREC, NT, NT>(a0, pow2f(kf), img_h, lane, a1);
+      kc += kf + wexp[1];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[t][r] = fmaxf(a1[t][r], 0.f);
+      if (a.h_save) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f32x16 hv;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hv[r] = ldexpf(a1[t][r], -kc);
+          store_tile_staged(a.h_save + (size_t)(a.n_slots + slot0) * NN + t * 32, NN, nrows, hv, stg, lane);
+        }
+      }
+    }
+    const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
+    const int kf = scale_exp(tile_max<NT>(hl));
+    kc += kf + wexp[2];
+    const float fo = pow2f(kf);
+    if (mt >= 2u) {
+      f32x16 o[2];
+      layer_chain<PREC, 2, NT>(hl, fo, img_out, lane, o);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = ldexpf(o[t][r], -kc);
+      store_tile_rows_scalar(a.y, a.ldy, 0, 32u, rows_lds, o[0], stg, lane);
+      store_tile_rows_scalar(a.y, a.ldy, 32, n_out - 32u, rows_lds, o[1], stg, lane);
+    } else {
+      f32x16 o[1];
+      layer_chain<PREC, 1, NT>(hl, fo, img_out, lane, o);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[0][r] = ldexpf(o[0][r], -kc);
+      store_tile_rows_scalar(a.y, a.ldy, 0, n_out, rows_lds, o[0], stg, lane);
+    }
+  }
+}
+
+
+// =================================================================================================================
+// dW_in[n][c] = sum_points dH_1[point][n] * X[point][c]: a streaming product whose K axis is the point axis.  Both
+// operands are read straight from memory in the form the matrix instruction wants -- lane = channel, elements = 8
+// consecutive points: dword loads, 2 rows x 128 contiguous bytes per instruction (dH_1 is slot-major, X goes through the
+// slot -> row table) -- split into three bf16 parts (scale-free, mlp_split.hpp) and multiplied; no LDS in the loop.  A wave
+// owns ALL NT x IT tiles of dW_in for its 32-point tiles (<= 128 accumulator registers), the workgroup's waves are added
+// in LDS at the end of a run.
+struct DwinArgs {
+  const float* dh1;                          // [n_slots, NN]
+  const float* x;
+  uint32_t ldx;
+  XSeg seg;
+  uint32_t n_in;
+  float* d_params;                           // dW_in block of the group = d_params + group * param_stride
+  uint32_t n_slots;
+  const int32_t* row_index;
+  const int32_t* tile_group;
+  uint32_t param_stride, tiles_per_block;
+};
+
+template <int NN, int IT, int PREC>
+__global__ __launch_bounds__(256, 2) void mlp_dwin_kernel(DwinArgs a) {
+  constexpr int NT = NN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* stg_base = reinterpret_cast<float*>(lds);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  int* rows_lds = reinterpret_cast<int*>(stg_base + wave * STG_WAVE_FLOATS + STG_FLOATS);
+  const uint32_t n_in = a.n_in;
+  const uint32_t n_btiles = (a.n_slots + 127u) / 128u;
+  const uint32_t bt0 = blockIdx.x * a.tiles_per_block;
+  const uint32_t bt1 = min(bt0 + a.tiles_per_block, n_btiles);
+  auto group_of = [&](uint32_t t) -> int { return a.tile_group ? a.tile_group[t] : 0; };
+  const uint32_t ch = lane & 31u, pt8 = 8u * (lane >> 5);
+  f32x16 acc[NT][IT];
+  for (uint32_t run0 = bt0; run0 < bt1;) {       // runs of tiles of one weight set (see mlp_split_bwd.inc)
+    const int grp = group_of(run0);
+    uint32_t run1 = run0 + 1;
+    while (run1 < bt1 && group_of(run1) == grp) ++run1;
+    if (grp < 0) {
+      run0 = run1;
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < IT; ++j) acc[i][j] = zero16();
+    for (uint32_t bt = run0; bt < run1; ++bt) {
+      const uint32_t slot0 = bt * 128u + wave * 32u;
+      tile_rows_publish(rows_lds, a.row_index, slot0, a.n_slots, lane);
+      Frag3 fa[NT][2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t slot = slot0 + 16u * s + pt8 + j;
+            v[j] = slot < a.n_slots ? a.dh1[(size_t)slot * NN + 32 * t + ch] : 0.f;
+          }
+          fa[t][s] = split8_bf3(v);
+        }
+#pragma unroll
+      for (int ct = 0; ct < IT; ++ct) {
+        const uint32_t col = 32u * ct + ch;
+        const bool second = a.seg.x2 != nullptr && col >= a.seg.n_in1;
+        const float* base = second ? a.seg.x2 + (col - a.seg.n_in1) : a.x + col;
+        const uint32_t ld = second ? a.seg.ldx2 : a.ldx;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int row = rows_lds[16 * s + pt8 + j];
+            v[j] = (row >= 0 && col < n_in) ? base[(size_t)row * ld] : 0.f;
+          }
+          const Frag3 fb = split8_bf3(v);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][ct] = mma_pt<PREC>(fa[t][s], fb, acc[t][ct]);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      float* dW = a.d_params + (size_t)grp * a.param_stride;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < IT; ++j)
+          flush_tile(acc[i][j], dW + (size_t)(32 * i) * n_in + 32 * j, n_in, 32u, n_in > 32u * j ? n_in - 32u * j : 0u, stg_base, wave, lane);
+    }
+    run0 = run1;
+  }
+}
+
+template <int NN, int NL>
+static bool set_fwd_attrs() {
+  return hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess;
+}
+
+static int split_init_attrs() {
+  const bool ok = set_fwd_attrs<32, 1>() && set_fwd_attrs<32, 2>() && set_fwd_attrs<64, 1>() && set_fwd_attrs<64, 2>();
+  if (!ok) {
+    set_error("dns_init: hipFuncSetAttribute failed for the split-operand MLP kernels");
+    return DNS_E_LAUNCH;
+  }
+  return DNS_OK;
+}
+static AttrRegistrar split_attr_registrar(split_init_attrs);
+
+}  // namespace sp
+
+// launch helpers used by dns_mlp_fwd / dns_mlp_bwd (mlp.hip): arguments already validated there
+int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* params,
+                         uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
+                         uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
+                         float* h_save, bool fp16_single, hipStream_t st) {
+  using namespace sp;
+  FwdArgs a;
+  a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.params = params; a.n_in = n_in; a.n_out = n_out;
+  a.y = y; a.ldy = ldy; a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
+  a.h_save = h_save;
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  uint32_t tpb = (n_btiles + 511u) / 512u;       // ~2 workgroups of 4 waves per CU, contiguous tile ranges
+  if (tpb < 1) tpb = 1;
+  a.tiles_per_block = tpb;
+  const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
+#define LAUNCH_FWD(NN, NL)                                                                                           \
+  {                                                                                                                  \
+    const size_t lds_bytes = FwdLds<NN, NL>::total(n_in, n_out, 4);                                                  \
+    if (fp16_single) hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL, 1>), dim3(blocks), dim3(256), lds_bytes, st, a);     \
+    else hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL, 3>), dim3(blocks), dim3(256), lds_bytes, st, a);                 \
+  }
+  if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
+  else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
+  else if (n_neurons == 64 && n_hidden_layers == 1) LAUNCH_FWD(64, 1)
+  else LAUNCH_FWD(64, 2)
+#undef LAUNCH_FWD
+  return check_launch("dns_mlp_fwd");
+}
+
+int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
+                         uint32_t lddy, const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
+                         uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
+                         float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
+                         uint32_t param_stride, int acc1, int acc2, bool fp16_single, hipStream_t st) {
+  using namespace sp;
+  BwdArgs a;
+  a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.dy = dy; a.lddy = lddy; a.params = params;
+  a.n_in = n_in; a.n_out = n_out; a.dx = d_x; a.lddx = lddx;
+  a.dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)acc1, (uint32_t)acc2};
+  a.d_params = d_params; a.dh1 = d_params ? ws : nullptr;
+  a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
+  uint32_t tpb = (n_btiles + 255u) / 256u;       // one workgroup of 4 waves per CU, contiguous tile ranges
+  if (tpb < 1) tpb = 1;
+  a.tiles_per_block = tpb;
+  const uint32_t blocks = (n_btiles + tpb - 1) / tpb;
+  int rc;
+  if (n_neurons == 32 && n_hidden_layers == 1) rc = launch_bwd_32_1(a, blocks, fp16_single, st);
+  else if (n_neurons == 32 && n_hidden_layers == 2) rc = launch_bwd_32_2(a, blocks, fp16_single, st);
+  else if (n_neurons == 64 && n_hidden_layers == 1) rc = launch_bwd_64_1(a, blocks, fp16_single, st);
+  else rc = launch_bwd_64_2(a, blocks, fp16_single, st);
+  if (rc != DNS_OK || !d_params) return rc;
+  // dW_in = dH_1^T X from the workspace the first kernel wrote
+  DwinArgs d;
+  d.dh1 = ws; d.x = x; d.ldx = ldx; d.seg = a.seg; d.n_in = n_in; d.d_params = d_params; d.n_slots = n_slots;
+  d.row_index = row_index; d.tile_group = tile_group; d.param_stride = param_stride;
+  uint32_t tpb2 = (n_btiles + 511u) / 512u;      // two workgroups per CU
+  if (tpb2 < 1) tpb2 = 1;
+  d.tiles_per_block = tpb2;
+  const uint32_t blocks2 = (n_btiles + tpb2 - 1) / tpb2;
+  const size_t lds2 = 4 * STG_WAVE_FLOATS * sizeof(float);
+  const uint32_t it = (n_in + 31u) / 32u;
+#define LAUNCH_DWIN2(NN, IT)                                                                                          \
+  {                                                                                                                   \
+    if (fp16_single) hipLaunchKernelGGL((mlp_dwin_kernel<NN, IT, 1>), dim3(blocks2), dim3(256), lds2, st, d);        \
+    else hipLaunchKernelGGL((mlp_dwin_kernel<NN, IT, 3>), dim3(blocks2), dim3(256), lds2, st, d);                     \
+  }
+#define LAUNCH_DWIN(NN)                  \
+  {                                      \
+    if (it <= 1) LAUNCH_DWIN2(NN, 1)     \
+    else if (it == 2) LAUNCH_DWIN2(NN, 2) \
+    else if (it == 3) LAUNCH_DWIN2(NN, 3) \
+    else LAUNCH_DWIN2(NN, 4)             \
+  }
+  if (n_neurons == 32) LAUNCH_DWIN(32)
+  else LAUNCH_DWIN(64)
+#undef LAUNCH_DWIN
+#undef LAUNCH_DWIN2
+  return check_launch("dns_mlp_bwd(dW_in)");
+}
+
+}  // namespace dns

@@ -1,0 +1,609 @@
+// Bias-free ReLU MLP on the CDNA4 matrix cores with SPLIT OPERANDS: every fp32 operand v is carried as two halfs
+// hi = f16(v s), lo = f16(v s - hi) (s a power of two), and a product is three v_mfma_f32_32x32x16_f16 with fp32
+// accumulation,  a_lo b_hi + a_hi b_lo + a_hi b_hi  (the a_lo b_lo term is below 2^-22 of the product).
+//
+// Replaces tcnn.Network{CutlassMLP} (reference models/decoder.py:58-64,84-90,101-116, slams/mapping.py:737-743):
+// y = W_out relu(W_h relu(W_in x)), no bias.
+//
+// Why: gfx950 has no reduced-precision fp32 path (no xf32) and its exact-fp32 MFMA runs at the fp32 VECTOR rate, 1/16
+// of the f16 rate.  Three f16 products per fp32 product were measured (tools/mfma_f16x3_probe.hip, MI355X) at 3.3x the
+// throughput of v_mfma_f32_32x32x2_f32 with an error of 6-8e-8 of sum|a b| -- BELOW the 1.1-1.5e-7 of an fp32 fma chain
+// (22 operand bits + an accumulator wider than fp32 inside a K = 16 step), f16 subnormals honoured.
+//
+// Orientation (unchanged from the fp32 kernels this file replaces): POINTS live on the MFMA column / lane axis, weights
+// are the A operand.  v_mfma_f32_32x32x16_f16: lane (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r], j = 0..7; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h.  With points on lanes a layer's
+// accumulator IS the next layer's B operand: registers 8s .. 8s+7 of an accumulator tile are K-step s, element j of lane
+// half h being row 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the weight images are stored in that k order ("CHAIN" map), so
+// activations never leave registers between layers.
+//
+// Scaling: f16 has 30 binades of normal range, so every operand is scaled by a power of two that puts its largest
+// magnitude in [2^13, 2^14): weights per matrix (workgroup-wide max when the LDS images are built), activations and
+// gradients PER POINT (a lane pair's max; the scale factors out of the point's output column), all tracked as integer
+// exponents and undone exactly with ldexp.  NaN / Inf propagate (a non-finite maximum leaves the scale at 1).
+#pragma once
+#include "common.hpp"
+
+namespace dns {
+namespace sp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+constexpr int TGT_EXP = 14;                  // scaled maxima lie in [2^13, 2^14)
+
+struct Frag {
+  half8 hi, lo;
+};
+
+__device__ __forceinline__ uint32_t acc_row(uint32_t r, uint32_t h) { return (r & 3u) + 8u * (r >> 2) + 4u * h; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// exponent k such that m * 2^k lies in [2^(TGT_EXP-1), 2^TGT_EXP); 0 for m = 0 or a non-finite m (which then propagates)
+__device__ __forceinline__ int scale_exp(float m) {
+  if (!(m > 0.f) || !(m < INFINITY)) return 0;
+  int ex;
+  (void)frexpf(m, &ex);                      // m = f 2^ex, f in [0.5, 1)
+  return min(max(TGT_EXP - ex, -110), 110);
+}
+
+__device__ __forceinline__ float pow2f(int k) { return ldexpf(1.0f, k); }
+
+// 8 fp32 values (already in the lane's k order) -> hi / lo halfs of v * s
+__device__ __forceinline__ Frag split8(const float (&v)[8], float s) {
+  Frag f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * s;
+    f.hi[j] = (_Float16)x;
+    f.lo[j] = (_Float16)(x - (float)f.hi[j]);
+  }
+  return f;
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 acc) {
+  if (PREC == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
+// ---- products whose K axis is the POINT axis (the weight gradients) ------------------------------------------------
+// There the scale of an operand cannot follow the point (the point is the summation index) and one accumulator collects
+// tiles of very different magnitude (gradients of rays that already fit beside rays that do not), so these products use the
+// format that needs no scaling at all: every fp32 value as THREE bf16 parts h + m + l (8 + 8 + 8 significant bits, fp32's
+// exponent range) and six v_mfma_f32_32x32x16_bf16 per product, h h + (h m + m h) + (h l + l h + m m); the dropped terms
+// are below 2^-23 of the product.  (Scaled f16 pairs with per-wave "ratchet" exponents were tried first: every place that
+// rescales or restarts an accumulator outside a matrix instruction costs the compiler a second copy of all accumulators.)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Frag3 {
+  bf16x8 h, m, l;
+};
+
+__device__ __forceinline__ Frag3 split8_bf3(const float (&v)[8]) {
+  Frag3 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f.h[j] = (__bf16)v[j];
+    const float r = v[j] - (float)f.h[j];
+    f.m[j] = (__bf16)r;
+    f.l[j] = (__bf16)(r - (float)f.m[j]);
+  }
+  return f;
+}
+
+// PREC == 1 (tcnn's half-precision mode): two parts (16 bits, at least fp16's 11) and three products
+template <int PREC>
+__device__ __forceinline__ f32x16 mma_pt(const Frag3& a, const Frag3& b, f32x16 acc) {
+  if (PREC == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+
+// ---- weight images ----------------------------------------------------------------------------------------------
+// A-operand image of Meff [rows x K]: fragment (row tile rt, K-step s, part p in {hi, lo}) = 64 lanes x 8 halfs (1 KB);
+// lane (r, h) element j holds part_p(scale * Meff[32 rt + r][kmap(s, h, j)]).  NAT map k = 16 s + 8 h + j (operands
+// staged from memory in column order), CHAIN map k = 16 s + 8 (j >> 2) + 4 h + (j & 3) (operands that are accumulators).
+enum KMap { K_NAT = 0, K_CHAIN = 1 };
+
+__device__ __forceinline__ const uint4* frag_ptr(const _Float16* img, uint32_t nsteps, uint32_t rt, uint32_t s, uint32_t part,
+                                                 uint32_t lane) {
+  return reinterpret_cast<const uint4*>(img) + ((rt * nsteps + s) * 2u + part) * 64u + lane;
+}
+
+template <int PREC>
+__device__ __forceinline__ Frag load_frag(const _Float16* img, uint32_t nsteps, uint32_t rt, uint32_t s, uint32_t lane) {
+  Frag f;
+  const uint4 hi = *frag_ptr(img, nsteps, rt, s, 0, lane);
+  f.hi = *reinterpret_cast<const half8*>(&hi);
+  if (PREC == 3) {
+    const uint4 lo = *frag_ptr(img, nsteps, rt, s, 1, lane);
+    f.lo = *reinterpret_cast<const half8*>(&lo);
+  } else {
+    f.lo = f.hi;
+  }
+  return f;
+}
+
+// Images are built by walking M in MEMORY order (aligned float4s): every workgroup re-reads the weights, so all loads
+// of all matrices are put in flight first (image_load), the maxima are reduced and the image area zeroed while they fly,
+// and only then are the values split and scattered (image_scatter).  M is row-major [R x C], C % 4 == 0.
+template <int MAXQ>
+struct ImgQuads {
+  float4 v[MAXQ];
+};
+
+template <int MAXQ>
+__device__ __forceinline__ float image_load(ImgQuads<MAXQ>& q, const float* __restrict__ M, uint32_t R, uint32_t C) {
+  const uint32_t nq = R * (C >> 2);
+  const bool vec = (((uintptr_t)M) & 15u) == 0;
+  float m = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    const uint32_t e = threadIdx.x + j * blockDim.x;
+    q.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < nq) {
+      const float* src = M + (size_t)e * 4u;
+      if (vec) q.v[j] = *reinterpret_cast<const float4*>(src);
+      else q.v[j] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+    const float a = fmaxf(fmaxf(fabsf(q.v[j].x), fabsf(q.v[j].y)), fmaxf(fabsf(q.v[j].z), fabsf(q.v[j].w)));
+    m = fmaxf(m, a);
+    bad = bad || !(a < INFINITY);            // fmaxf drops a NaN: keep non-finite weights visible
+  }
+  return bad ? INFINITY : m;
+}
+
+// Meff[i][k] = transpose ? M[k][i] : M[i][k]; entries with i >= 32 row_tiles or k outside the image stay zero
+template <int MAXQ>
+__device__ __forceinline__ void image_scatter(const ImgQuads<MAXQ>& q, _Float16* __restrict__ img, uint32_t R, uint32_t C,
+                                              bool transpose, uint32_t row_tiles, uint32_t nsteps, int kmap, float scale) {
+  auto slot = [&](uint32_t i, uint32_t k, uint32_t& idx) -> bool {   // half index of element (i, k) of part hi
+    const uint32_t s = k >> 4, qq = k & 15u;
+    uint32_t h, j;
+    if (kmap == K_NAT) {
+      h = qq >> 3;
+      j = qq & 7u;
+    } else {
+      h = (qq >> 2) & 1u;
+      j = ((qq >> 3) << 2) | (qq & 3u);
+    }
+    const uint32_t rt = i >> 5;
+    if (rt >= row_tiles || s >= nsteps) return false;
+    idx = ((((rt * nsteps + s) * 2u) * 64u) + (i & 31u) + 32u * h) * 8u + j;
+    return true;
+  };
+  const uint32_t qpr = C >> 2, nq = R * qpr;
+#pragma unroll
+  for (int jq = 0; jq < MAXQ; ++jq) {
+    const uint32_t e = threadIdx.x + jq * blockDim.x;
+    if (e >= nq) continue;
+    const uint32_t rr = e / qpr, cc = (e - rr * qpr) * 4u;
+    const float vv[4] = {q.v[jq].x * scale, q.v[jq].y * scale, q.v[jq].z * scale, q.v[jq].w * scale};
+    _Float16 hi[4], lo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      hi[c] = (_Float16)vv[c];
+      lo[c] = (_Float16)(vv[c] - (float)hi[c]);
+    }
+    uint32_t idx;
+    if (!transpose) {                        // i = rr, k = cc .. cc+3: four consecutive halfs of one lane slot
+      if (slot(rr, cc, idx)) {
+        half4v h4, l4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { h4[c] = hi[c]; l4[c] = lo[c]; }
+        *reinterpret_cast<half4v*>(img + idx) = h4;
+        *reinterpret_cast<half4v*>(img + idx + 64u * 8u) = l4;     // part lo = the next 64-lane block
+      }
+    } else {                                 // i = cc + c, k = rr: one element of four neighbouring lanes
+#pragma unroll
+      for (uint32_t c = 0; c < 4u; ++c) {
+        if (slot(cc + c, rr, idx)) {
+          img[idx] = hi[c];
+          img[idx + 64u * 8u] = lo[c];
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_zero16(void* p, uint32_t bytes) {   // bytes % 16 == 0
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (uint32_t e = threadIdx.x; e < bytes / 16u; e += blockDim.x) q[e] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// workgroup-wide maxima of up to 3 values -> power-of-two exponents in wexp[0..2] (LDS); red: 3 * nwaves floats of LDS
+__device__ __forceinline__ void block_scale_exps(float m0, float m1, float m2, float* red, int* wexp) {
+  float m[3] = {m0, m1, m2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m[i] = fmaxf(m[i], __shfl_xor(m[i], o));
+  }
+  const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63u) == 0) {
+    red[wave * 3 + 0] = m[0];
+    red[wave * 3 + 1] = m[1];
+    red[wave * 3 + 2] = m[2];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float mm = 0.f;
+    for (uint32_t w = 0; w < nw; ++w) mm = fmaxf(mm, red[w * 3 + threadIdx.x]);
+    wexp[threadIdx.x] = scale_exp(mm);
+  }
+  __syncthreads();
+}
+
+// ---- row-coalesced global I/O through a wave-private LDS staging tile (32 rows x 36 floats) -----------------------
+// In the accumulator layout a lane owns ONE point, so a direct float4 access touches 64 cache lines per instruction; staged
+// through LDS the same kilobyte moves as 8 rows x 128 contiguous bytes.
+constexpr uint32_t STG_LD = 36;
+constexpr uint32_t STG_FLOATS = 32 * STG_LD;
+constexpr uint32_t STG_ROWS = 64;            // two row tables: the tile being computed and the one being prefetched
+constexpr uint32_t STG_RMAX = 32;            // per-row maxima of the tile's input rows
+constexpr uint32_t STG_WAVE_FLOATS = STG_FLOATS + STG_ROWS + STG_RMAX;
+
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("" ::: "memory");             // LDS instructions of one wave execute in order: compiler fence only
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void tile_rows_publish(int* __restrict__ rows_lds, const int32_t* __restrict__ row_index,
+                                                  uint32_t slot0, uint32_t n_slots, uint32_t lane) {
+  if (lane < 32u) {
+    const uint32_t slot = slot0 + lane;
+    int row = -1;
+    if (slot < n_slots) row = row_index ? row_index[slot] : (int)slot;
+    rows_lds[lane] = row;
+  }
+  wave_lds_fence();
+}
+
+struct XSeg {                                // optional second input segment: columns [n_in1, n_in) come from x2
+  const float* x2;
+  uint32_t ldx2, n_in1;
+};
+
+struct XChunk {                              // 32 columns of the tile's 32 rows: lane (r8 = l >> 3, j = l & 7) holds
+  float4 v[4];                               // float4 j of rows r8, r8+8, r8+16, r8+24
+};
+
+__device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restrict__ x, uint32_t ldx, const XSeg& seg,
+                                              uint32_t n_in, const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
+  const uint32_t col = 32u * c + 4u * (lane & 7u);
+  const bool second = seg.x2 != nullptr && col >= seg.n_in1;
+  const float* base = second ? seg.x2 + (col - seg.n_in1) : x + col;
+  const uint32_t ld = second ? seg.ldx2 : ldx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rows_lds[(lane >> 3) + 8 * i];
+    xc.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= 0 && col < n_in) xc.v[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld);
+  }
+}
+
+// max |x| of every row of the tile over all its chunks (still in the load layout: 8 lanes share a row) -> rmax[32] in LDS.
+// The point's scale must be known before its first operand is converted, and this costs 12 cross-lane steps per tile
+// where keeping the whole half row in registers until its maximum is known cost 48 registers.
+template <int NCH>
+__device__ __forceinline__ void x_row_max(const XChunk (&xc)[NCH], uint32_t n_chunks, float* __restrict__ rmax, uint32_t lane) {
+  float rm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if ((uint32_t)c < n_chunks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rm[i] = fmaxf(rm[i], fmaxf(fmaxf(fabsf(xc[c].v[i].x), fabsf(xc[c].v[i].y)), fmaxf(fabsf(xc[c].v[i].z), fabsf(xc[c].v[i].w))));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int o = 1; o <= 4; o <<= 1) rm[i] = fmaxf(rm[i], __shfl_xor(rm[i], o));
+    if ((lane & 7u) == 0) rmax[(lane >> 3) + 8 * i] = rm[i];
+  }
+  wave_lds_fence();
+}
+
+__device__ __forceinline__ void x_chunk_commit(const XChunk& xc, float* __restrict__ stg, uint32_t lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(stg + ((lane >> 3) + 8 * i) * STG_LD + 4u * (lane & 7u)) = xc.v[i];
+  wave_lds_fence();
+}
+
+// the lane's operands of the staged 32-column chunk: columns 16 s + 8 h + j (NAT map), s = 0, 1
+__device__ __forceinline__ void x_chunk_read(float (&xs)[16], const float* __restrict__ stg, uint32_t lane) {
+  const float* src = stg + (lane & 31u) * STG_LD + 8u * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float4 a = *reinterpret_cast<const float4*>(src + 16 * s), b = *reinterpret_cast<const float4*>(src + 16 * s + 4);
+    xs[8 * s + 0] = a.x; xs[8 * s + 1] = a.y; xs[8 * s + 2] = a.z; xs[8 * s + 3] = a.w;
+    xs[8 * s + 4] = b.x; xs[8 * s + 5] = b.y; xs[8 * s + 6] = b.z; xs[8 * s + 7] = b.w;
+  }
+  wave_lds_fence();                          // the staging tile may be overwritten once these reads are issued
+}
+
+// a (32 features x 32 points, accumulator layout, already unscaled) -> y[row][col0 + f], f < ncols, rows through the
+// tile's row table; dword stores with lane = feature: 2 rows x 128 bytes per instruction (any ldy / alignment)
+__device__ __forceinline__ void store_tile_rows_scalar(float* __restrict__ y, uint32_t ldy, uint32_t col0, uint32_t ncols,
+                                                       const int* __restrict__ rows_lds, const f32x16& a,
+                                                       float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t f = lane & 31u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t r = (lane >> 5) + 2 * i;
+    const int row = rows_lds[r];
+    const float v = stg[r * STG_LD + f];
+    if (row >= 0 && f < ncols) y[(size_t)row * ldy + col0 + f] = v;
+  }
+  wave_lds_fence();
+}
+
+// a: 32 features x 32 points -> rows dst[row * ld + 0..31] of 32 consecutive slot rows, row < nrows (16-byte aligned rows)
+__device__ __forceinline__ void store_tile_staged(float* __restrict__ dst, uint32_t ld, uint32_t nrows, const f32x16& a,
+                                                  float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = rr + 8 * i;
+    const float4 v = *reinterpret_cast<const float4*>(stg + row * STG_LD + c4);
+    if (row < nrows) *reinterpret_cast<float4*>(dst + (size_t)row * ld + c4) = v;
+  }
+  wave_lds_fence();
+}
+
+template <int NT>
+__device__ __forceinline__ float tile_max(const f32x16 (&a)[NT]) {      // after ReLU: values are >= 0 (or NaN)
+  float m = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(a[t][r]));
+  return fmaxf(m, __shfl_xor(m, 32));        // the point's other lane half
+}
+
+// out[t] = W[t-th 32 rows] * act, act = accumulator tiles scaled by 2^kf on conversion; image in the CHAIN map.
+// The A fragments of K-step s+1 are requested before step s's operand is converted, so their LDS latency hides under
+// the conversion and the matrix instructions instead of stalling every step (s_waitcnt lgkmcnt(0) in front of each group).
+template <int PREC, int NT_OUT, int NT_IN>
+__device__ __forceinline__ void layer_chain(const f32x16 (&act)[NT_IN], float f, const _Float16* img, uint32_t lane,
+                                            f32x16 (&out)[NT_OUT]) {
+  constexpr uint32_t nsteps = NT_IN * 2;
+#pragma unroll
+  for (int t = 0; t < NT_OUT; ++t) out[t] = zero16();
+  Frag an[NT_OUT];
+#pragma unroll
+  for (int t = 0; t < NT_OUT; ++t) an[t] = load_frag<PREC>(img, nsteps, t, 0, lane);
+#pragma unroll
+  for (int st = 0; st < (int)nsteps; ++st) {
+    Frag ac[NT_OUT];
+#pragma unroll
+    for (int t = 0; t < NT_OUT; ++t) ac[t] = an[t];
+    if (st + 1 < (int)nsteps) {
+#pragma unroll
+      for (int t = 0; t < NT_OUT; ++t) an[t] = load_frag<PREC>(img, nsteps, t, st + 1, lane);
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act[st >> 1][8 * (st & 1) + j];
+    const Frag b = split8(v, f);
+#pragma unroll
+    for (int t = 0; t < NT_OUT; ++t) out[t] = mma<PREC>(ac[t], b, out[t]);
+  }
+}
+
+struct DxSeg {
+  float* dx2;
+  uint32_t lddx2, acc1, acc2;                // acc: read-add-write instead of overwrite
+};
+
+// The values a read-add-write store of store_tile_rows_vec will add to: requested EARLY (all input-gradient tiles of a
+// point tile at once, before their matrix products), because a wave that is alone on its SIMD pays the full memory latency
+// of a load that is issued right in front of its use (measured: the accumulating networks took 220-260 us, the overwriting
+// one 144).  Zero where nothing is to be added.
+struct DxOld {
+  float4 v[4];
+};
+
+__device__ __forceinline__ void dx_old_issue(DxOld& o, const float* __restrict__ dst1, uint32_t ld1, const DxSeg& seg,
+                                             uint32_t n_in1, uint32_t col0, uint32_t ncols, const int* __restrict__ rows_lds,
+                                             uint32_t lane) {
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+  const uint32_t col = col0 + c4;
+  const bool second = seg.dx2 != nullptr && col >= n_in1;
+  const bool acc = second ? seg.acc2 != 0 : seg.acc1 != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rows_lds[rr + 8 * i];
+    o.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (acc && row >= 0 && c4 < ncols) {
+      const float4* p = second ? reinterpret_cast<const float4*>(seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1))
+                               : reinterpret_cast<const float4*>(dst1 + (size_t)row * ld1 + col);
+      o.v[i] = *p;
+    }
+  }
+}
+
+// a: 32 features x 32 points (true scale) -> dst[row][col0 + f] (f < ncols, ncols % 4 == 0, 16-byte aligned rows), rows
+// through the tile's row table; `old` (dx_old_issue) is added; optional second segment for columns >= n_in1
+__device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst1, uint32_t ld1, const DxSeg& seg, uint32_t n_in1,
+                                                    uint32_t col0, uint32_t ncols, const int* __restrict__ rows_lds,
+                                                    const f32x16& a, const DxOld& old, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t r = rr + 8 * i;
+    const int row = rows_lds[r];
+    float4 v = *reinterpret_cast<const float4*>(stg + r * STG_LD + c4);
+    if (row >= 0 && c4 < ncols) {
+      const uint32_t col = col0 + c4;
+      const bool second = seg.dx2 != nullptr && col >= n_in1;
+      float4* p = second ? reinterpret_cast<float4*>(seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1))
+                         : reinterpret_cast<float4*>(dst1 + (size_t)row * ld1 + col);
+      const float4 u = old.v[i];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      *p = v;
+    }
+  }
+  wave_lds_fence();
+}
+
+// same, dword accesses with lane = feature (any ld / alignment)
+__device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ dst1, uint32_t ld1, const DxSeg& seg,
+                                                           uint32_t n_in1, uint32_t col0, uint32_t ncols,
+                                                           const int* __restrict__ rows_lds, const f32x16& a,
+                                                           float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t f = lane & 31u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t r = (lane >> 5) + 2 * i;
+    const int row = rows_lds[r];
+    float v = stg[r * STG_LD + f];
+    if (row >= 0 && f < ncols) {
+      const uint32_t col = col0 + f;
+      const bool second = seg.dx2 != nullptr && col >= n_in1;
+      float* p = second ? seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1) : dst1 + (size_t)row * ld1 + col;
+      if (second ? seg.acc2 : seg.acc1) v += *p;
+      *p = v;
+    }
+  }
+  wave_lds_fence();
+}
+
+// dy columns 32c .. 32c+31 of the tile's rows as dword loads with lane = column (any lddy): 2 rows x 128 B per instruction
+struct DyChunk {
+  float v[16];
+};
+
+__device__ __forceinline__ void dy_chunk_issue(DyChunk& d, const float* __restrict__ dy, uint32_t lddy, uint32_t n_out,
+                                               const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
+  const uint32_t col = 32u * c + (lane & 31u);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = rows_lds[(lane >> 5) + 2 * i];
+    d.v[i] = (row >= 0 && col < n_out) ? dy[(size_t)row * lddy + col] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void dy_chunk_commit(const DyChunk& d, float* __restrict__ stg, uint32_t lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stg[((lane >> 5) + 2 * i) * STG_LD + (lane & 31u)] = d.v[i];
+  wave_lds_fence();
+}
+
+// the staged 32 x 32 tile T[row][col] read COLUMN-wise: lane (c = l & 31, h) gets rows 16 s + 8 h + j of column c
+__device__ __forceinline__ void stage_read_cols(float (&xs)[16], const float* __restrict__ stg, uint32_t lane) {
+  const float* src = stg + 8u * (lane >> 5) * STG_LD + (lane & 31u);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xs[8 * s + j] = src[(16 * s + j) * STG_LD];
+}
+
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+
+// accumulator tile (holding 2^k_lane * value, k_lane per lane) -> the two K-step fragments of the point-transposed form of
+// the TRUE values (lane = feature, elements = 8 consecutive points)
+__device__ __forceinline__ void transpose_frags(const f32x16& a, int k_lane, Frag3 (&out)[2], float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * STG_LD + pt] = ldexpf(a[r], -k_lane);
+  wave_lds_fence();
+  const float* src = stg + pt * STG_LD + 8u * h;     // here "pt" is the feature row of the transposed read
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float4 x0 = *reinterpret_cast<const float4*>(src + 16 * s), x1 = *reinterpret_cast<const float4*>(src + 16 * s + 4);
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    out[s] = split8_bf3(v);
+  }
+  wave_lds_fence();
+}
+
+struct BwdArgs {
+  const float* x;
+  uint32_t ldx;
+  XSeg seg;
+  const float* dy;
+  uint32_t lddy;
+  const float* params;
+  uint32_t n_in, n_out;
+  float* dx;
+  uint32_t lddx;
+  DxSeg dseg;
+  float* d_params;
+  float* dh1;                                // [n_slots, n_neurons] workspace: dH_1 for the dW_in kernel (NULL without d_params)
+  uint32_t n_slots;
+  const int32_t* row_index;
+  const int32_t* tile_group;
+  uint32_t param_stride, tiles_per_block;
+};
+
+// per-(n_neurons, n_hidden_layers) launchers: one translation unit each (mlp_split_bwd_*.hip)
+int launch_bwd_32_1(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
+int launch_bwd_32_2(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
+int launch_bwd_64_1(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
+int launch_bwd_64_2(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
+
+// adds the workgroup's four copies of one 32 x 32 accumulator tile (rows = dW rows, lanes = dW columns) and issues the
+// float atomics: one 128-byte row segment per lane half per instruction
+__device__ __forceinline__ void flush_tile(const f32x16& a, float* __restrict__ dst, uint32_t ld, uint32_t rows_valid,
+                                           uint32_t cols_valid, float* __restrict__ stg_base, uint32_t wave, uint32_t lane) {
+  float* stg = stg_base + wave * STG_WAVE_FLOATS;
+  const uint32_t j = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * STG_LD + j] = a[r];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = wave * 8u + 2u * i + h;
+    float v = 0.f;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) v += stg_base[w * STG_WAVE_FLOATS + row * STG_LD + j];
+    if (row < rows_valid && j < cols_valid && v != 0.f) atomicAdd(dst + (size_t)row * ld + j, v);
+  }
+  __syncthreads();
+}
+
+
+}  // namespace sp
+}  // namespace dns

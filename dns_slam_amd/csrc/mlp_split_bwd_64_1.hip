@@ -1,0 +1,4 @@
+// MLP backward kernels for 1 hidden layer(s) of 64 neurons (see mlp_split_bwd.inc).
+#define DNS_BWD_NN 64
+#define DNS_BWD_NL 1
+#include "mlp_split_bwd.inc"

@@ -201,10 +201,10 @@ def _row_major_2d(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-# True: the forward keeps the hidden activations (512 B/point at 2x64) and the backward skips the recompute;
-# False: nothing is kept and dns_mlp_bwd recomputes them from x (less memory, ~1.7x more MFMA work in the backward).
+# The backward recomputes the hidden activations (two layers of f16 matrix instructions cost less than reading 512 B per
+# point back from HBM): the forward keeps nothing.  True = dns_mlp_fwd also writes them (h_save; inspection only).
 LOSS_SUMS_FLOATS = 32 + 5 * 1024          # include/dns_hip.h DNS_LOSS_SUMS_FLOATS
-MLP_SAVE_HIDDEN = True
+MLP_SAVE_HIDDEN = False
 MLP_FP16_FLAG = 0x100                      # include/dns_hip.h DNS_MLP_FP16
 
 
@@ -227,7 +227,7 @@ class _MlpFn(torch.autograd.Function):
             y = torch.zeros(P, n_out, device=x.device, dtype=torch.float32)
         stride = params.shape[-1] if params.dim() == 2 else 0
         # keep the hidden activations when a backward will follow: it then skips the forward recompute
-        keep = (MLP_SAVE_HIDDEN or fp16) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        keep = MLP_SAVE_HIDDEN and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         h_save = torch.empty(nl * n_slots * nn, device=x.device, dtype=torch.float32) if keep else None
         check(lib.dns_mlp_fwd(ptr(x), x.stride(0), None, 0, 0, ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, n_slots,
                               ptr(row_index), ptr(tile_group), stride, ptr(h_save), fp16, stream_ptr()), "dns_mlp_fwd")
@@ -268,7 +268,7 @@ class _MlpCatFn(torch.autograd.Function):
         x1, x2 = _row_major_2d(x1.float()), _row_major_2d(x2.float())
         P, n1 = x1.shape
         y = torch.empty(P, n_out, device=x1.device, dtype=torch.float32)
-        h_save = torch.empty(nl * P * nn, device=x1.device, dtype=torch.float32)     # two-segment backward needs it
+        h_save = torch.empty(nl * P * nn, device=x1.device, dtype=torch.float32) if MLP_SAVE_HIDDEN else None
         check(lib.dns_mlp_fwd(ptr(x1), x1.stride(0), ptr(x2), x2.stride(0), n1, ptr(params), n_in, n_out, nn, nl, ptr(y),
                               n_out, P, None, None, 0, ptr(h_save), fp16, stream_ptr()), "dns_mlp_fwd")
         ctx.save_for_backward(x1, x2, params, h_save)
@@ -362,7 +362,7 @@ class _RenderNetsFn(torch.autograd.Function):
         buf = _row_major_2d(buf.float())
         pixel = pixel.float()
         P, dev = buf.shape[0], buf.device
-        keep = MLP_SAVE_HIDDEN or bool(fp16)
+        keep = MLP_SAVE_HIDDEN
         st = stream_ptr()
 
         def run(x, x2, n_in1, params, shape, y, ri, tg, n_slots, stride):

@@ -164,6 +164,7 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class
  * fine decoders of slams/mapping.py:590-601 without gathering activations. */
 #define DNS_MLP_FP16 0x100u   /* flags of dns_mlp_fwd; bit 8 of accumulate_dx of dns_mlp_bwd */
+#define DNS_MLP_EXACT_F32 0x200u /* development: the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) */
 int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,

@@ -67,6 +67,7 @@ class OracleModel:
         self.color = mk("color")
         self.logit = mk("logit")
         self.fine: Dict[int, torch.Tensor] = {int(c): mk("fine") for c in fine_classes}
+        self.taps = None                         # set to {} to record x and dL/d(grid features) of every pe_fn call (tests)
 
     def parameters(self):
         return [self.table, self.coarse, self.color, self.logit] + [self.fine[k] for k in sorted(self.fine)]
@@ -78,7 +79,12 @@ class OracleModel:
     # models/decoder.py:45-48
     def pe_fn(self, x):
         x = x.float()
-        return tr.oneblob_forward(x, self.cfg.n_bins), tr.hashgrid_forward(x, self.table, self.meta)
+        grid = tr.hashgrid_forward(x, self.table, self.meta)
+        if self.taps is not None and grid.requires_grad:
+            i = len(self.taps)
+            self.taps[i] = {"x": x.detach()}
+            grid.register_hook(lambda g, i=i: self.taps[i].__setitem__("d_grid", g.detach()))
+        return tr.oneblob_forward(x, self.cfg.n_bins), grid
 
     def _mlp(self, name, params, x):
         n_in, n_out = self.shapes[name]

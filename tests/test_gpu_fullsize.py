@@ -57,43 +57,120 @@ def test_fullsize_properties(workload):
 
 
 def test_cfg2_fullsize_matches_oracle():
-    """One full-size iteration (262 144 points) against the CPU oracle: loss terms and the table / coarse gradients."""
+    """One full-size iteration (262 144 ray points + the 63^3 smoothness lattice, bundle adjustment on) against the CPU
+    oracle: the seven loss terms and EVERY gradient -- hash table (element-wise, backward-error bound), coarse / colour /
+    logit networks, each per-class fine decoder, quaternions and translations of frames 1-3."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle import slam_ref as sr
-    from util import assert_close, oracle_from_product, randomise_, table_level_groups
+    from oracle import tcnn_ref as tr
+    from util import assert_close, mlp_param_groups, oracle_from_product, randomise_, table_level_groups
     wl, cfg, bound, cam, frames, mapper = _build("cfg2")
     dec = mapper.decoder
     randomise_(dec, 3)
     with torch.no_grad():
         dec.pe_fn.grid_fn.params.mul_(2000.0)
     randomise_([mapper.fine_decoders.pool], 4)
-    mapper.is_BA = False
+    mapper.is_BA = True
+    mapper.static_shapes = False                     # reference semantics: rays leaving the box are dropped (tiled labels, D1)
     _, ql, Tl = mapper.set_optimizer(frames)
     prep = mapper.prepare_frames(frames)
     torch.manual_seed(11)
     pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+    u_off, u_jit = torch.rand(3), torch.rand((1, 1, 1, 3))
     s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
-    loss, terms = mapper.iteration_loss(s, smooth=False)
-    loss.backward()
+    # record what every encode call of the product receives as upstream gradient (for the scatter-only check below)
+    from dns_slam_amd import ops as _ops
+    enc_calls, real_encode = [], _ops.encode
+
+    def spy_encode(pts_, table_, meta_, bound_=None, *a_, **k_):
+        out = real_encode(pts_, table_, meta_, bound_, *a_, **k_)
+        rec = {"pts": pts_.detach(), "bound": bound_}
+        out.register_hook(lambda g, rec=rec: rec.__setitem__("d_out", g.detach()))
+        enc_calls.append(rec)
+        return out
+
+    _ops.encode = spy_encode
+    try:
+        loss, terms = mapper.iteration_loss(s, smooth=True, u_offset=u_off, u_jitter=u_jit)
+        loss.backward()
+    finally:
+        _ops.encode = real_encode
     om = oracle_from_product(cfg, bound, dec, mapper, table64=True)
+    om.taps = {}
     camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
     npf = pix.numel() // 4
     fr = []
+    qo = [q.detach().cpu().clone().requires_grad_(f > 0) for f, q in enumerate(ql)]
+    To = [t.detach().cpu().clone().requires_grad_(f > 0) for f, t in enumerate(Tl)]
     for f in range(4):
         img5 = torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
-        fr.append(sr.frame_samples(img5, ql[f].detach().cpu(), Tl[f].detach().cpu(), camt, bound, pix.cpu()[f * npf:(f + 1) * npf],
+        fr.append(sr.frame_samples(img5, qo[f], To[f], camt, bound, pix.cpu()[f * npf:(f + 1) * npf],
                                    jit[0][f].cpu(), jit[1][f].cpu(), wl["nu"], wl["ns"]))
     so = sr.mapper_target_samples(fr)
-    lo, to, _ = sr.mapping_loss(om, so, sr.LossCfg())
+    lo, to, _ = sr.mapping_loss(om, so, sr.LossCfg(smooth_pts=wl["smooth_pts"]), u_off, u_jit)
     lo.backward()
-    for kp, ko in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"), ("opacity_loss", "op")):
+    for kp, ko in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"), ("opacity_loss", "op"),
+                   ("smooth_loss", "sm")):
         a, b = float(terms[kp]), float(to[ko])
         assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), (kp, a, b)
-    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad.float(), what="d table (full size)",
-                 groups=table_level_groups(om.meta))
-    n = 64 * 80 + 64 * 64 + 33 * 64
-    assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:n], om.coarse.grad[:n], what="d coarse (full size)")
+    # Table gradient, element by element.  A cell of a coarse level sums ~500 contributions w*g of either sign, so its fp32
+    # error scales with A = sum |w g| of the cell, not with the (cancelled) sum: |a - b| <= 1e-4 |b| + 1e-5 A, where A is the
+    # same scatter with |g| upstream (w >= 0), evaluated by the oracle in float64 -- the backward-error bound of an fp32
+    # accumulation whose terms are good to ~1e-5.  Up to 1e-4 of the 1.7 M entries may miss it (ReLU-kink flips of single
+    # points, see tests/util.py); every entry obeys the scale-relative 1e-4.
+    taps = [t for t in om.taps.values() if "d_grid" in t]
+    leaf = torch.zeros_like(om.table, requires_grad=True)
+    A = sum(torch.autograd.grad(tr.hashgrid_forward(t["x"], leaf, om.meta), leaf, t["d_grid"].abs())[0] for t in taps)
+    got_table = dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2)
+    assert_close(got_table, om.table.grad.float(), what="d table (full size)", atol=1e-5 * A, outlier_frac=1e-2)
+    # The entries outside that bound are ReLU-kink flips: a hidden unit within rounding of zero takes the other branch in one
+    # of the two fp32 implementations, which changes THAT point's 128 cell contributions by a few per cent -- visible in the
+    # fine levels' cells, which sum only a handful of points.  The scatter itself is therefore checked on its own, with no
+    # network in between: the product's OWN upstream gradients (recorded above) through the oracle's float64 scatter must
+    # reproduce the product's table gradient in EVERY entry to 1e-5 |b| + 1e-6 A + 1e-10 max|b| (the binned sums are exact in
+    # 64-bit fixed point with a quantum of 2^-40 of the launch's largest |gradient| per contribution -- the last term --; what
+    # remains is one fp32 rounding per chunk flush and the float atomics that combine chunk slices).
+    from oracle import render_math as rm
+    exp = torch.zeros_like(om.table)
+    A2 = torch.zeros_like(om.table)
+    for rec in enc_calls:
+        assert "d_out" in rec
+        x = rec["pts"].cpu()
+        if rec["bound"] is not None:
+            x = rm.normalise_points(x, bound)
+        g = rec["d_out"].cpu()[:, 48:].contiguous()
+        leaf = torch.zeros_like(om.table, requires_grad=True)
+        y = tr.hashgrid_forward(x.float(), leaf, om.meta)
+        exp += torch.autograd.grad(y, leaf, g, retain_graph=True)[0]
+        A2 += torch.autograd.grad(y, leaf, g.abs())[0]
+    assert len(enc_calls) == 2
+    assert_close(got_table, exp.float(), rtol=1e-5, what="d table (full size, scatter only)",
+                 atol=1e-6 * A2 + 1e-10 * float(exp.abs().max()))
+    used = lambda n_in, n_out: 64 * n_in + 64 * 64 + n_out * 64
+    grp = lambda n_in, n_out: mlp_param_groups(n_in, n_out, 64, 2)
+    assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:used(80, 33)], om.coarse.grad[:used(80, 33)], what="d coarse (full size)",
+                 groups=grp(80, 33))
+    assert_close(dec.out_fn.color_decoder.params.grad.cpu()[:used(112, 3)], om.color.grad[:used(112, 3)], what="d colour (full size)",
+                 groups=grp(112, 3))
+    assert_close(dec.out_fn.logit_decoder.params.grad.cpu()[:used(112, 8)], om.logit.grad[:used(112, 8)], what="d logit (full size)",
+                 groups=grp(112, 8))
+    pool_grad = mapper.fine_decoders.pool.grad.cpu()
+    n_fine = 0
+    for c, slot in mapper.fine_decoders.slot.items():
+        go = om.fine[c].grad
+        if go is None:
+            assert torch.count_nonzero(pool_grad[slot]) == 0
+        else:
+            assert_close(pool_grad[slot][:used(80, 33)], go[:used(80, 33)], what=f"d fine[{c}] (full size)", groups=grp(80, 33))
+            n_fine += 1
+    assert n_fine == 8
+    # Pose gradients: each is a sum over ~65 000 rays x 64 samples of terms of either sign, through the encoder's input
+    # gradient; both sides carry their own fp32 summation error (DESIGN.md section 2, tolerances): 2e-4 of the vector's scale
+    for f in range(1, 4):
+        assert_close(ql[f].grad.cpu(), qo[f].grad, rtol=2e-4, what=f"d quat[{f}] (full size)", elementwise=False)
+        assert_close(Tl[f].grad.cpu(), To[f].grad, rtol=2e-4, what=f"d T[{f}] (full size)", elementwise=False)
+    assert ql[0].grad is None
 
 
 def test_cfg2_prefetched_draws_same_trajectory_without_host_syncs(monkeypatch):

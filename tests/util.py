@@ -47,7 +47,7 @@ def _group_scales(b: torch.Tensor, groups) -> torch.Tensor:
     return s
 
 
-def elem_err(a: torch.Tensor, b: torch.Tensor, rtol=RTOL, groups=None, atol_factor=1.0) -> float:
+def elem_err(a: torch.Tensor, b: torch.Tensor, rtol=RTOL, groups=None, atol_factor=1.0, atol=None, outlier_frac=0.0) -> float:
     """Worst element-wise ratio |a-b| / (rtol*|b| + atol); <= 1 passes.  atol = atol_factor * rtol * (RMS of the non-zero
     reference entries of the element's group): an entry much smaller than its group's typical magnitude is a sum with
     cancellation, whose fp32 error scales with the terms (~ the group's magnitude), not with the result -- everything else
@@ -62,22 +62,35 @@ def elem_err(a: torch.Tensor, b: torch.Tensor, rtol=RTOL, groups=None, atol_fact
             return float("inf")
         m = torch.isfinite(b)
         a, b = torch.where(m, a, torch.zeros_like(a)), torch.where(m, b, torch.zeros_like(b))
-    tol = rtol * b.abs() + atol_factor * rtol * _group_scales(b, groups)
+    if atol is not None:                              # explicit per-element (or scalar) absolute term, e.g. from sum |terms|
+        tol = rtol * b.abs() + (atol.detach().double().cpu() if torch.is_tensor(atol) else float(atol))
+    else:
+        tol = rtol * b.abs() + atol_factor * rtol * _group_scales(b, groups)
     d = (a - b).abs()
     ok0 = (tol == 0) & (d == 0)
-    ratio = torch.where(ok0, torch.zeros_like(d), d / tol.clamp_min(1e-300))
+    ratio = torch.where(ok0, torch.zeros_like(d), d / tol.clamp_min(1e-300)).reshape(-1)
+    i = int(torch.argmax(ratio))
+    elem_err.worst = (i, a.reshape(-1)[i].item(), b.reshape(-1)[i].item(), tol.reshape(-1)[i].item())
+    if outlier_frac > 0.0 and ratio.numel() > 1:
+        # a hidden unit whose pre-activation is within rounding of zero falls on either side of the ReLU in two fp32
+        # implementations; the affected point's contribution then differs by a finite amount.  Such elements are allowed as a
+        # stated FRACTION of the tensor (they still obey the scale-relative criterion); the figure returned is the worst ratio
+        # among the rest.
+        k = max(int(ratio.numel() * (1.0 - outlier_frac)), 1)
+        return torch.kthvalue(ratio, k).values.item()
     return ratio.max().item()
 
 
-def assert_close(a, b, rtol=RTOL, what="", groups=None, atol_factor=1.0, elementwise=True):
+def assert_close(a, b, rtol=RTOL, what="", groups=None, atol_factor=1.0, elementwise=True, atol=None, outlier_frac=0.0):
     """Two criteria, both reported: (i) max|a-b| <= rtol * max|b| (the tensor's scale); (ii) element-wise
     |a-b| <= rtol*|b| + atol with the per-group atol of ``elem_err``."""
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     e = rel_err(a, b)
-    r = elem_err(a, b, rtol, groups, atol_factor) if elementwise else float("nan")
+    r = elem_err(a, b, rtol, groups, atol_factor, atol, outlier_frac) if elementwise else float("nan")
     REPORT.append((what, e, r, rtol))
     assert e <= rtol, f"{what}: scale-relative error {e:.3e} > {rtol:.1e} (element-wise ratio {r:.2f})"
-    assert not (r > 1.0), f"{what}: element-wise |a-b| <= {rtol:.0e}*|b| + atol violated, worst ratio {r:.2f} (scale-relative {e:.3e})"
+    assert not (r > 1.0), (f"{what}: element-wise |a-b| <= {rtol:.0e}*|b| + atol violated, worst ratio {r:.2f} (scale-relative "
+                           f"{e:.3e}); worst element (index, got, want, tolerance) = {getattr(elem_err, 'worst', None)}")
 
 
 def table_level_groups(meta, n_features=2):

@@ -16,4 +16,4 @@ for _ in range(10):
     y = ops.mlp(x, w, n_in, n_out, nn, nl); y.backward(gy)
 torch.cuda.synchronize()
 r = ops.timer.disarm()
-print(f"GEMM_BLOCKS={os.environ.get('DNS_GEMM_BLOCKS')} {n_in}->{nn}x{nl}->{n_out}: " + ", ".join(f"{k} {v[1] / v[0] * 1e3:.1f} us" for k, v in r.items()))
+print(f"{n_in}->{nn}x{nl}->{n_out}: " + ", ".join(f"{k} {v[1] / v[0] * 1e3:.1f} us" for k, v in r.items()))
