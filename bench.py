@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 
 WORKLOADS = {
     # name: rays/frame (uniform, by-class), n_uniform, n_surface, hash_size, voxel, neurons, layers, smooth_pts
@@ -38,6 +37,11 @@ WORKLOADS = {
                       "T=2^16 hash grid, 2x64 MLPs, 8 classes + per-class fine decoders, 63^3 smoothness lattice, Adam"),
     "ref": dict(rays=(332, 166), nu=32, ns=15, hash_size=16, voxel=0.02, nn=32, nl=1, smooth_pts=64,
                 desc="reference Replica defaults: 1992 rays x 47 samples, 1x32 MLPs"),
+    "cfg3": dict(rays=(683, 341), nu=48, ns=16, hash_size=16, voxel=0.02, nn=64, nl=2, smooth_pts=64, bound="office_0", code_seed=5,
+                 track_pixels=512,
+                 desc="BASELINE configs[2]: office_0 bound, 640x480, semantic head on (8 classes: logit network + per-class fine "
+                      "decoders), 2-D feature code U(-1,1) seed 5 on every sample, mapping iteration 4096 rays x 64 samples; the "
+                      "tracking loop (512 rays, 50 iterations per frame) is the `tracking` line"),
     "cfg5": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
                  desc="BASELINE configs[4] shape in fp32: scene0000 bound, 8192 rays x 128 samples, T=2^20 (58.7 MB table), "
                       "2x64 MLPs"),
@@ -48,27 +52,90 @@ WORKLOADS = {
 }
 
 
-def algorithmic_cost(name, units, wl):
-    """(bytes, flops) one launch of C-ABI entry `name` must move / compute for `units` points."""
-    nn, nl = wl["nn"], wl["nl"]
-    if name == "dns_encode_fwd":
-        return units * (16 * 8 * 2 * 4 + 12), 0            # 1024 B gathered per point + the point
-    if name == "dns_encode_bwd":
-        return units * (2 * 16 * 8 * 2 * 4 + 12), 0        # read-modify-write of the same 128 table cells
-    if name == "dns_composite_fwd" or name == "dns_composite_bwd":
-        return units * (wl["nu"] + wl["ns"]) * (4 + 1 + 8) * 4, 0   # units = rays; raw + z + logits per sample
-    return 0, 0
+F16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 1024 flop/clk/SIMD (32x32x16 in 32 clk) x 1024 SIMDs x 2.4 GHz
+SPLIT_PRODUCTS = 3             # f16 MFMAs per fp32 product on the forward-type products (hi*hi + hi*lo + lo*hi); weight gradients: 6 bf16
+
+
+def mlp_macs(info):
+    n_in, n_out, nn, nl = info["n_in"], info["n_out"], info["nn"], info["nl"]
+    return n_in * nn, (nl - 1) * nn * nn, nn * n_out          # first layer, hidden layers, output layer (per point)
+
+
+def kernel_cost(entry, kernel, units, info, wl):
+    """Algorithmic cost of ONE launch of `kernel`: ("hbm", bytes) or ("mfma", fp32-equivalent flops,
+    16-bit MFMA flops actually issued for them).  units = points / slots / rays of the launch."""
+    S = wl["nu"] + wl["ns"]
+    k = kernel.split("<")[0]
+    if k == "encode_fwd_kernel":
+        return ("hbm", units * (16 * 8 * 2 * 4 + 12))                     # 128 table cells of 8 B gathered + the point
+    if k == "dgrid_transpose_kernel":
+        return ("hbm", units * 2 * 32 * 4)                                 # [P,32] gradient read, level-major copy written
+    if k in ("hashgrid_bwd_binned_kernel", "hashgrid_bwd_queue_kernel"):
+        return ("hbm", units * (2 * 16 * 8 * 2 * 4 + 12 + 32 * 4))         # RMW of the same 128 cells + the point + its gradient
+    if k in ("composite_fwd_kernel", "composite_bwd_kernel"):
+        return ("hbm", units * S * (4 + 1 + 8) * 4 * (2 if k == "composite_bwd_kernel" else 1))   # raw + z + logits (and their gradients)
+    if k == "mlp_fwd_kernel":
+        m = sum(mlp_macs(info))
+        return ("mfma", 2 * units * m, 2 * units * m * (1 if wl.get("mlp_dtype") == "fp16" else SPLIT_PRODUCTS))
+    if k == "mlp_bwd_kernel":
+        m_in, m_hid, m_out = mlp_macs(info)
+        single = wl.get("mlp_dtype") == "fp16"
+        pf, pw = (1, 3) if single else (SPLIT_PRODUCTS, 6)
+        fwd_like = (m_in + m_hid) + (m_out + m_hid) + (m_in if info["dx"] else 0)   # recompute (no output layer), dH chain, dX
+        wgrad = (m_out + m_hid) if info["dw"] else 0                                # dW_out, dW_hidden (dW_in: mlp_dwin_kernel)
+        return ("mfma", 2 * units * (fwd_like + wgrad), 2 * units * (fwd_like * pf + wgrad * pw))
+    if k == "mlp_dwin_kernel":
+        m_in = mlp_macs(info)[0]
+        return ("mfma", 2 * units * m_in, 2 * units * m_in * (3 if wl.get("mlp_dtype") == "fp16" else 6))
+    return None
+
+
+def kernel_rooflines(spans, wl, steps, pmc):
+    """Per-kernel roofline rows from the library's own event spans (one per launch, on the launch stream)."""
+    agg = {}
+    for entry, kernel, ms, units, info in spans:
+        c = kernel_cost(entry, kernel, units, info, wl)
+        row = agg.setdefault(kernel.split("<")[0], {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "issued": 0, "modelled": c is not None})
+        row["launches"] += 1
+        row["ms"] += ms
+        if c and c[0] == "hbm":
+            row["bytes"] += c[1]
+        elif c:
+            row["flops"] += c[1]
+            row["issued"] += c[2]
+    rows = []
+    for k, r in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        out = {"kernel": k, "launches_per_step": r["launches"] / steps, "ms_per_step": r["ms"] / steps, "avg_launch_ms": r["ms"] / r["launches"]}
+        sec = r["ms"] / 1e3
+        if r["bytes"]:
+            ach = r["bytes"] / sec / 1e9
+            out.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]})
+        elif r["flops"]:
+            ach = r["flops"] / sec / 1e12
+            peak = F16_MFMA_PEAK_TFLOPS / (1 if wl.get("mlp_dtype") == "fp16" else SPLIT_PRODUCTS)
+            out.update({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "algorithmic_flops_per_launch": r["flops"] / r["launches"],
+                        "mfma_issue_frac": r["issued"] / sec / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                        "peak_note": "fp32-equivalent flops; peak = 16-bit dense MFMA peak / products per fp32 product "
+                                     "(3 x f16 forward-type, 6 x bf16 weight gradients: mfma_issue_frac counts those)"})
+        ent = (pmc or {}).get("kernels", {}).get(k)
+        out["traffic"] = (ent["fetch_bytes"] + ent["write_bytes"]) if ent else None
+        rows.append(out)
+    return rows
 
 
 def build(wl, device, seed, dist_ctx, overlap=False):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
-    bound, cam, frames = synthetic.make_scene(4, seed=0, bound=synthetic.SCENE0000_BOUND if wl.get("bound") == "scene0000" else None)
+    scene_bound = {"scene0000": synthetic.SCENE0000_BOUND, "office_0": synthetic.OFFICE0_BOUND}.get(wl.get("bound"))
+    bound, cam, frames = synthetic.make_scene(4, seed=0, bound=scene_bound)
     n_per_frame = sum(wl["rays"])
     cfg = synthetic.default_cfg(n_pixels=4 * n_per_frame, n_samples_ray=wl["nu"], n_surface_ray=wl["ns"], n_frames=4,
                                 hash_size=wl["hash_size"], voxel_size=wl["voxel"], n_neurons=wl["nn"],
-                                n_hidden_layers=wl["nl"], smooth_pts=wl["smooth_pts"], mlp_dtype=wl.get("mlp_dtype", "fp32"))
+                                n_hidden_layers=wl["nl"], smooth_pts=wl["smooth_pts"], mlp_dtype=wl.get("mlp_dtype", "fp32"),
+                                track_pixels=wl.get("track_pixels", 500))
     torch.manual_seed(1234)                                  # identical initial parameters on every rank
     dec = Decoder(cfg["model"], bound, n_class=8).to(device)
     mapper = Mapper(cfg, dec, bound, cam, device=device)
@@ -87,10 +154,16 @@ def build(wl, device, seed, dist_ctx, overlap=False):
     torch.manual_seed(seed)                                  # per-rank ray draws
     torch.cuda.manual_seed(seed)
     params = [p for g in optimizer.param_groups for p in g["params"]]
+    code = None
+    if wl.get("code_seed") is not None:      # 2-D feature code of every sample (U(-1,1), seed 5), resident in HBM
+        g = torch.Generator().manual_seed(wl["code_seed"])
+        code = (torch.rand(4 * n_per_frame, wl["nu"] + wl["ns"], 32, generator=g) * 2 - 1).to(device)
+
+    mapper.bench_code = code
 
     def step():
         optimizer.zero_grad(set_to_none=True)
-        samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep)
+        samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep, features=code)
         loss, terms = mapper.iteration_loss(samples, lambda_lt=10.0, smooth=True)
         loss.backward()
         dist_ctx.allreduce_grads(params)
@@ -158,6 +231,9 @@ def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
     npf = sum(wl["rays"])
     lc = sr.LossCfg(smooth_pts=wl["smooth_pts"])
     g = torch.Generator().manual_seed(0)
+    code = None
+    if wl.get("code_seed") is not None:
+        code = torch.rand(4 * npf, wl["nu"] + wl["ns"], 32, generator=torch.Generator().manual_seed(wl["code_seed"])) * 2 - 1
     times = []
     t_start = time.perf_counter()
     while True:
@@ -169,7 +245,7 @@ def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
             t = torch.rand(wl["ns"], generator=g)
             t[wl["ns"] // 2 + 1] = 0.5
             fr.append(sr.frame_samples(img5[f], quats[f], Ts[f], camt, bound, idx, t, torch.rand(wl["ns"], generator=g),
-                                       wl["nu"], wl["ns"]))
+                                       wl["nu"], wl["ns"], features=None if code is None else code[f * npf:(f + 1) * npf]))
         so = sr.mapper_target_samples(fr)
         loss, _, _ = sr.mapping_loss(om, so, lc, torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g))
         loss.backward()
@@ -250,14 +326,15 @@ def main():
     elapsed = ctx.max_over_ranks(elapsed, device)
     # per-kernel durations for the roofline: the same K steps launched eagerly with an event pair around every
     # C-ABI call (a replayed graph cannot be bracketed per kernel; kernels and shapes are identical)
-    kernel_times = {}
+    kernel_times, spans = {}, []
     if not args.no_kernel_timing:
         mapper.overlap_smooth = False           # one stream: an event pair must bracket its own kernel only
-        ops.timer.arm()
+        ops.timer.arm(kernels=True)             # + the library's own event pair around every kernel launch
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         kernel_times = ops.timer.disarm()
+        spans = ops.timer.kernel_spans
         mapper.overlap_smooth = overlap
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_rays * S * ctx.world_size / (ms_per_step / 1e3)
@@ -265,56 +342,51 @@ def main():
     if ctx.rank != 0:
         return
     roofline = None
-    breakdown = {}
+    breakdown, per_kernel = {}, []
+    pmc = None
+    try:        # HBM bytes per launch / per step from the committed rocprofv3 --pmc passes of this same command (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pmc.get("workload") != args.workload:
+            pmc = None
+    except Exception:
+        pass
     if kernel_times:
         tot_ms = sum(v[1] for v in kernel_times.values()) or 1.0
         for k, (calls, ms, units) in sorted(kernel_times.items(), key=lambda kv: -kv[1][1]):
             breakdown[k] = {"calls_per_step": calls / args.steps, "ms_per_step": ms / args.steps, "share": ms / tot_ms}
-        # dominant memory-bound entry point
-        name = max(kernel_times, key=lambda k: kernel_times[k][1])
-        calls, ms, units = kernel_times[name]
-        nbytes, flops = algorithmic_cost(name, units, wl)
-        if nbytes:
-            ach = nbytes / (ms / 1e3) / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "avg_launch_ms": ms / calls, "units_per_step": units / args.steps}
-        else:
-            # MFMA-bound MLP entry points: flops of the launches / time
-            fl = mlp_flops(name, kernel_times, wl, n_rays * S, args.steps)
-            ach = fl / (ms / 1e3) / 1e12
-            roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / calls}
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/), if present
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = pmc["entry_points"].get(name)
-            if ent and pmc.get("workload") == args.workload:
-                roofline["traffic"] = ent["hbm_bytes_per_launch"]
+        per_kernel = kernel_rooflines(spans, wl, args.steps, pmc)
+        modelled = [r for r in per_kernel if "frac" in r]
+        if modelled:
+            roofline = dict(modelled[0])            # the kernel with the largest summed duration in the timed steps
+            if pmc:
                 roofline["traffic_source"] = pmc["source"]
-        except Exception:
-            pass
     # whole-iteration rooflines of SURVEY 8d (per ray-sample and per GPU): HBM with the algorithmic 1024 B gathered + 2048 B
     # scattered + the 12-byte point, fp32 MFMA with 3 x the forward flops of the four render networks
     nn_, nl_ = wl["nn"], wl["nl"]
     macs_ = lambda n_in, n_out: n_in * nn_ + (nl_ - 1) * nn_ * nn_ + nn_ * n_out
-    flops_sample = 3 * 2 * (2 * macs_(80, 33) + macs_(112, 3) + macs_(112, 8))
+    flops_sample = 3 * 2 * (2 * macs_(80, 33) + macs_(112, 3) + macs_(112, 8))       # fwd + dX + dW of the four render networks
+    mlp_peak = F16_MFMA_PEAK_TFLOPS / (1 if wl.get("mlp_dtype") == "fp16" else SPLIT_PRODUCTS)
     bytes_sample = 3 * 16 * 8 * 2 * 4 + 12
     per_gpu = value / ctx.world_size
     iteration_roofline = {
         "hbm": {"bytes_per_ray_sample": bytes_sample, "achieved": per_gpu * bytes_sample / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": per_gpu * bytes_sample / 1e9 / HBM_PEAK_GBS},
         "mfma": {"flops_per_ray_sample": flops_sample, "achieved": per_gpu * flops_sample / 1e12,
-                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per_gpu * flops_sample / 1e12 / F32_MFMA_PEAK_TFLOPS},
-        "note": "per GPU, whole mapping iteration incl. the smoothness lattice, losses and Adam (not counted in the numerators)"}
+                 "peak": mlp_peak, "unit": "TFLOP/s", "frac": per_gpu * flops_sample / 1e12 / mlp_peak},
+        "traffic": pmc.get("hbm_bytes_per_step") if pmc else None,
+        "algorithmic_bytes_per_step": bytes_sample * n_rays * S,
+        "note": "per GPU, whole mapping iteration incl. the smoothness lattice, losses and Adam (not counted in the numerators); "
+                "traffic = sum of the PMC FETCH+WRITE bytes of every kernel of one iteration (profiles/pmc_traffic.json)"}
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands, f32 accumulate" if wl.get("mlp_dtype") == "fp16" else "f32", "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "final_loss": final_loss,
+        "scaling": "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
+                  "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "final_loss": final_loss,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
                    "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
         "roofline": roofline,
         "iteration_roofline": iteration_roofline,
+        "kernel_rooflines": per_kernel,
         "kernel_breakdown": breakdown,
     }
     # secondary line: forward-only full-image render of one 640x480 frame (frame_vis path), rays/s
@@ -364,18 +436,6 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "ray-samples/s", "cores": host_cores(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     print(json.dumps(out))
-
-
-def mlp_flops(name, kernel_times, wl, n_points, steps):
-    """Total flops the MLP launches of the timed region performed (forward 2*MACs; backward ~2x forward + recompute)."""
-    nn, nl = wl["nn"], wl["nl"]
-    def macs(n_in, n_out):
-        return n_in * nn + (nl - 1) * nn * nn + nn * n_out
-    lattice = (wl["smooth_pts"] - 1) ** 3
-    per_step_fwd = 2 * (n_points * (2 * macs(80, 33) + macs(112, 3) + macs(112, 8)) + lattice * macs(80, 33))
-    if name == "dns_mlp_fwd":
-        return per_step_fwd * steps
-    return 2 * per_step_fwd * steps        # data gradients + weight gradients (hidden activations are kept, no recompute)
 
 
 if __name__ == "__main__":

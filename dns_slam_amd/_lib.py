@@ -38,6 +38,9 @@ SIGNATURES = {
     "dns_abi_version": (C.c_int, []),
     "dns_last_error": (C.c_char_p, []),
     "dns_init": (C.c_int, []),
+    "dns_kernel_timing": (C.c_int, [C.c_int]),
+    "dns_kernel_timing_count": (C.c_int, []),
+    "dns_kernel_timing_get": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float)]),
     "dns_grid_meta_init": (C.c_int, [C.POINTER(DnsGridMeta), _U, _U, _U, _U, C.c_double]),
     "dns_raygen_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I,
                                     _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -85,7 +85,7 @@ extern "C" int dns_adam_step(const DnsAdamTensor* tensors, uint32_t n_tensors, f
   }
   b.n_tensors = k;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, beta1, beta2);
-  if (k) hipLaunchKernelGGL(adam_step_kernel, dim3(nb), dim3(256), 0, st, b, state, beta1, beta2, eps);
+  DNS_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, beta1, beta2);
+  if (k) DNS_LAUNCH(adam_step_kernel, dim3(nb), dim3(256), 0, st, b, state, beta1, beta2, eps);
   return check_launch("dns_adam_step");
 }

@@ -39,6 +39,22 @@ struct AttrRegistrar {
   explicit AttrRegistrar(AttrInitFn fn);
 };
 int ensure_ready(hipStream_t st, const char* who);
+
+// Per-kernel durations for bench.py's roofline (dns_kernel_timing, host.cpp): while timing is on, every launch made through
+// DNS_LAUNCH is bracketed by an event pair on ITS stream; off (the default) the scope costs one relaxed atomic load.
+struct KernelSpan {
+  KernelSpan(const char* name, hipStream_t st);
+  ~KernelSpan();
+  const char* name;
+  hipStream_t st;
+  hipEvent_t e0;
+  bool on;
+};
+#define DNS_LAUNCH(kern, grid, block, lds, st, ...)                    \
+  do {                                                                  \
+    dns::KernelSpan _span(#kern, st);                                   \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);        \
+  } while (0)
 constexpr int MAX_DYN_LDS = 160 * 1024;      // gfx950: 160 KiB of LDS per CU, all of it available to one workgroup
 
 // Device-side copy of the level table, passed by value as a kernel argument.

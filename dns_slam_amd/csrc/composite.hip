@@ -225,9 +225,9 @@ extern "C" int dns_composite_fwd(const float* raw, const float* z, const float* 
   hipStream_t st = (hipStream_t)stream;
   const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
   const size_t ldsb = 4 * 64 * E * sizeof(float);
-  if (E == 1) hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
-  else if (E == 2) hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
-  else hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
+  if (E == 1) DNS_LAUNCH(composite_fwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
+  else if (E == 2) DNS_LAUNCH(composite_fwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
+  else DNS_LAUNCH(composite_fwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
   return check_launch("dns_composite_fwd");
 }
 
@@ -244,8 +244,8 @@ extern "C" int dns_composite_bwd(const float* raw, const float* z, const float* 
   hipStream_t st = (hipStream_t)stream;
   const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
   const size_t ldsb = 4 * 64 * E * sizeof(float);
-  if (E == 1) hipLaunchKernelGGL(composite_bwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
-  else if (E == 2) hipLaunchKernelGGL(composite_bwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
-  else hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
+  if (E == 1) DNS_LAUNCH(composite_bwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
+  else if (E == 2) DNS_LAUNCH(composite_bwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
+  else DNS_LAUNCH(composite_bwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
   return check_launch("dns_composite_bwd");
 }

@@ -815,10 +815,10 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
   const bool tiled = pe_out && grid_out && ld_pe == pe_dim + g_dim && ld_grid == ld_pe && grid_out == pe_out + pe_dim;
   if (tiled) {
     const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
-    hipLaunchKernelGGL(encode_fwd_kernel<true>, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound),
+    DNS_LAUNCH(encode_fwd_kernel<true>, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound),
                        bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid);
   } else {
-    hipLaunchKernelGGL(encode_fwd_kernel<false>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, in, make_bound(bound),
+    DNS_LAUNCH(encode_fwd_kernel<false>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, in, make_bound(bound),
                        bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid);
   }
   return check_launch("dns_encode_fwd");
@@ -853,12 +853,12 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     const bool tiled = d_pe && d_grid && d_x && ld_dpe == ld_dgrid && d_grid == d_pe + 3 * n_bins &&
                        ld_dpe == 3 * n_bins + 2 * lv.n_levels;
     if (tiled) {
-      hipLaunchKernelGGL(encode_bwd_kernel<true>, dim3(blocks128), dim3(128),
+      DNS_LAUNCH(encode_bwd_kernel<true>, dim3(blocks128), dim3(128),
                          (size_t)128 * ((3 * n_bins > 2 * lv.n_levels ? 3 * n_bins : 2 * lv.n_levels) + 1) * sizeof(float), st, x,
                          make_bound(bound), bound ? 1 : 0, P, n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid,
                          d_table_direct, d_x);
     } else {
-      hipLaunchKernelGGL(encode_bwd_kernel<false>, dim3(blocks128), dim3(128), 0, st, x, make_bound(bound), bound ? 1 : 0, P,
+      DNS_LAUNCH(encode_bwd_kernel<false>, dim3(blocks128), dim3(128), 0, st, x, make_bound(bound), bound ? 1 : 0, P,
                          n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid, d_table_direct, d_x);
     }
   }
@@ -918,9 +918,9 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       return DNS_E_LAUNCH;
     }
     DNS_REQUIRE(lv.n_levels <= 16, "dns_encode_bwd: binned scatter supports <= 16 levels");
-    hipLaunchKernelGGL(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
+    DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
     if (jobs)
-      hipLaunchKernelGGL(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);
+      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);
     if (part) {
       uint32_t* qcount = gmax + 4;
       float* queues = reinterpret_cast<float*>(qcount + DNS_MAX_LEVELS * PART_MAX_CHUNKS);
@@ -928,9 +928,9 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
         set_error("dns_encode_bwd: memset failed");
         return DNS_E_LAUNCH;
       }
-      hipLaunchKernelGGL(hashgrid_bwd_partition_kernel, dim3((P + PART_THREADS - 1) / PART_THREADS), dim3(PART_THREADS), 0, st, x, P, lv,
+      DNS_LAUNCH(hashgrid_bwd_partition_kernel, dim3((P + PART_THREADS - 1) / PART_THREADS), dim3(PART_THREADS), 0, st, x, P, lv,
                          pp, (const float2*)ws, qcount, queues, d_table);
-      hipLaunchKernelGGL(hashgrid_bwd_queue_kernel, dim3(pp.qoff[pp.n] * pp.slices), dim3(1024), lds_bytes, st, lv, pp,
+      DNS_LAUNCH(hashgrid_bwd_queue_kernel, dim3(pp.qoff[pp.n] * pp.slices), dim3(1024), lds_bytes, st, lv, pp,
                          qcount, queues, gmax, d_table);
     }
   }
@@ -940,7 +940,7 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
 extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, uint32_t* rows, void* stream) {
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(x && meta && rows, "dns_hashgrid_indices: NULL argument");
-  hipLaunchKernelGGL(hashgrid_indices_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, P,
+  DNS_LAUNCH(hashgrid_indices_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, P,
                      to_levels(meta), rows);
   return check_launch("dns_hashgrid_indices");
 }

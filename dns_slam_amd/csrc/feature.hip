@@ -71,7 +71,7 @@ extern "C" int dns_feature_gather(const float* pts, const float* w2c, const floa
   for (int i = 0; i < 9; ++i) Km.k[i] = K[i];
   const uint64_t pairs = (uint64_t)R * P;
   DNS_REQUIRE((pairs + 3) / 4 < (1ull << 31), "dns_feature_gather: too many points");
-  hipLaunchKernelGGL(feature_gather_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pts, w2c, Km,
+  DNS_LAUNCH(feature_gather_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pts, w2c, Km,
                      feat, R, P, C, h, w, H, W, code, mask);
   return check_launch("dns_feature_gather");
 }

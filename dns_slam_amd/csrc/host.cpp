@@ -3,6 +3,8 @@
 #include <string.h>
 #include <atomic>
 #include <mutex>
+#include <vector>
+#include <stdio.h>
 #include "common.hpp"
 
 namespace dns {
@@ -54,7 +56,57 @@ int ensure_ready(hipStream_t st, const char* who) {
   (void)hipGetLastError();
   return init_current_device();
 }
+
+// ---- per-kernel event timing (measurement aid; see KernelSpan in common.hpp) ----
+struct SpanRec {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+static std::atomic<int> g_timing{0};
+static std::mutex g_span_mutex;                    // launches come from the caller's thread AND the autograd thread
+static std::vector<SpanRec> g_spans;
+
+KernelSpan::KernelSpan(const char* name_, hipStream_t st_) : name(name_), st(st_), e0(nullptr), on(false) {
+  if (!g_timing.load(std::memory_order_relaxed)) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;   // no timing in a capture
+  if (hipEventCreate(&e0) != hipSuccess) return;
+  on = hipEventRecord(e0, st) == hipSuccess;
+}
+KernelSpan::~KernelSpan() {
+  if (!on) return;
+  hipEvent_t e1;
+  if (hipEventCreate(&e1) != hipSuccess || hipEventRecord(e1, st) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_span_mutex);
+  g_spans.push_back({name, e0, e1});
+}
 }  // namespace dns
+
+extern "C" int dns_kernel_timing(int enable) {
+  std::lock_guard<std::mutex> lock(dns::g_span_mutex);
+  if (enable) {
+    for (auto& s : dns::g_spans) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
+    dns::g_spans.clear();
+  }
+  dns::g_timing.store(enable ? 1 : 0);
+  return DNS_OK;
+}
+extern "C" int dns_kernel_timing_count(void) {
+  std::lock_guard<std::mutex> lock(dns::g_span_mutex);
+  return (int)dns::g_spans.size();
+}
+extern "C" int dns_kernel_timing_get(int i, char* name, int name_cap, float* ms) {
+  std::lock_guard<std::mutex> lock(dns::g_span_mutex);
+  DNS_REQUIRE(i >= 0 && i < (int)dns::g_spans.size(), "dns_kernel_timing_get: span %d of %d", i, (int)dns::g_spans.size());
+  DNS_REQUIRE(name != nullptr && name_cap > 1 && ms != nullptr, "dns_kernel_timing_get: NULL output");
+  const dns::SpanRec& s = dns::g_spans[i];
+  if (hipEventSynchronize(s.e1) != hipSuccess || hipEventElapsedTime(ms, s.e0, s.e1) != hipSuccess) {
+    dns::set_error("dns_kernel_timing_get: %s", hipGetErrorString(hipGetLastError()));
+    return DNS_E_LAUNCH;
+  }
+  snprintf(name, (size_t)name_cap, "%s", s.name);
+  return DNS_OK;
+}
 
 extern "C" int dns_init(void) { return dns::init_current_device(); }
 extern "C" int dns_abi_version(void) { return DNS_ABI_VERSION; }

@@ -369,14 +369,14 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
   DNS_REQUIRE(tracker || (fine && coarse && z && L >= 1 && S >= 1), "dns_loss_sums: mapper mode needs fine, coarse, z");
   DNS_REQUIRE(tracker || (uint64_t)N * S * L < (1ull << 32) - (1ull << 22), "dns_loss_sums: N*S*L must stay below 2^32");
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
-  hipLaunchKernelGGL(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
+  DNS_LAUNCH(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
                      pred_logits, gt_color, gt_depth, gt_label, valid, sums);
   if (!tracker) {
     const uint64_t E = (uint64_t)N * S * L;
     // few, fat workgroups: every workgroup ends in 5 atomics on the same 5 words (same-address atomics serialise)
     const uint32_t cap = S_MAX_BLOCKS;
     const uint32_t blocks = (uint32_t)((E + 255) / 256 < cap ? (E + 255) / 256 : cap);
-    hipLaunchKernelGGL(loss_point_sums_kernel, dim3(blocks), dim3(256), 0, st, c, fine, coarse, z, gt_depth, valid, sums);
+    DNS_LAUNCH(loss_point_sums_kernel, dim3(blocks), dim3(256), 0, st, c, fine, coarse, z, gt_depth, valid, sums);
   }
   return check_launch("dns_loss_sums");
 }
@@ -385,7 +385,7 @@ extern "C" int dns_loss_finalize(const float* lambdas, uint32_t N, uint32_t S, u
                                  const float* sums, float* out, void* stream) {
   DNS_REQUIRE(lambdas && sums && out, "dns_loss_finalize: NULL argument");
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c, sums, out);
+  DNS_LAUNCH(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c, sums, out);
   return check_launch("dns_loss_finalize");
 }
 
@@ -401,12 +401,12 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
   DNS_REQUIRE(tracker || (d_fine && d_coarse), "dns_loss_bwd: mapper mode needs d_fine and d_coarse");
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_ray_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, out, g_total, pred_color, pred_depth,
+  DNS_LAUNCH(loss_ray_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, out, g_total, pred_color, pred_depth,
                      pred_var, pred_logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var, d_logits);
   if (!tracker) {
     const uint64_t E = (uint64_t)N * S * L;
     const uint32_t blocks = (uint32_t)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
-    hipLaunchKernelGGL(loss_point_bwd_kernel, dim3(blocks), dim3(256), 0, st, c, out, g_total, fine, coarse, z, gt_depth,
+    DNS_LAUNCH(loss_point_bwd_kernel, dim3(blocks), dim3(256), 0, st, c, out, g_total, fine, coarse, z, gt_depth,
                        valid, d_fine, d_coarse);
   }
   return check_launch("dns_loss_bwd");

@@ -144,7 +144,7 @@ extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sa
   const uint32_t total = n * n * n;
   const uint32_t blocks = (total + 255) / 256 < 256 ? (total + 255) / 256 : 256;   // each ends in one atomic on ONE word
   const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
-  hipLaunchKernelGGL(tv_fwd_kernel, dim3(blocks), dim3(256), 0, st, lat, ld, n, inv, out);
+  DNS_LAUNCH(tv_fwd_kernel, dim3(blocks), dim3(256), 0, st, lat, ld, n, inv, out);
   return check_launch("dns_tv_fwd");
 }
 
@@ -155,7 +155,7 @@ extern "C" int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sa
   const uint32_t total = n * n * n * ld;
   const uint32_t blocks = (total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192;
   const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
-  hipLaunchKernelGGL(tv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lat, ld, n, inv, g, d_lat);
+  DNS_LAUNCH(tv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lat, ld, n, inv, g, d_lat);
   return check_launch("dns_tv_bwd");
 }
 
@@ -175,9 +175,9 @@ extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_
   }
   if (P) {
     const uint32_t hb = (P + 255) / 256 < 512 ? (P + 255) / 256 : 512;
-    hipLaunchKernelGGL(group_hist_kernel, dim3(hb), dim3(256), 0, st, slot_of_point, P, n_groups, counts);
+    DNS_LAUNCH(group_hist_kernel, dim3(hb), dim3(256), 0, st, slot_of_point, P, n_groups, counts);
   }
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, st, counts, n_groups, min_count, n_slots / 128u, cursor, tile_group);
-  if (P) hipLaunchKernelGGL(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index);
+  DNS_LAUNCH(group_scan_kernel, dim3(1), dim3(256), 0, st, counts, n_groups, min_count, n_slots / 128u, cursor, tile_group);
+  if (P) DNS_LAUNCH(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index);
   return check_launch("dns_group_slots");
 }

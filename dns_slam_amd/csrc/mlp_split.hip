@@ -320,8 +320,8 @@ int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
 #define LAUNCH_FWD(NN, NL)                                                                                           \
   {                                                                                                                  \
     const size_t lds_bytes = FwdLds<NN, NL>::total(n_in, n_out, 4);                                                  \
-    if (fp16_single) hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL, 1>), dim3(blocks), dim3(256), lds_bytes, st, a);     \
-    else hipLaunchKernelGGL((mlp_fwd_kernel<NN, NL, 3>), dim3(blocks), dim3(256), lds_bytes, st, a);                 \
+    if (fp16_single) DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 1>), dim3(blocks), dim3(256), lds_bytes, st, a);     \
+    else DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 3>), dim3(blocks), dim3(256), lds_bytes, st, a);                 \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
@@ -366,8 +366,8 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
   const uint32_t it = (n_in + 31u) / 32u;
 #define LAUNCH_DWIN2(NN, IT)                                                                                          \
   {                                                                                                                   \
-    if (fp16_single) hipLaunchKernelGGL((mlp_dwin_kernel<NN, IT, 1>), dim3(blocks2), dim3(256), lds2, st, d);        \
-    else hipLaunchKernelGGL((mlp_dwin_kernel<NN, IT, 3>), dim3(blocks2), dim3(256), lds2, st, d);                     \
+    if (fp16_single) DNS_LAUNCH((mlp_dwin_kernel<NN, IT, 1>), dim3(blocks2), dim3(256), lds2, st, d);        \
+    else DNS_LAUNCH((mlp_dwin_kernel<NN, IT, 3>), dim3(blocks2), dim3(256), lds2, st, d);                     \
   }
 #define LAUNCH_DWIN(NN)                  \
   {                                      \

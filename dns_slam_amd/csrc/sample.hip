@@ -406,7 +406,7 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
       set_error("dns_raygen_sample: memset failed");
       return DNS_E_LAUNCH;
     }
-    hipLaunchKernelGGL(depth_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pix_idx, depth, H, W, H0, W0, wwin, n_frames, n_per_frame, depth_max_ws);
+    DNS_LAUNCH(depth_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pix_idx, depth, H, W, H0, W0, wwin, n_frames, n_per_frame, depth_max_ws);
   }
   BoundD bd;
   for (int i = 0; i < 6; ++i) bd.b[i] = bound[i];
@@ -414,7 +414,7 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
   const int S = n_uniform + n_surface;
   const dim3 grid((n + 3) / 4), block(256);
 #define LAUNCH_RS(E)                                                                                                   \
-  hipLaunchKernelGGL(raygen_sample_kernel<E>, grid, block, 0, st, pix_idx, color, depth, label, quat, trans, c, bd, H, \
+  DNS_LAUNCH(raygen_sample_kernel<E>, grid, block, 0, st, pix_idx, color, depth, label, quat, trans, c, bd, H, \
                      W, H0, W0, wwin, n_frames, n_per_frame, t_uniform, t_surf, t_zero, n_uniform, n_surface,          \
                      jitter_stride, depth_max_ws, rays_o, rays_d, gt_color, gt_depth, gt_label, inside, z, pts)
   if (S <= 64) LAUNCH_RS(1);
@@ -436,12 +436,12 @@ extern "C" int dns_sample_along_rays(const float* gt_depth, const double* far_bb
     set_error("dns_sample_along_rays: memset failed");
     return DNS_E_LAUNCH;
   }
-  hipLaunchKernelGGL(depth_max_flat_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, st, gt_depth, n_rays, depth_max_ws);
+  DNS_LAUNCH(depth_max_flat_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, st, gt_depth, n_rays, depth_max_ws);
   const int S = n_uniform + n_surface;
   const dim3 grid((n_rays + 3) / 4), block(256);
-  if (S <= 64) hipLaunchKernelGGL(sample_along_rays_kernel<1>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
-  else if (S <= 128) hipLaunchKernelGGL(sample_along_rays_kernel<2>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
-  else hipLaunchKernelGGL(sample_along_rays_kernel<4>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
+  if (S <= 64) DNS_LAUNCH(sample_along_rays_kernel<1>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
+  else if (S <= 128) DNS_LAUNCH(sample_along_rays_kernel<2>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
+  else DNS_LAUNCH(sample_along_rays_kernel<4>, grid, block, 0, st, gt_depth, far_bb, n_rays, t_uniform, t_surf, t_zero, n_uniform, n_surface, depth_max_ws, z);
   return check_launch("dns_sample_along_rays");
 }
 
@@ -459,9 +459,9 @@ extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const d
     set_error("dns_raygen_bwd: memset failed");
     return DNS_E_LAUNCH;
   }
-  hipLaunchKernelGGL(raygen_bwd_reduce_kernel, dim3((n_per_frame + 63) / 64, n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
+  DNS_LAUNCH(raygen_bwd_reduce_kernel, dim3((n_per_frame + 63) / 64, n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
                      n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);
-  hipLaunchKernelGGL(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
+  DNS_LAUNCH(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
   return check_launch("dns_raygen_bwd");
 }
 
@@ -475,7 +475,7 @@ extern "C" int dns_rays_from_pixels(const int64_t* pix_idx, const float* image, 
   DNS_REQUIRE(!sample || (image && C >= 1 && C <= 8), "dns_rays_from_pixels: sample rows need image and 1 <= C <= 8");
   Cam c;
   c.fx = (float)cam[0]; c.fy = (float)cam[1]; c.cx = (float)cam[2]; c.cy = (float)cam[3];
-  hipLaunchKernelGGL(rays_from_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pix_idx, image, C, R, T,
+  DNS_LAUNCH(rays_from_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pix_idx, image, C, R, T,
                      c, W, H0, W0, W1 - W0, n, rays_o, rays_d, sample, ij);
   return check_launch("dns_rays_from_pixels");
 }

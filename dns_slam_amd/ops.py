@@ -20,26 +20,34 @@ class _TimedLib:
 
     def __init__(self, raw):
         self._raw = raw
-        self.records = None          # list of (name, start_event, end_event) while armed
+        self.records = None          # list of (name, start_event, end_event, units, key arguments, kernel-span range) while armed
+        self.kernels = False         # also collect the library's per-kernel spans (dns_kernel_timing)
 
     def __getattr__(self, name):
         fn = getattr(self._raw, name)
         if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_last_error",
-                                            "dns_abi_version", "dns_init"):
+                                            "dns_abi_version", "dns_init") or name.startswith("dns_kernel_timing"):
             return fn
 
         ui = self._UNITS_ARG.get(name)
+        info_of = self._INFO.get(name)
 
         def timed(*a):
+            k0 = self._raw.dns_kernel_timing_count() if self.kernels else 0
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*a)
             e1.record()
+            k1 = self._raw.dns_kernel_timing_count() if self.kernels else 0
             units = 0 if ui is None else (a[ui] if not isinstance(ui, tuple) else a[ui[0]] * a[ui[1]])
-            self.records.append((name, e0, e1, int(units)))
+            self.records.append((name, e0, e1, int(units), info_of(a) if info_of else None, (k0, k1)))
             return rc
         return timed
+
+    # per-call facts the roofline needs: the network shape of an MLP launch and which gradients it produces
+    _INFO = {"dns_mlp_fwd": lambda a: {"n_in": a[6], "n_out": a[7], "nn": a[8], "nl": a[9]},
+             "dns_mlp_bwd": lambda a: {"n_in": a[8], "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]), "dw": bool(a[16])}}
 
     # argument index holding the number of units (points / slots / rays) a launch processes
     _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 12, "dns_mlp_bwd": 18,
@@ -47,16 +55,28 @@ class _TimedLib:
                   "dns_rays_from_pixels": 12,
                   "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5)}
 
-    def arm(self):
+    def arm(self, kernels=False):
+        self.kernels = bool(kernels)
+        if self.kernels:
+            check(self._raw.dns_kernel_timing(1), "dns_kernel_timing")
         self.records = []
 
     def disarm(self):
-        """-> {entry point: (calls, total_ms, total_units)}; call after a device synchronise."""
+        """-> {entry point: (calls, total_ms, total_units)}; call after a device synchronise.  With ``arm(kernels=True)``
+        ``self.kernel_spans`` then holds one ``(entry point, kernel, ms, units, info)`` per kernel launch."""
         recs, self.records = self.records or [], None
         out = {}
-        for name, e0, e1, units in recs:
+        spans = []
+        if self.kernels:
+            check(self._raw.dns_kernel_timing(0), "dns_kernel_timing")
+            buf, ms = C.create_string_buffer(160), C.c_float()
+        for name, e0, e1, units, info, (k0, k1) in recs:
             c, t, u = out.get(name, (0, 0.0, 0))
             out[name] = (c + 1, t + e0.elapsed_time(e1), u + units)
+            for k in range(k0, k1):
+                check(self._raw.dns_kernel_timing_get(k, buf, 160, C.byref(ms)), "dns_kernel_timing_get")
+                spans.append((name, buf.value.decode().strip("()"), float(ms.value), units, info))
+        self.kernel_spans, self.kernels = spans, False
         return out
 
 

@@ -15,6 +15,7 @@ import torch
 
 ROOM0_BOUND = [[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]]
 SCENE0000_BOUND = [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]]
+OFFICE0_BOUND = [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]]      # reference configs/replica/office_0.yaml:4
 
 
 def load_bound(bound, bound_divisible=0.32, scale=1.0) -> torch.Tensor:

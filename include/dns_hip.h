@@ -62,6 +62,14 @@ const char* dns_last_error(void);
  * device. */
 int dns_init(void);
 
+/* Measurement aid (bench.py's roofline): dns_kernel_timing(1) clears the record and brackets every kernel the library
+ * launches from then on with an event pair on its launch stream (never inside a stream capture); dns_kernel_timing(0)
+ * stops.  dns_kernel_timing_count() = spans recorded so far; dns_kernel_timing_get(i, ...) waits for span i and returns
+ * the kernel's name and its duration in milliseconds. */
+int dns_kernel_timing(int enable);
+int dns_kernel_timing_count(void);
+int dns_kernel_timing_get(int i, char* name, int name_cap, float* ms);
+
 /* [host] fills *meta.  per_level_scale is the float64 value reference pos_encoding.py:33 computes. */
 int dns_grid_meta_init(DnsGridMeta* meta, uint32_t n_levels, uint32_t n_features,
                        uint32_t log2_hashmap_size, uint32_t base_resolution, double per_level_scale);
@@ -156,6 +164,9 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * params: flat fp32 [n_neurons*n_in | (n_hidden_layers-1)*n_neurons^2 | out_pad*n_neurons], row-major
  * matrices, out_pad = next multiple of 16 of n_out.  n_neurons in {32,64}; n_hidden_layers in {1,2};
  * n_in a multiple of 8 and <= 128; n_out <= 64; x 16-byte aligned with ldx % 4 == 0.
+ * Arithmetic: every fp32 operand is split into two f16 parts (power-of-two scaled per matrix / per point) and a product
+ * is three v_mfma_f32_32x32x16_f16 with fp32 accumulation -- error below an fp32 fma chain's;
+ * DNS_MLP_FP16 keeps the leading part only (tcnn's own precision: fp16 operands, fp32 accumulate).
  * Two-segment input (x2 != NULL): input columns [0, n_in1) are read from x, columns [n_in1, n_in) from
  * x2[row*ldx2 + (col - n_in1)] -- the torch.cat((pe, features), -1) inputs of decoder.py:73,93,123-124 without
  * the copy.  n_in1 % 4 == 0; x2 16-byte aligned, ldx2 % 4 == 0.  x2 == NULL: one segment (ldx2, n_in1 ignored).
@@ -164,23 +175,22 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class
  * fine decoders of slams/mapping.py:590-601 without gathering activations. */
 #define DNS_MLP_FP16 0x100u   /* flags of dns_mlp_fwd; bit 8 of accumulate_dx of dns_mlp_bwd */
-#define DNS_MLP_EXACT_F32 0x200u /* development: the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) */
 int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
-                float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: hidden activations kept for dns_mlp_bwd */,
-                uint32_t flags /* DNS_MLP_FP16: fp16 operands, fp32 accumulate (tcnn's precision); 0: exact fp32 */,
-                void* stream);
+                float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: also write the hidden activations (inspection;
+                                 the backward does not need them) */,
+                uint32_t flags /* 0 or DNS_MLP_FP16 */, void* stream);
 
-/* Backward.  Hidden activations come from h_saved (what dns_mlp_fwd wrote) or, if NULL, are recomputed from x
- * (one-segment inputs only).  d_x [rows, lddx] (columns [0, n_in1)) and, with a two-segment input, d_x2
- * [rows, lddx2] (columns [n_in1, n_in)) are written for valid slots (d_x NULL = skip both); d_params (+=) same
- * layout as params (+ group*param_stride), NULL = skip.  ws: 16-byte aligned float workspace of
- * dns_mlp_bwd_ws_floats(n_slots, n_neurons, n_hidden_layers) elements.
- * accumulate_dx: bit 0 -> d_x += instead of =, bit 1 -> d_x2 += (several networks reading one input add their
- * input gradients in place instead of through separate buffers and an add); | DNS_MLP_FP16: data-gradient products with
- * fp16 operands (per-tile power-of-two scaling), fp32 accumulate; dH, the weight gradients and their GEMM stay fp32. */
+/* Backward.  Hidden activations are RECOMPUTED from x (h_saved is accepted and ignored).  One kernel produces d_x, dW_hidden
+ * and dW_out and leaves dH_1 in ws; a second, streaming kernel forms dW_in = dH_1^T x.  d_x [rows, lddx] (columns
+ * [0, n_in1)) and, with a two-segment input, d_x2 [rows, lddx2] (columns [n_in1, n_in)) are written for valid slots (d_x NULL
+ * = skip both); d_params (+=) same layout as params (+ group*param_stride), NULL = skip (no weight-gradient work at all:
+ * the tracker's frozen scene).  ws: 16-byte aligned workspace of dns_mlp_bwd_ws_floats(...) floats (needed with d_params).
+ * accumulate_dx: bit 0 -> d_x += instead of =, bit 1 -> d_x2 += (several networks reading one input add their input
+ * gradients in place instead of through separate buffers and an add); | DNS_MLP_FP16: as in the forward (weight gradients
+ * then use two bf16 parts, 16 significant bits). */
 int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* dy, uint32_t lddy, const float* params,
                 uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,

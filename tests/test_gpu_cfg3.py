@@ -1,0 +1,192 @@
+"""GPU parity for BASELINE.json configs[2] ("cfg3"): office_0 bound, T=2^16 hash grid at 2 cm, 2x64 MLPs, semantic
+head on (8-class logit network + per-class fine decoders), a 2-D feature code U(-1,1) (seed 5) on every sample, tracker with
+512 rays.  One mapping iteration (slams/mapping.py:881-910) and a 50-iteration ``Tracker.track_frame`` (slams/tracking.py:
+313-340) are replayed against the oracle -- the tracker step by step with torch.optim.Adam on the same draws."""
+import pytest
+import torch
+
+from oracle import slam_ref as sr
+from util import REPORT, assert_close, assert_pose_grad_close, oracle_from_product, randomise_, table_level_groups
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NU, NS = 48, 16
+
+
+def _setup(n_pixels=1024, track_pixels=512, smooth_pts=16, H=120, W=160):
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    cam = synthetic.camera(H=H, W=W, fx=W * 0.75, fy=W * 0.75)
+    bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=0, bound=synthetic.OFFICE0_BOUND)
+    cfg = synthetic.default_cfg(n_pixels=n_pixels, n_samples_ray=NU, n_surface_ray=NS, n_frames=4, hash_size=16,
+                                voxel_size=0.02, n_neurons=64, n_hidden_layers=2, smooth_pts=smooth_pts,
+                                track_pixels=track_pixels, track_iters=50)
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    mapper = Mapper(cfg, dec, bound, cam, device=DEV)
+    mapper.set_decoder(frames)
+    randomise_(dec, 31, scale=1.0)
+    with torch.no_grad():
+        dec.pe_fn.grid_fn.params.mul_(2000.0)
+    randomise_([mapper.fine_decoders.pool], 32)
+    return cfg, bound, cam, frames, dec, mapper
+
+
+def _code(n_rays, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n_rays, NU + NS, 32, generator=g) * 2 - 1
+
+
+def test_cfg3_level_table_is_the_office0_table():
+    """office_0's bound (configs/replica/office_0.yaml:4) at voxel 0.02 / T=2^16: finest resolution = longest side / 0.02
+    (~12.1 m -> ~608), the four coarsest levels dense, the other twelve hashed at 2^16 rows."""
+    cfg, bound, cam, frames, dec, mapper = _setup(n_pixels=64)
+    lv = dec.pe_fn.grid_fn.meta.levels()
+    side = float((bound[:, 1] - bound[:, 0]).max())
+    assert len(lv) == 16 and lv[0]["resolution"] == 16
+    assert abs(lv[-1]["resolution"] - side / 0.02) <= 1.5, (lv[-1]["resolution"], side / 0.02)
+    assert [l["hashed"] for l in lv] == [False] * 4 + [True] * 12
+    assert all(l["size"] == 65536 for l in lv[4:])
+
+
+def test_cfg3_mapper_iteration_with_feature_code_matches_oracle():
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    mapper.is_BA = True
+    _, ql, Tl = mapper.set_optimizer(frames)
+    prep = mapper.prepare_frames(frames)
+    torch.manual_seed(41)
+    pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+    g = torch.Generator().manual_seed(42)
+    u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+    code = _code(pix.numel())
+    s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit, features=code.to(DEV))
+    # the code only lives inside the truncation band around the measured depth (slams/mapping.py:553-556)
+    z, d = s["z_vals"], s["gt_depth"][:, None]
+    band = (z >= d * 0.95) & (z <= d * 1.05) & (d > 0)
+    assert bool((s["features"].abs().sum(-1) > 0).eq(band).all())
+    loss, terms = mapper.iteration_loss(s, lambda_lt=10.0, smooth=True, u_offset=u_off, u_jitter=u_jit, strict=True)
+    loss.backward()
+
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    qo = [q.detach().cpu().clone().requires_grad_(q.requires_grad) for q in ql]
+    To = [t.detach().cpu().clone().requires_grad_(t.requires_grad) for t in Tl]
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    npf = pix.numel() // 4
+    fr = []
+    for f in range(4):
+        img5 = torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
+        fr.append(sr.frame_samples(img5, qo[f], To[f], camt, bound, pix.cpu()[f * npf:(f + 1) * npf], jit[0][f].cpu(),
+                                   jit[1][f].cpu(), NU, NS, features=code[f * npf:(f + 1) * npf]))
+    so = sr.mapper_target_samples(fr)
+    lo, to, outs = sr.mapping_loss(om, so, sr.LossCfg(smooth_pts=cfg["training"]["smooth_pts"]), u_off, u_jit)
+    lo.backward()
+
+    pc, pd, pv, pl, fine, coarse = mapper.renderer(s)
+    for a, k in ((pc, "rgb"), (pd, "depth"), (pv, "var"), (pl, "logits"), (fine, "fine"), (coarse, "coarse")):
+        assert_close(a.cpu(), outs[k], what=f"cfg3 {k}")
+    for kp, ko in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"),
+                   ("opacity_loss", "op"), ("smooth_loss", "sm")):
+        a, b = float(terms[kp]), float(to[ko])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), f"{kp}: {a} vs {b}"
+    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what="cfg3 d table",
+                 groups=table_level_groups(om.meta))
+    used = lambda n_in, n_out: 64 * n_in + 64 * 64 + n_out * 64
+    assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:used(80, 33)], om.coarse.grad[:used(80, 33)], what="cfg3 d coarse")
+    assert_close(dec.out_fn.color_decoder.params.grad.cpu()[:used(112, 3)], om.color.grad[:used(112, 3)], what="cfg3 d color")
+    assert_close(dec.out_fn.logit_decoder.params.grad.cpu()[:used(112, 8)], om.logit.grad[:used(112, 8)], what="cfg3 d logit")
+    pool_grad = mapper.fine_decoders.pool.grad.cpu()
+    for c, slot in mapper.fine_decoders.slot.items():
+        go = om.fine[c].grad
+        if go is None:
+            assert torch.count_nonzero(pool_grad[slot]) == 0
+        else:
+            assert_close(pool_grad[slot][:used(80, 33)], go[:used(80, 33)], what=f"cfg3 d fine[{c}]")
+    for f in range(1, 4):
+        assert_pose_grad_close(ql[f], ql[f].grad, qo[f].grad, Tl[f].grad, To[f].grad, what=f"cfg3 frame {f}")
+
+
+def test_cfg3_track_frame_50_iterations_match_oracle_adam(monkeypatch):
+    """The whole per-frame tracking loop -- 50 x (draw 512 pixels + jitter -> rays -> coarse / colour / logit networks with
+    the feature code -> composite -> the three masked losses -> pose gradient -> Adam, keep-best) -- against the oracle on
+    the same draws, two ways.  (i) Evaluation parity, all 50 iterations: the oracle's loss AT THE POSE the product held in
+    iteration k equals the product's loss within 1e-4 relative.  (ii) Free-running: the oracle stepped by torch.optim.Adam
+    from the same start follows the same trajectory -- losses within 1e-3 relative (the loss is steep in the pose: a 1e-6
+    pose difference, i.e. 1e-3 of one Adam step, moves it by 1e-4), best-loss camera within 2e-5 (unit quaternion, metres) after
+    50 steps of <= 1e-3 each."""
+    from dns_slam_amd import ops
+    from dns_slam_amd.common import get_quad_from_c2w
+    from dns_slam_amd.tracking import Tracker
+    cfg, bound, cam, frames, dec, mapper = _setup(n_pixels=64)
+    tracker = Tracker(cfg, dec, bound, cam, device=DEV)
+    tracker.border = 4
+    assert tracker.n_pixels == 512 and not tracker.static_shapes
+    cur = {"gt_color": frames["gt_color"][2], "gt_depth": frames["gt_depth"][2], "gt_label": frames["gt_label"][2]}
+    c2w = frames["est_c2w"][2].clone()
+    c2w[:3, 3] += torch.tensor([0.02, -0.015, 0.01], dtype=c2w.dtype)
+    code = _code(512)
+
+    got, poses = [], []
+    real_loss, real_rays = ops.tracking_losses, ops.raygen_sample
+
+    def spy_loss(*a, **k):
+        out = real_loss(*a, **k)
+        got.append(out[0].detach())
+        return out
+
+    def spy_rays(quat, trans, *a, **k):
+        poses.append((quat.detach()[0].cpu().clone(), trans.detach()[0].cpu().clone()))
+        return real_rays(quat, trans, *a, **k)
+
+    monkeypatch.setattr(ops, "tracking_losses", spy_loss)
+    monkeypatch.setattr(ops, "raygen_sample", spy_rays)
+    torch.manual_seed(77)
+    cam7, best = tracker.track_frame(cur, c2w, n_iters=50, features=code.to(DEV), fused=True)
+    monkeypatch.setattr(ops, "tracking_losses", real_loss)
+    monkeypatch.setattr(ops, "raygen_sample", real_rays)
+    got = [float(v) for v in got]
+    assert len(got) == 50 and len(poses) == 50
+
+    om = oracle_from_product(cfg, bound, dec)
+    for p in (om.table, om.coarse, om.color, om.logit):
+        p.requires_grad_(False)                                     # frozen scene (slams/tracking.py:120-124)
+    qo = get_quad_from_c2w(c2w).clone().detach().float().requires_grad_(True)
+    To = c2w[:3, 3].clone().detach().float().requires_grad_(True)
+    lr = tracker.cam_lr
+    opt_o = torch.optim.Adam([{"params": [To], "lr": lr * 0.2 if tracker.seperate_LR else lr}, {"params": [qo], "lr": lr}])
+    img5 = torch.cat((cur["gt_color"], cur["gt_depth"][..., None], cur["gt_label"][..., None]), -1)
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    b = tracker.border
+    win = (b, cam["H"] - b, b, cam["W"] - b)
+
+    def oracle_loss(q, T, pix, jit):
+        so = sr.frame_samples(img5, q, T, camt, bound, pix.cpu(), jit[0].cpu(), jit[1].cpu(), NU, NS, window=win, features=code)
+        mask = (so["gt_depth"] > 0.01) & so["inside"]
+        return sr.tracking_loss(om, so, mask, tracker.lambda_p, tracker.lambda_d, tracker.lambda_l)[0]
+
+    torch.manual_seed(77)
+    best_o, cam_o, worst_eval, worst_free = float("inf"), None, 0.0, 0.0
+    for it in range(50):
+        pix, jit = tracker.draw_pixels(), tracker.draw_jitter()       # the draws track_frame made, in its order
+        with torch.no_grad():
+            at_product_pose = float(oracle_loss(poses[it][0], poses[it][1], pix, jit))
+        rel = abs(got[it] - at_product_pose) / abs(at_product_pose)
+        worst_eval = max(worst_eval, rel)
+        assert rel <= 1e-4, f"iteration {it}, loss at the product's pose: {got[it]} vs {at_product_pose}"
+        opt_o.zero_grad()
+        lo = oracle_loss(qo, To, pix, jit)
+        if float(lo) < best_o:
+            best_o, cam_o = float(lo), torch.cat((qo, To)).detach().clone()
+        lo.backward()
+        opt_o.step()
+        rel = abs(got[it] - float(lo)) / abs(float(lo))
+        worst_free = max(worst_free, rel)
+        assert rel <= 1e-3, f"iteration {it}, free-running: {got[it]} vs {float(lo)}"
+    REPORT.append(("cfg3 track_frame: worst per-iteration loss deviation at the product's pose, 50 iterations", worst_eval, worst_eval / 1e-4, 1e-4))
+    REPORT.append(("cfg3 track_frame: worst per-iteration loss deviation, free-running oracle Adam, 50 iterations", worst_free, worst_free / 1e-3, 1e-3))
+    assert abs(float(best) - best_o) <= 1e-3 * abs(best_o)
+    # |q| drifts freely (the loss does not depend on it: Adam turns the rounding residue along q into +-lr steps), so the
+    # cameras are compared as what they are: unit quaternion (rotation) + translation
+    unit = lambda c: torch.cat((c[:4] / c[:4].norm(), c[4:]))
+    dev = float((unit(cam7.cpu()) - unit(cam_o)).abs().max())
+    REPORT.append(("cfg3 track_frame: best camera (unit quaternion, translation) vs free-running oracle Adam", dev, dev / 2e-5, 2e-5))
+    assert dev <= 2e-5, (unit(cam7.cpu()), unit(cam_o))

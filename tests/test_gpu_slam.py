@@ -6,7 +6,7 @@ import torch
 
 from oracle import render_math as rm
 from oracle import slam_ref as sr
-from util import assert_close, oracle_from_product, randomise_, rel_err, table_level_groups
+from util import assert_close, assert_pose_grad_close, oracle_from_product, randomise_, rel_err, table_level_groups
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -121,8 +121,7 @@ def test_mapper_renderer_loss_and_gradients(nn, nl, layout):
         else:
             assert_close(pool_grad[slot][:used(80, 33)], go[:used(80, 33)], what=f"d fine[{c}]")
     for f in range(1, 4):                                 # frame 0 is fixed (slams/mapping.py:457)
-        assert_close(quad_list[f].grad.cpu(), qo[f].grad, rtol=2e-4, what=f"d quat[{f}]")
-        assert_close(T_list[f].grad.cpu(), To[f].grad, rtol=2e-4, what=f"d T[{f}]")
+        assert_pose_grad_close(quad_list[f], quad_list[f].grad, qo[f].grad, T_list[f].grad, To[f].grad, what=f"frame {f}")
     assert quad_list[0].grad is None
 
 
@@ -172,8 +171,7 @@ def test_tracker_renderer_losses_and_pose_gradient():
     assert_close(pv.cpu(), outs["var"], what="var")
     assert_close(pl.cpu(), outs["logits"], what="logits")
     assert abs(float(loss) - float(lo)) <= 1e-4 * abs(float(lo))
-    assert_close(quad.grad.cpu(), qo.grad, rtol=2e-4, what="d quat")
-    assert_close(T.grad.cpu(), To.grad, rtol=2e-4, what="d T")
+    assert_pose_grad_close(quad, quad.grad, qo.grad, T.grad, To.grad, what="tracker")
 
 
 def test_mapping_iterations_reduce_loss():

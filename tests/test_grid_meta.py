@@ -10,7 +10,7 @@ from oracle import tcnn_ref as tr
 REPLICA = {  # reference configs/replica/*.yaml back_end.bound
     "room_0": [[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]],
     "room_1": [[-7.0, 2.8], [-4.6, 4.3], [-3.0, 2.9]],
-    "office_0": [[-2.2, 2.6], [-1.7, 3.5], [-2.0, 3.2]],
+    "office_0": [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]],
     "scene0000": [[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]],
 }
 

@@ -93,6 +93,23 @@ def assert_close(a, b, rtol=RTOL, what="", groups=None, atol_factor=1.0, element
                            f"{e:.3e}); worst element (index, got, want, tolerance) = {getattr(elem_err, 'worst', None)}")
 
 
+def assert_pose_grad_close(q, gq, gq_ref, gT, gT_ref, what=""):
+    """Pose gradients.  The rotation depends on q only through q/|q| (utils/common.py quad2rotation divides by |q|^2), so the
+    exact gradient has NO component along q: whatever either fp32 implementation returns there is rounding residue of terms
+    that cancel analytically, and it moves nothing (a step along q leaves the rotation unchanged).  The component in the
+    tangent space of the unit sphere -- the part that rotates the camera -- is held to 1e-4; the radial residue of each side
+    must be small against the gradient itself; the translation gradient is held to 1e-4."""
+    q = q.detach().double().cpu()
+    n = q / q.norm()
+    tang = lambda g: (g.detach().double().cpu() - (g.detach().double().cpu() @ n) * n).float()
+    assert_close(tang(gq), tang(gq_ref), rtol=1e-4, what=f"{what} d quat (tangential)", elementwise=False)
+    for g, side in ((gq, "product"), (gq_ref, "oracle")):
+        rad = abs(float(g.detach().double().cpu() @ n))
+        REPORT.append((f"{what} d quat radial residue / |g| ({side})", rad / float(g.norm()), rad / float(g.norm()) / 1e-3, 1e-3))
+        assert rad <= 1e-3 * float(g.norm()), f"{what}: radial component {rad:.3e} of |g| = {float(g.norm()):.3e} ({side})"
+    assert_close(gT.detach().cpu(), gT_ref, rtol=1e-4, what=f"{what} d T", elementwise=False)
+
+
 def table_level_groups(meta, n_features=2):
     """Slices of the flattened [total_rows, F] hash table (or its gradient), one per level: a fine level's entries are
     compared against the magnitude of THEIR level, not the coarse levels'.  meta: oracle or product grid meta."""

@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 2 --no-overlap --no-cpu-baseline --no-kernel-timing --no-render-forward
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py ... (same)
-    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg2 r01
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg2 r02 5      # 5 = warmup + steps of the run
 
 Units / corrections (MI355X_MICROARCH.md, HBM): counters are KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
 coalesced (16 B/lane) streaming read -> doubled for the streaming kernels (MLP, losses, compositing, transpose, Adam);
@@ -10,8 +10,9 @@ coalesced (16 B/lane) streaming read -> doubled for the streaming kernels (MLP, 
 import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, workload, tag = sys.argv[1:5]
+n_steps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 ENTRY = {  # C-ABI entry point -> kernels it launches
-    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_data_kernel", "gemm_tn_kernel", "gemm_roles_kernel", "gemm_units_kernel"],
+    "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_kernel", "mlp_dwin_kernel"],
     "dns_encode_fwd": ["encode_fwd_kernel"], "dns_encode_bwd": ["encode_bwd_kernel", "dgrid_transpose_kernel", "hashgrid_bwd_binned_kernel"],
     "dns_composite_fwd": ["composite_fwd_kernel"], "dns_composite_bwd": ["composite_bwd_kernel"],
     "dns_loss_sums": ["loss_ray_sums_kernel", "loss_point_sums_kernel"], "dns_loss_bwd": ["loss_ray_bwd_kernel", "loss_point_bwd_kernel"],
@@ -28,7 +29,7 @@ def load(d):
     for r in csv.DictReader(open(f)):
         if "dns::" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dns::", "").split("<")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"]) * 1024.0
     return agg
@@ -41,7 +42,8 @@ for k in sorted(set(fe) | set(wr)):
     raw_f = fe.get(k, [0, 0.0])[1] / n
     f = raw_f if k in GATHER else 2.0 * raw_f
     w = wr.get(k, [0, 0.0])[1] / n
-    kern[k] = {"launches": n, "fetch_raw_bytes": raw_f, "fetch_bytes": f, "write_bytes": w, "fetch_corrected": k not in GATHER}
+    kern[k] = {"launches": n, "launches_per_step": n / n_steps, "fetch_raw_bytes": raw_f, "fetch_bytes": f, "write_bytes": w,
+               "fetch_corrected": k not in GATHER}
 entries = {}
 for e, ks in ENTRY.items():
     present = [k for k in ks if k in kern]
@@ -52,6 +54,8 @@ for e, ks in ENTRY.items():
     entries[e] = {"hbm_bytes_per_launch": tot, "kernels": present}
 out = {"workload": workload, "source": f"profiles/{tag}_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                       "FETCH doubled for streaming kernels, raw for 8-byte gather kernels)",
+       "steps_profiled": n_steps,
+       "hbm_bytes_per_step": sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches"] for v in kern.values()) / n_steps,
        "kernels": kern, "entry_points": entries}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 with open(f"profiles/{tag}_pmc_traffic.txt", "w") as fh:
@@ -59,6 +63,7 @@ with open(f"profiles/{tag}_pmc_traffic.txt", "w") as fh:
     fh.write(f"{'kernel':34s} {'launches':>8s} {'FETCH raw MB':>13s} {'FETCH used MB':>14s} {'WRITE MB':>10s}\n")
     for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]['fetch_bytes'] + kv[1]['write_bytes'])):
         fh.write(f"{k:34s} {v['launches']:8d} {v['fetch_raw_bytes'] / 1e6:13.2f} {v['fetch_bytes'] / 1e6:14.2f} {v['write_bytes'] / 1e6:10.2f}\n")
+    fh.write(f"\nall kernels of the library, per iteration: {out['hbm_bytes_per_step'] / 1e6:.1f} MB\n")
     fh.write("\nper C-ABI entry point (bytes per call):\n")
     for e, v in sorted(entries.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         fh.write(f"{e:22s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB   ({', '.join(v['kernels'])})\n")

@@ -1,4 +1,4 @@
-"""Time dns_encode_bwd's table scatter alone (torch events), for tuning DNS_SCATTER / DNS_SCATTER_SLICES."""
+"""Time dns_encode_bwd's table scatter alone (torch events), per scatter form (ops.SCATTER_FORM)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dns_slam_amd import ops
@@ -25,4 +25,4 @@ for _ in range(10):
     y.backward(gy, retain_graph=True)
 e1.record()
 torch.cuda.synchronize()
-print(f"DNS_SCATTER={os.environ.get('DNS_SCATTER')} SLICES={os.environ.get('DNS_SCATTER_SLICES')} P={P}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per backward (incl. zeros_like + transpose)")
+print(f"P={P}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per backward (incl. zeros_like + transpose)")
