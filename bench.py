@@ -125,7 +125,7 @@ def kernel_rooflines(spans, wl, steps, pmc):
     return rows
 
 
-def build(wl, device, seed, dist_ctx, overlap=False):
+def build(wl, device, seed, dist_ctx, overlap=False, graph=False):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
@@ -154,6 +154,13 @@ def build(wl, device, seed, dist_ctx, overlap=False):
     torch.manual_seed(seed)                                  # per-rank ray draws
     torch.cuda.manual_seed(seed)
     params = [p for g in optimizer.param_groups for p in g["params"]]
+    buckets = None
+    if dist_ctx.enabled and not graph:
+        # persistent gradient buckets, all-reduced asynchronously from autograd hooks (dist.py): the colour / logit /
+        # fine-decoder gradients are complete when the ray branch's MLP backward ends and travel under the hash-grid
+        # scatter; the table, the coarse network (both also fed by the lattice branch) and the poses go last
+        early = [dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, mapper.fine_decoders.pool]
+        buckets = dist_ctx.make_buckets([early, [p for p in params if all(p is not e for e in early)]])
     code = None
     if wl.get("code_seed") is not None:      # 2-D feature code of every sample (U(-1,1), seed 5), resident in HBM
         g = torch.Generator().manual_seed(wl["code_seed"])
@@ -162,11 +169,17 @@ def build(wl, device, seed, dist_ctx, overlap=False):
     mapper.bench_code = code
 
     def step():
-        optimizer.zero_grad(set_to_none=True)
+        if buckets is not None:
+            buckets.zero()
+        else:
+            optimizer.zero_grad(set_to_none=True)
         samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep, features=code)
         loss, terms = mapper.iteration_loss(samples, lambda_lt=10.0, smooth=True)
         loss.backward()
-        dist_ctx.allreduce_grads(params)
+        if buckets is not None:
+            buckets.finish()
+        else:
+            dist_ctx.allreduce_grads(params)
         optimizer.step()
         return loss
 
@@ -274,13 +287,16 @@ def main():
                     help="replay the iteration from a hipGraph (one stream) instead of launching it eagerly on two streams")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches; kept for older command lines")
     ap.add_argument("--no-overlap", action="store_true", help="eager, but keep the smoothness branch on the main stream")
+    ap.add_argument("--union-batch", action="store_true",
+                    help="N>1: the N ranks share ONE batch of the configured size (shared-seed draws, rank slices of the rays and "
+                         "of the smoothness lattice; strong scaling) instead of one batch per rank (weak scaling, the default)")
     args = ap.parse_args()
 
     from dns_slam_amd import dist as ddist
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # intended: the lattice branch's stream
     from dns_slam_amd import ops
-    ctx = ddist.init_from_env()
+    ctx = ddist.init_from_env(mode="union" if args.union_batch else "weak")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("DNS_FORCE_DEVICE") is not None:       # rehearsal of the N-rank path on a one-GPU box (with gloo)
         local = int(os.environ["DNS_FORCE_DEVICE"])
@@ -288,8 +304,11 @@ def main():
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]
     overlap = not args.graph and not args.no_overlap          # hipGraph replay serialises the two branches: no gain there
-    cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + ctx.rank, dist_ctx=ctx, overlap=overlap)
+    union = ctx.union
+    cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + (0 if union else ctx.rank), dist_ctx=ctx, overlap=overlap,
+                                                  graph=args.graph and not args.no_graph)
     n_rays = 4 * sum(wl["rays"])
+    job_rays = n_rays if union else n_rays * ctx.world_size          # rays the whole job renders per step
     S = wl["nu"] + wl["ns"]
 
     run = step
@@ -337,7 +356,7 @@ def main():
         spans = ops.timer.kernel_spans
         mapper.overlap_smooth = overlap
     ms_per_step = elapsed * 1e3 / args.steps
-    value = n_rays * S * ctx.world_size / (ms_per_step / 1e3)
+    value = job_rays * S / (ms_per_step / 1e3)
 
     if ctx.rank != 0:
         return
@@ -380,10 +399,12 @@ def main():
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
+        "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
                   "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "final_loss": final_loss,
-        "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": n_rays, "samples_per_ray": S,
-                   "global_rays": n_rays * ctx.world_size, "parallelism": f"dp{ctx.world_size} (ray-batch sharding)"},
+        "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,
+                   "global_rays": job_rays,
+                   "parallelism": f"dp{ctx.world_size} (" + ("union batch: rank slices of one shared-seed batch and of the lattice"
+                                                              if union else "one batch per rank") + ")"},
         "roofline": roofline,
         "iteration_roofline": iteration_roofline,
         "kernel_rooflines": per_kernel,

@@ -59,8 +59,8 @@ SIGNATURES = {
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _P, _P]),
     "dns_feature_gather": (C.c_int, [_P, _P, _P, _P, _U, _U, _U, _I, _I, _I, _I, _P, _P, _P]),
-    "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _P, _P]),
-    "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _P, _P, _P]),
+    "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P]),
+    "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P, _P]),
     "dns_group_slots": (C.c_int, [_P, _U, _U, _U, _U, _P, _P, _P, _P]),
     "dns_adam_step": (C.c_int, [C.POINTER(DnsAdamTensor), _U, C.c_float, C.c_float, C.c_float, _P, _P]),
     "dns_composite_fwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P]),

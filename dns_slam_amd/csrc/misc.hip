@@ -17,17 +17,21 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void tv_fwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t n, float inv_norm,
-                                                     float* __restrict__ out) {
+// The lattice is a slab of nx x-planes of n x n points (nx = n: the whole cube).  With `halo` the LAST plane belongs to the
+// next slab (multi-GPU: the lattice is cut along x, one slab per rank): it only closes the x-differences of plane nx-2, its
+// own y / z differences are the next rank's -- the slabs' sums add up to the cube's sum, term for term.
+__global__ __launch_bounds__(256) void tv_fwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t nx, uint32_t n,
+                                                     uint32_t halo, float inv_norm, float* __restrict__ out) {
   __shared__ float sh[4];
-  const uint32_t total = n * n * n;
+  const uint32_t total = nx * n * n;
   float acc = 0.f;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
+    const bool own = !(halo && i + 1 == nx);
     const float v = lat[(size_t)e * ld];
-    if (i + 1 < n) { const float d = lat[(size_t)(e + n * n) * ld] - v; acc += d * d; }
-    if (j + 1 < n) { const float d = lat[(size_t)(e + n) * ld] - v; acc += d * d; }
-    if (k + 1 < n) { const float d = lat[(size_t)(e + 1) * ld] - v; acc += d * d; }
+    if (i + 1 < nx) { const float d = lat[(size_t)(e + n * n) * ld] - v; acc += d * d; }
+    if (own && j + 1 < n) { const float d = lat[(size_t)(e + n) * ld] - v; acc += d * d; }
+    if (own && k + 1 < n) { const float d = lat[(size_t)(e + 1) * ld] - v; acc += d * d; }
   }
   acc = wave_sum_f(acc);
   if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = acc;
@@ -38,23 +42,25 @@ __global__ __launch_bounds__(256) void tv_fwd_kernel(const float* __restrict__ l
 // d_lat [n^3, ld]: column 0 = d loss / d occ, the other columns zero (the gradient of coarse[:, 0:1] padded back)
 // Flat walk over the [n^3 * ld] output (coalesced stores; a thread-per-point walk writes 132-byte rows at a 132-byte lane
 // stride, 33 scattered store instructions per wave): the element that is a row's column 0 evaluates the stencil.
-__global__ __launch_bounds__(256) void tv_bwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t n, float inv_norm,
-                                                     const float* __restrict__ g, float* __restrict__ d_lat) {
-  const uint32_t total = n * n * n * ld;               // < 2^32 (checked on the host)
+__global__ __launch_bounds__(256) void tv_bwd_kernel(const float* __restrict__ lat, uint32_t ld, uint32_t nx, uint32_t n,
+                                                     uint32_t halo, float inv_norm, const float* __restrict__ g,
+                                                     float* __restrict__ d_lat) {
+  const uint32_t total = nx * n * n * ld;              // < 2^32 (checked on the host)
   const float c = 2.0f * inv_norm * g[0];
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const uint32_t e = t / ld;
     float out = 0.f;
     if (t - e * ld == 0) {
       const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
+      const bool own = !(halo && i + 1 == nx);
       const float v = lat[(size_t)e * ld];
       float a = 0.f;
-      if (i + 1 < n) a -= lat[(size_t)(e + n * n) * ld] - v;
+      if (i + 1 < nx) a -= lat[(size_t)(e + n * n) * ld] - v;
       if (i > 0) a += v - lat[(size_t)(e - n * n) * ld];
-      if (j + 1 < n) a -= lat[(size_t)(e + n) * ld] - v;
-      if (j > 0) a += v - lat[(size_t)(e - n) * ld];
-      if (k + 1 < n) a -= lat[(size_t)(e + 1) * ld] - v;
-      if (k > 0) a += v - lat[(size_t)(e - 1) * ld];
+      if (own && j + 1 < n) a -= lat[(size_t)(e + n) * ld] - v;
+      if (own && j > 0) a += v - lat[(size_t)(e - n) * ld];
+      if (own && k + 1 < n) a -= lat[(size_t)(e + 1) * ld] - v;
+      if (own && k > 0) a += v - lat[(size_t)(e - 1) * ld];
       out = c * a;
     }
     d_lat[t] = out;
@@ -133,29 +139,32 @@ __global__ __launch_bounds__(256) void group_scatter_kernel(const int64_t* __res
 
 using namespace dns;
 
-extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, float* out, void* stream) {
-  DNS_REQUIRE(lat && out && n >= 1 && ld >= 1, "dns_tv_fwd: bad argument");
-  DNS_REQUIRE((uint64_t)n * n * n < (1ull << 31), "dns_tv_fwd: lattice too large");
+extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t nx, uint32_t n, int halo, uint32_t sample_points, float* out,
+                          void* stream) {
+  DNS_REQUIRE(lat && out && n >= 1 && nx >= 1 && ld >= 1, "dns_tv_fwd: bad argument");
+  DNS_REQUIRE(!halo || nx >= 2, "dns_tv_fwd: a slab with a halo plane needs at least one plane of its own");
+  DNS_REQUIRE((uint64_t)nx * n * n < (1ull << 31), "dns_tv_fwd: lattice too large");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) {
     set_error("dns_tv_fwd: memset failed");
     return DNS_E_LAUNCH;
   }
-  const uint32_t total = n * n * n;
+  const uint32_t total = nx * n * n;
   const uint32_t blocks = (total + 255) / 256 < 256 ? (total + 255) / 256 : 256;   // each ends in one atomic on ONE word
   const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
-  DNS_LAUNCH(tv_fwd_kernel, dim3(blocks), dim3(256), 0, st, lat, ld, n, inv, out);
+  DNS_LAUNCH(tv_fwd_kernel, dim3(blocks), dim3(256), 0, st, lat, ld, nx, n, halo ? 1u : 0u, inv, out);
   return check_launch("dns_tv_fwd");
 }
 
-extern "C" int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, const float* g, float* d_lat,
-                          void* stream) {
-  DNS_REQUIRE(lat && g && d_lat && n >= 1 && ld >= 1, "dns_tv_bwd: bad argument");
-  DNS_REQUIRE((uint64_t)n * n * n * ld < 0xFFFFFFFFull, "dns_tv_bwd: lattice too large for 32-bit indexing");
-  const uint32_t total = n * n * n * ld;
+extern "C" int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t nx, uint32_t n, int halo, uint32_t sample_points, const float* g,
+                          float* d_lat, void* stream) {
+  DNS_REQUIRE(lat && g && d_lat && n >= 1 && nx >= 1 && ld >= 1, "dns_tv_bwd: bad argument");
+  DNS_REQUIRE(!halo || nx >= 2, "dns_tv_bwd: a slab with a halo plane needs at least one plane of its own");
+  DNS_REQUIRE((uint64_t)nx * n * n * ld < 0xFFFFFFFFull, "dns_tv_bwd: lattice too large for 32-bit indexing");
+  const uint32_t total = nx * n * n * ld;
   const uint32_t blocks = (total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192;
   const float inv = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
-  DNS_LAUNCH(tv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lat, ld, n, inv, g, d_lat);
+  DNS_LAUNCH(tv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lat, ld, nx, n, halo ? 1u : 0u, inv, g, d_lat);
   return check_launch("dns_tv_bwd");
 }
 

@@ -1,6 +1,22 @@
 """Ray-batch data parallelism over the GPUs of one node: one process per GPU, parameters
-replicated, every rank renders its own slice of the ray batch, ONE flat all-reduce of the gradients per
-iteration (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" on CPU for tests).
+replicated, every rank renders its own slice of the ray batch, the gradients are all-reduced once per iteration
+(RCCL over xGMI via torch.distributed backend "nccl"; "gloo" on CPU for tests).
+
+Two modes (``DistCtx.mode``):
+* ``"weak"``  -- every rank draws its OWN batch (per-rank seed): the global batch is W times the configured one.  Per
+  iteration: one MAX over K floats (the per-frame max sampled depth, before sampling), one SUM over the 16 loss numerators /
+  counts (before the backward), the gradient all-reduce.  Every rank evaluates its own smoothness lattice at weight 1/W.
+* ``"union"`` -- SURVEY 8e's partitioning: all ranks draw the SAME pixel list / jitter / lattice offsets (shared seed, same
+  generator calls), rank r renders rays [r n/W, (r+1) n/W) of every frame's list and x-planes [r 63/W, (r+1) 63/W) of the
+  smoothness lattice (+ one halo plane): the W ranks together compute exactly the one-GPU iteration on the configured batch
+  (strong scaling).  The MAX needs no collective (every rank holds the whole list); per iteration: the 16-float SUM and the
+  gradient all-reduce.
+
+Gradient exchange (``GradBuckets``): the parameters' ``.grad`` tensors are VIEWS into persistent flat fp32 buckets (no
+per-iteration allocation, flattening or copy-back); a bucket's all-reduce is launched asynchronously from the
+post-accumulate hook of its last parameter -- the bucket of the colour / logit / fine-decoder gradients, complete when the
+ray branch's MLP backward ends, travels while the hash-grid scatter, the pose backward and the lattice branch still run;
+the bucket holding the table, the coarse network (both also fed by the lattice branch) and the poses goes last.
 
 The reference has no live distributed path (its NCCL helpers utils/common.py:79-162 are dead code); this is the
 north_star's addition.  Exactness w.r.t. one GPU rendering the union batch: the fused loss kernel (csrc/losses.hip) first produces the 16
@@ -22,9 +38,104 @@ import torch
 import torch.distributed as dist
 
 
+def shard_range(n: int, world: int, rank: int):
+    """[a, b): rank's contiguous share of n items, sizes differing by at most one (the first n % world ranks get the extra)."""
+    q, r = divmod(n, world)
+    a = rank * q + min(rank, r)
+    return a, a + q + (1 if rank < r else 0)
+
+
+def union_point_labels(labels_union: torch.Tensor, n_frames: int, n_per_frame: int, a: int, b: int, n_samples: int) -> torch.Tensor:
+    """Fine-decoder routing labels of a union-batch shard under the reference's tiled layout (slams/mapping.py:613):
+    point k of the WHOLE batch (ray-major, N = n_frames * n_per_frame rays) is routed by labels[k mod N].  The shard holds rays
+    [a, b) of every frame's list; returns the labels of its points, ray-major, [n_frames * (b - a) * n_samples]."""
+    dev = labels_union.device
+    N = n_frames * n_per_frame
+    gid = (torch.arange(n_frames, device=dev)[:, None] * n_per_frame + torch.arange(a, b, device=dev)[None]).reshape(-1)
+    k = gid[:, None] * n_samples + torch.arange(n_samples, device=dev)[None]
+    return labels_union.reshape(-1)[k % N].reshape(-1)
+
+
+class GradBuckets:
+    """Persistent flat gradient buckets with hook-launched asynchronous all-reduces (see the module docstring).
+
+    ``groups``: list of parameter lists, in LAUNCH order (collectives must be issued in the same order on every rank: bucket
+    k is launched only after buckets < k, whatever order autograd finishes them in).  Usage per iteration::
+
+        buckets.zero()            # instead of optimizer.zero_grad(): .grad stays a view of the bucket
+        loss.backward()           # hooks launch bucket k once its last parameter has accumulated
+        buckets.finish()          # launch what no hook launched (parameters without a gradient this iteration), wait
+        optimizer.step()
+    """
+
+    def __init__(self, ctx: "DistCtx", groups):
+        self.ctx = ctx
+        self.groups = [[p for p in g if p.requires_grad and p.numel() > 0] for g in groups]
+        self.groups = [g for g in self.groups if g]
+        self.flat, self._pending, self._works, self._next = [], [], [], 0
+        self._hooks = []
+        for k, g in enumerate(self.groups):
+            flat = torch.zeros(sum(p.numel() for p in g), device=g[0].device, dtype=torch.float32)
+            o = 0
+            for p in g:
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+                if ctx.enabled:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, k=k: self._ready(k)))
+            self.flat.append(flat)
+            self._pending.append(len(g))
+        self._counts = list(self._pending)
+
+    def nbytes(self):
+        return [f.numel() * 4 for f in self.flat]
+
+    def zero(self):
+        for f in self.flat:
+            f.zero_()
+        self._pending = list(self._counts)
+        self._works, self._next = [], 0
+
+    def _launch_through(self, k):
+        while self._next <= k:
+            self._works.append(dist.all_reduce(self.flat[self._next], op=dist.ReduceOp.SUM, group=self.ctx.group, async_op=True))
+            self._next += 1
+
+    def _ready(self, k):
+        self._pending[k] -= 1
+        # launch in bucket order: bucket k goes once it AND every earlier bucket are complete
+        while self._next < len(self.flat) and self._pending[self._next] <= 0:
+            self._launch_through(self._next)
+
+    def finish(self):
+        if not self.ctx.enabled:
+            return
+        self._launch_through(len(self.flat) - 1)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def detach(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 class DistCtx:
-    def __init__(self, world_size: int = 1, rank: int = 0, group=None):
-        self.world_size, self.rank, self.group = world_size, rank, group
+    def __init__(self, world_size: int = 1, rank: int = 0, group=None, mode: str = "weak"):
+        if mode not in ("weak", "union"):
+            raise ValueError(f"DistCtx mode '{mode}' (weak | union)")
+        self.world_size, self.rank, self.group, self.mode = world_size, rank, group, mode
+        self._flat_cache = {}
+
+    @property
+    def union(self):
+        return self.enabled and self.mode == "union"
+
+    def shard(self, n: int):
+        return shard_range(n, self.world_size, self.rank)
+
+    def make_buckets(self, groups) -> GradBuckets:
+        return GradBuckets(self, groups)
 
     @property
     def enabled(self):
@@ -68,11 +179,16 @@ class DistCtx:
         if not ps:
             return
         n = sum(p.numel() for p in ps)
-        flat = torch.zeros(n, device=ps[0].device, dtype=torch.float32)
+        key = (n, str(ps[0].device))
+        flat = self._flat_cache.get(key)                  # persistent: no allocation per iteration
+        if flat is None:
+            flat = self._flat_cache[key] = torch.empty(n, device=ps[0].device, dtype=torch.float32)
         o = 0
         for p in ps:
             if p.grad is not None:
                 flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            else:
+                flat[o:o + p.numel()].zero_()
             o += p.numel()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         o = 0
@@ -96,11 +212,11 @@ class DistCtx:
         return float(t.item())
 
 
-def init_from_env(backend: Optional[str] = None) -> DistCtx:
+def init_from_env(backend: Optional[str] = None, mode: str = "weak") -> DistCtx:
     """One process per GPU, launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
-        return DistCtx()
+        return DistCtx(mode=mode)
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
@@ -109,4 +225,4 @@ def init_from_env(backend: Optional[str] = None) -> DistCtx:
         torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return DistCtx(world, rank)
+    return DistCtx(world, rank, mode=mode)

@@ -178,6 +178,15 @@ class Mapper:
     def smoothness(self, sample_points=64, voxel_size=0.1, margin=0.05, u_offset=None, u_jitter=None):
         n = sample_points - 1
         self._ensure_lattice(sample_points, voxel_size, margin)
+        lattice, nx, halo = self._lattice, n, False
+        if self.dist is not None and self.dist.union:
+            # union-batch mode: this rank's x-planes [a, b) of the ONE lattice all ranks draw, plus the next slab's first plane
+            # to close the x-differences (csrc/misc.hip); the ranks' partial sums add up to the cube's value
+            if not self.fused_losses:
+                raise ValueError("the lattice is only sharded on the fused-loss path")
+            a, b = self.dist.shard(n)
+            hi = min(b + 1, n)
+            lattice, nx, halo = self._lattice[a:hi], hi - a, hi > b
         if u_offset is None and u_jitter is None and self.static_shapes:
             # sync-free iteration: the same fp64 affine map, folded to  pts = lattice * A + B  with
             # A = voxel / (b1 - b0),  B = (jitter * voxel + offset) / (b1 - b0)  -- 6 launches instead of 14
@@ -188,7 +197,7 @@ class Mapper:
                 r = torch.rand(6, device=self.device)
             r = r.to(torch.float64)                                            # [offset(3) | jitter(3)], as float32 draws
             b = torch.addcmul(torch.addcmul(c_mar, r[:3], c_off), r[3:], c_vox)
-            pts = torch.addcmul(b, self._lattice, c_vox)
+            pts = torch.addcmul(b, lattice, c_vox)
             pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
             if self.fused_losses:
                 # Only the occupancy logit (output row 0, mapping.py:152) enters the TV term: the coarse network runs as an
@@ -197,7 +206,7 @@ class Mapper:
                 net = self.decoder.coarse_fn.decoder
                 occ = ops.mlp(fused_cat(pe, grid_pts), net.params, net.n_input_dims, 1, net.n_neurons, net.n_hidden_layers,
                               fp16=getattr(net, "fp16", False))
-                return ops.tv_smoothness(occ, n, sample_points)
+                return ops.tv_smoothness(occ, n, sample_points, nx=nx, halo=halo)
             coarse = self.decoder.coarse_fn(pe, features=grid_pts)
             occ = coarse[:, 0:1].reshape(n, n, n, 1)
             tv_x = torch.pow(occ[1:, ...] - occ[:-1, ...], 2).sum()
@@ -211,13 +220,13 @@ class Mapper:
         # reference: float64 through `volume`; (coords + jitter) * voxel + b0 + offset, then normalise by the bound
         bd = self.bound_dev
         offset = u_offset.to(self.device).to(torch.float64) * self._offset_max + margin
-        pts = (self._lattice + u_jitter.to(self.device).to(torch.float64)) * voxel_size + bd[:, 0] + offset
+        pts = (lattice + u_jitter.to(self.device).to(torch.float64)) * voxel_size + bd[:, 0] + offset
         pts = (pts - bd[:, 0]) / (bd[:, 1] - bd[:, 0])
         shp = pts.shape
         pe, grid_pts = self.decoder.pe_fn(pts.reshape(-1, 3))
         coarse = self.decoder.coarse_fn(pe, features=grid_pts)
         if self.fused_losses:
-            return ops.tv_smoothness(coarse, n, sample_points)        # :151-157 in one reduction kernel
+            return ops.tv_smoothness(coarse, n, sample_points, nx=nx, halo=halo)        # :151-157 in one reduction kernel
         occ = coarse[:, 0:1].reshape(*shp[:3], 1)          # intended shape of :152
         tv_x = torch.pow(occ[1:, ...] - occ[:-1, ...], 2).sum()
         tv_y = torch.pow(occ[:, 1:, ...] - occ[:, :-1, ...], 2).sum()
@@ -383,6 +392,18 @@ class Mapper:
             return ts[0].to(self.device), t0s[0].to(self.device)
         return torch.stack(ts).to(self.device), torch.stack(t0s).to(self.device)
 
+    def _check_same_draws(self, full):
+        """Union-batch mode relies on identical generator states on all ranks: verified once (one tiny all-reduce)."""
+        if getattr(self, "_union_checked", False):
+            return
+        s = full.sum().to(torch.float64)
+        pair = torch.stack((s, -s))
+        self.dist.allreduce_max(pair)
+        if float(pair[0]) != -float(pair[1]):
+            raise RuntimeError("union-batch mode: the ranks drew different pixel lists -- seed every rank identically "
+                               "(torch.manual_seed + torch.cuda.manual_seed) before the first iteration")
+        self._union_checked = True
+
     # ------------------------------------------------------------------ slams/mapping.py:471-588
     def get_target_samples(self, target_frames, quad_list, T_list, refer_frames=None, features=None,
                            prep=None, pix_idx=None, jitter=None):
@@ -406,7 +427,26 @@ class Mapper:
         if isinstance(jitter, (list,)) and len(jitter) == K and isinstance(jitter[0], (tuple, list)):
             jitter = (torch.stack([j[0] for j in jitter]), torch.stack([j[1] for j in jitter]))
         dmax = None
-        if self.dist is not None and self.dist.enabled:
+        point_labels = None
+        if self.dist is not None and self.dist.union:
+            # union-batch mode (dist.py): pix_idx / jitter are the SAME on every rank; this rank renders rays [a, b) of every
+            # frame's list.  The batch-global max(gt_depth) (utils/common.py:581,591) comes from the whole list: no collective.
+            full = pix_idx.reshape(K, npf)
+            self._check_same_draws(full)
+            a, b = self.dist.shard(npf)
+            dmax = torch.gather(prep["depth"].reshape(K, -1), 1, full).amax(dim=1).clamp_min(0.0)
+            if self.label_layout == "reference_tiled":
+                # point k of the (union) batch is routed by label[k mod N] -- a function of the GLOBAL ray index
+                if not self.static_shapes:
+                    raise ValueError("union-batch mode with the reference_tiled label layout needs static_shapes (no ray drop)")
+                from .dist import union_point_labels
+                S = self.t_uniform.numel() + self.n_surface_ray
+                lab = torch.gather(prep["label"].reshape(K, -1), 1, full).reshape(-1).long()
+                point_labels = union_point_labels(lab, K, npf, a, b, S)
+            if features is not None and features.dim() == 3:
+                features = features.reshape(K, npf, *features.shape[1:])[:, a:b].reshape(K * (b - a), *features.shape[1:])
+            pix_idx, npf = full[:, a:b].reshape(-1), b - a
+        elif self.dist is not None and self.dist.enabled:
             # batch-global max(gt_depth) of sample_along_rays (utils/common.py:581,591): over ALL ranks' rays of a frame
             dflat = prep["depth"].reshape(K, -1)
             dmax = torch.gather(dflat, 1, pix_idx.reshape(K, npf)).amax(dim=1).clamp_min(0.0)
@@ -433,8 +473,11 @@ class Mapper:
             # no compaction (and no host sync): rays leaving the box stay in the batch with valid = 0 and are
             # excluded from every loss mean -- same values as dropping them (slams/mapping.py:576-586) for the
             # per_ray label layout; the reference_tiled layout (D1) depends on the post-drop N and needs the sync path
-            return {"gt_color": gt_color, "gt_depth": gt_depth, "gt_label": gt_label, "rays_o": rays_o, "rays_d": rays_d,
-                    "pts": pts, "z_vals": z, "features": code, "valid": inside}
+            out = {"gt_color": gt_color, "gt_depth": gt_depth, "gt_label": gt_label, "rays_o": rays_o, "rays_d": rays_d,
+                   "pts": pts, "z_vals": z, "features": code, "valid": inside}
+            if point_labels is not None:
+                out["point_labels"] = point_labels
+            return out
         mask = inside.bool()
         if bool(mask.all()):                                                # the reference syncs here too (:576)
             sel = lambda t: t
@@ -502,7 +545,9 @@ class Mapper:
         n_pts, n_samples, _ = pts.shape
         z_vals = samples["z_vals"]
         gt_label = samples["gt_label"]
-        if self.label_layout == "reference_tiled":
+        if samples.get("point_labels") is not None:
+            classes = samples["point_labels"]                              # union-batch shard: the tiling of the WHOLE batch
+        elif self.label_layout == "reference_tiled":
             classes = gt_label.repeat(1, n_samples).flatten(0, 1)          # :613 -- tiles, SURVEY D1
         else:
             classes = gt_label.repeat_interleave(n_samples)
@@ -661,8 +706,10 @@ class Mapper:
                 smooth_loss = smooth_pre
             else:
                 smooth_loss = self.smoothness(sample_points=tr["smooth_pts"], u_offset=u_offset, u_jitter=u_jitter)
-            # multi-GPU: gradients are SUMMED over ranks, so each rank's lattice contributes 1/W (average of W lattices)
-            loss = loss + (self.lambda_sm / world) * smooth_loss
+            # multi-GPU: gradients are SUMMED over ranks.  weak mode: every rank evaluates its own lattice, each contributes 1/W
+            # (average of W lattices); union mode: the ranks hold slabs of ONE lattice whose values add up to the cube's
+            w_sm = self.lambda_sm if (world > 1 and self.dist.union) else self.lambda_sm / world
+            loss = loss + w_sm * smooth_loss
             terms["smooth_loss"] = smooth_loss
         return loss, terms
 

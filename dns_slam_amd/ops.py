@@ -741,29 +741,33 @@ def tracking_losses(pred_color, pred_depth, pred_var, pred_logits, gt_color, gt_
 # ----------------------------------------------------------------------------- smoothness (TV)
 class _TvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lat, n, sample_points):
+    def forward(ctx, lat, n, sample_points, nx, halo):
         require_cuda(lat)
         lat = lat.contiguous().float()
+        if lat.shape[0] != nx * n * n:
+            raise ValueError(f"tv_smoothness: {lat.shape[0]} lattice rows for a {nx} x {n} x {n} slab")
         out = torch.empty(1, device=lat.device)
-        check(lib.dns_tv_fwd(ptr(lat), lat.shape[1], n, sample_points, ptr(out), stream_ptr()), "dns_tv_fwd")
+        check(lib.dns_tv_fwd(ptr(lat), lat.shape[1], nx, n, int(halo), sample_points, ptr(out), stream_ptr()), "dns_tv_fwd")
         ctx.save_for_backward(lat)
-        ctx.misc = (n, sample_points)
+        ctx.misc = (n, sample_points, nx, int(halo))
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
         lat, = ctx.saved_tensors
-        n, sp = ctx.misc
+        n, sp, nx, halo = ctx.misc
         d = torch.empty_like(lat)
-        check(lib.dns_tv_bwd(ptr(lat), lat.shape[1], n, sp, ptr(g.reshape(1).contiguous().float()), ptr(d), stream_ptr()),
+        check(lib.dns_tv_bwd(ptr(lat), lat.shape[1], nx, n, halo, sp, ptr(g.reshape(1).contiguous().float()), ptr(d), stream_ptr()),
               "dns_tv_bwd")
-        return d, None, None
+        return d, None, None, None, None
 
 
-def tv_smoothness(latents: torch.Tensor, n: int, sample_points: int) -> torch.Tensor:
+def tv_smoothness(latents: torch.Tensor, n: int, sample_points: int, nx: Optional[int] = None, halo: bool = False) -> torch.Tensor:
     """Total variation of latents[:, 0] on an n^3 lattice / sample_points^3 (slams/mapping.py:151-157).
-    latents [n^3, L] = the coarse decoder's output on the lattice points (x-major)."""
-    return _TvFn.apply(latents, n, sample_points)
+    latents [n^3, L] = the coarse decoder's output on the lattice points (x-major).  ``nx`` / ``halo``: the rows are a slab of
+    nx x-planes of a lattice cut along x, the last plane being the next slab's first (include/dns_hip.h): the slabs' values
+    sum to the cube's."""
+    return _TvFn.apply(latents, n, sample_points, n if nx is None else nx, halo)
 
 
 # ----------------------------------------------------------------------------- 2-D feature lookup

@@ -254,12 +254,15 @@ int dns_adam_step(const DnsAdamTensor* tensors, uint32_t n_tensors, float beta1,
                   float* state, void* stream);
 
 /* ---- small fused helpers of the mapping iteration ----------------------------------------------
- * Total-variation smoothness of coarse[:, 0] on an n^3 lattice, divided by sample_points^3
- * (slams/mapping.py:151-157).  lat [n^3, ld] (the coarse latents, occupancy in column 0).  out: 1 float.
- * Backward: d_lat [n^3, ld] = g[0] * d loss / d lat (column 0; the other columns are zeroed). */
-int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, float* out, void* stream);
-int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t n, uint32_t sample_points, const float* g, float* d_lat,
+ * Total-variation smoothness of coarse[:, 0] on a lattice of nx x n x n points (x-major; nx = n: the n^3 cube of
+ * slams/mapping.py:151-157), divided by sample_points^3.  lat [nx*n*n, ld] (the coarse latents, occupancy in column 0).
+ * halo != 0: the last x-plane belongs to the next slab of a lattice cut along x (one slab per GPU) -- it closes the
+ * x-differences of plane nx-2 and contributes no y / z differences, so the slabs' values sum to the cube's value.
+ * out: 1 float.  Backward: d_lat [nx*n*n, ld] = g[0] * d loss / d lat (column 0; the other columns are zeroed). */
+int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t nx, uint32_t n, int halo, uint32_t sample_points, float* out,
                void* stream);
+int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t nx, uint32_t n, int halo, uint32_t sample_points, const float* g,
+               float* d_lat, void* stream);
 
 /* Counting sort of P points by weight-set id into 128-slot tiles for dns_mlp_fwd/bwd (the per-class dispatch of
  * Mapper.fine_fn, slams/mapping.py:590-601).  slot_of_point [P] int64 (negative = no network).  Outputs row_index

@@ -1,9 +1,13 @@
-"""Multi-GPU path (dns_slam_amd/dist.py): world_size-2 tests.
+"""Multi-GPU path (dns_slam_amd/dist.py): world_size 2 and 4.
 
-CPU (gloo): the flat-bucket gradient all-reduce and the loss-sum all-reduce give, for per-rank losses of the form
-(local numerators) / (global denominators), exactly the gradient of the union batch -- including a masked mean whose
-per-rank counts differ.  GPU (gloo over CUDA tensors, both ranks on cuda:0): the real HIP mapping iteration on two ray
-shards equals the one-process iteration on the union batch (per_ray label layout; 1e-4)."""
+CPU (gloo): the gradient exchange -- the flat all-reduce and the persistent two-bucket form whose all-reduces are launched
+from post-accumulate hooks -- and the loss-sum all-reduce give, for per-rank losses of the form (local numerators) /
+(global denominators), exactly the gradient of the union batch, including a masked mean whose per-rank counts differ, a
+parameter without a gradient on some rank, and buckets that complete in the opposite of their launch order; the shard
+arithmetic of the union-batch mode (ray ranges, lattice slabs with halo planes, tiled routing labels).
+GPU (gloo over CUDA tensors, all ranks on cuda:0): the real HIP mapping iteration on W ray shards equals the one-process
+iteration on the whole batch, in weak mode (explicit shards, per_ray labels) and in union-batch mode (shared draws, rank
+slices, sharded lattice, reference_tiled labels), 1e-4."""
 import os
 import socket
 
@@ -40,45 +44,106 @@ def _toy_loss(w, b, x, y, mask, ctx):
     return num / sums[1]                      # local numerator over GLOBAL denominator
 
 
-def _cpu_worker(rank, world, port, q):
-    ctx = _init(rank, world, port)
+def _toy_data():
     g = torch.Generator().manual_seed(0)
     x, y = torch.randn(64, 5, generator=g), torch.randn(64, generator=g)
     mask = (torch.rand(64, generator=g) < 0.6).float()
     w = torch.randn(5, generator=g).requires_grad_(True)
     b = torch.zeros(()).requires_grad_(True)
-    frozen = torch.zeros(3).requires_grad_(True)        # no gradient on this rank: must contribute zeros
-    sl = slice(rank * 32, (rank + 1) * 32)              # uneven mask counts per shard
-    loss = _toy_loss(w, b, x[sl], y[sl], mask[sl], ctx)
-    loss.backward()
-    ctx.allreduce_grads([w, b, frozen])
+    return x, y, mask, w, b
+
+
+def _cpu_worker(rank, world, port, q, buckets):
+    from dns_slam_amd.dist import shard_range
+    ctx = _init(rank, world, port)
+    x, y, mask, w, b = _toy_data()
+    frozen = torch.zeros(3).requires_grad_(True)        # no gradient on any rank: must contribute zeros
+    rare = torch.ones(2).requires_grad_(True)           # gradient on rank 0 only
+    a, e = shard_range(64, world, rank)                 # uneven mask counts per shard
+    sl = slice(a, e)
+    ptrs = None
+    if buckets:
+        # launch order [w, frozen] then [b, rare]; autograd finishes b (the last op of the forward) BEFORE w: the second
+        # bucket is complete first and must wait for the first; `frozen` never fires its hook: finish() launches the rest
+        bk = ctx.make_buckets([[w, frozen], [b, rare]])
+        ptrs = [p.grad.data_ptr() for p in (w, frozen, b, rare)]
+    for it in range(2):                                 # two iterations: the persistent views survive and are re-zeroed
+        if buckets:
+            bk.zero()
+        else:
+            for p in (w, b, frozen, rare):
+                p.grad = None
+        loss = _toy_loss(w, b, x[sl], y[sl], mask[sl], ctx)
+        if rank == 0:
+            loss = loss + (rare * torch.tensor([2.0, -3.0])).sum()
+        loss.backward()
+        if buckets:
+            bk.finish()
+        else:
+            ctx.allreduce_grads([w, b, frozen, rare])
+    if buckets:
+        assert ptrs == [p.grad.data_ptr() for p in (w, frozen, b, rare)], "a .grad left its bucket"
+        assert bk.nbytes() == [8 * 4, 3 * 4]
     t = ctx.max_over_ranks(float(rank), "cpu")
     ctx.barrier()
     if rank == 0:
-        q.put((w.grad.numpy().copy(), b.grad.numpy().copy(), frozen.grad.numpy().copy(), t))   # numpy: no fd passing
+        q.put((w.grad.numpy().copy(), b.grad.numpy().copy(), frozen.grad.numpy().copy(), rare.grad.numpy().copy(), t))   # numpy: no fd passing
     dist.destroy_process_group()
 
 
-def test_gloo_world2_sum_of_shard_grads_is_union_grad():
+@pytest.mark.parametrize("world,buckets", [(2, False), (2, True), (4, False), (4, True)])
+def test_gloo_sum_of_shard_grads_is_union_grad(world, buckets):
     port = _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_cpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctxm.Process(target=_cpu_worker, args=(r, world, port, q, buckets)) for r in range(world)]
     [p.start() for p in procs]
-    gw, gb, gf, t = q.get(timeout=120)
-    gw, gb, gf = torch.from_numpy(gw), torch.from_numpy(gb), torch.from_numpy(gf)
+    gw, gb, gf, gr, t = q.get(timeout=180)
+    gw, gb, gf, gr = [torch.from_numpy(v) for v in (gw, gb, gf, gr)]
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    g = torch.Generator().manual_seed(0)
-    x, y = torch.randn(64, 5, generator=g), torch.randn(64, generator=g)
-    mask = (torch.rand(64, generator=g) < 0.6).float()
-    w = torch.randn(5, generator=g).requires_grad_(True)
-    b = torch.zeros(()).requires_grad_(True)
+    x, y, mask, w, b = _toy_data()
     _toy_loss(w, b, x, y, mask, None).backward()
-    assert mask[:32].sum() != mask[32:].sum()           # the test exercises unequal denominators
+    assert len({float(mask[i * 64 // world:(i + 1) * 64 // world].sum()) for i in range(world)}) > 1   # unequal denominators
     torch.testing.assert_close(gw, w.grad, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(gb, b.grad, rtol=1e-6, atol=1e-7)
-    assert torch.count_nonzero(gf) == 0 and t == 1.0
+    assert torch.count_nonzero(gf) == 0 and t == float(world - 1)
+    assert torch.equal(gr, torch.tensor([2.0, -3.0]))
+
+
+def test_union_mode_shard_arithmetic():
+    """shard_range covers [0, n) without overlap for ragged n; the lattice slabs (+ halo plane) account for every
+    total-variation term of the cube exactly once; the tiled routing labels of a shard are the whole batch's tiling
+    (slams/mapping.py:613) restricted to the shard's points."""
+    from dns_slam_amd.dist import shard_range, union_point_labels
+    for n, W in ((63, 4), (63, 8), (1024, 3), (5, 4)):
+        cuts = [shard_range(n, W, r) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+        assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+    # TV decomposition (the rule csrc/misc.hip implements for nx / halo), restated with torch on a random cube
+    g = torch.Generator().manual_seed(1)
+    n = 11
+    occ = torch.randn(n, n, n, generator=g, dtype=torch.float64)
+    tv = lambda o: ((o[1:] - o[:-1]) ** 2).sum() + ((o[:, 1:] - o[:, :-1]) ** 2).sum() + ((o[:, :, 1:] - o[:, :, :-1]) ** 2).sum()
+    for W in (2, 3, 4):
+        tot = 0.0
+        for r in range(W):
+            a, b = shard_range(n, W, r)
+            hi = min(b + 1, n)
+            slab, halo = occ[a:hi], hi > b
+            own = slab[:-1] if halo else slab
+            tot = tot + ((slab[1:] - slab[:-1]) ** 2).sum() + ((own[:, 1:] - own[:, :-1]) ** 2).sum() + ((own[:, :, 1:] - own[:, :, :-1]) ** 2).sum()
+        assert abs(float(tot - tv(occ))) <= 1e-12 * float(tv(occ))
+    K, npf, S = 3, 10, 4
+    lab = torch.randint(0, 8, (K * npf,), generator=g)
+    tiled = lab.repeat(1, S).flatten(0, 1)                              # the reference's expression on the whole batch
+    for W in (2, 4):
+        for r in range(W):
+            a, b = shard_range(npf, W, r)
+            got = union_point_labels(lab, K, npf, a, b, S)
+            rays = torch.cat([torch.arange(f * npf + a, f * npf + b) for f in range(K)])
+            want = tiled.reshape(K * npf, S)[rays].reshape(-1)          # point (ray, s) of the whole batch is tiled[ray * S + s]
+            assert torch.equal(got, want)
 
 
 def test_single_process_ctx_is_a_noop():
@@ -94,7 +159,7 @@ def test_single_process_ctx_is_a_noop():
 
 
 # ----------------------------------------------------------------------------------------------- GPU: real path
-def _gpu_setup(dev):
+def _gpu_setup(dev, layout="per_ray"):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
@@ -105,7 +170,7 @@ def _gpu_setup(dev):
     bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=0)
     cfg = synthetic.default_cfg(n_pixels=480, n_samples_ray=32, n_surface_ray=15, hash_size=14, voxel_size=0.08, smooth_pts=10)
     dec = Decoder(cfg["model"], bound, n_class=8).to(dev)
-    mapper = Mapper(cfg, dec, bound, cam, device=dev, label_layout="per_ray")
+    mapper = Mapper(cfg, dec, bound, cam, device=dev, label_layout=layout)
     mapper.static_shapes = True
     mapper.set_decoder(frames)
     randomise_(dec, 11)
@@ -131,18 +196,33 @@ def _grads(dec, mapper, ql, Tl):
     return [g.detach().cpu().clone() for g in out]
 
 
-def _gpu_worker(rank, world, port, q):
+def _gpu_worker(rank, world, port, q, mode):
     ctx = _init(rank, world, port)
+    ctx.mode = mode
     dev = "cuda:0"
-    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup(dev)
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup(dev, "reference_tiled" if mode == "union" else "per_ray")
     mapper.dist = ctx
-    half = npf // 2
-    shard = torch.cat([pix[f * npf + rank * half: f * npf + (rank + 1) * half] for f in range(4)])
-    s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=shard, jitter=jit)
+    part = npf // world
+    params = [p for p in list(dec.parameters()) + [mapper.fine_decoders.pool] + ql + Tl if p.numel() > 0]
+    if mode == "union":
+        # every rank is handed the WHOLE list (what a shared seed gives); the mapper takes its slice, its lattice slab, the
+        # tiled routing labels of the whole batch; gradients travel in two persistent buckets launched from hooks
+        early = [dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, mapper.fine_decoders.pool]
+        late = [p for p in params if all(p is not e for e in early)]
+        bk = ctx.make_buckets([early, late])
+        bk.zero()
+        whole = torch.cat([pix[f * npf: f * npf + world * part] for f in range(4)])
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=whole, jitter=jit)
+        assert s["z_vals"].shape[0] == 4 * part
+    else:
+        shard = torch.cat([pix[f * npf + rank * part: f * npf + (rank + 1) * part] for f in range(4)])
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=shard, jitter=jit)
     loss, _ = mapper.iteration_loss(s, smooth=True, u_offset=u[0], u_jitter=u[1])
     loss.backward()
-    params = list(dec.parameters()) + [mapper.fine_decoders.pool] + ql + Tl
-    ctx.allreduce_grads([p for p in params if p.numel() > 0])
+    if mode == "union":
+        bk.finish()
+    else:
+        ctx.allreduce_grads(params)
     torch.cuda.synchronize()
     if rank == 0:
         q.put([g.numpy() for g in _grads(dec, mapper, ql, Tl)])      # numpy: plain bytes, no fd hand-shake with a dying child
@@ -151,20 +231,21 @@ def _gpu_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_two_rank_shards_equal_union_batch_on_gpu():
+@pytest.mark.parametrize("world,mode", [(2, "weak"), (2, "union"), (4, "weak"), (4, "union")])
+def test_rank_shards_equal_whole_batch_on_gpu(world, mode):
     port = _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctxm.Process(target=_gpu_worker, args=(r, world, port, q, mode)) for r in range(world)]
     [p.start() for p in procs]
     sharded = [torch.from_numpy(a) for a in q.get(timeout=300)]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0")
-    half = npf // 2
-    # the per-frame max(gt_depth) of sample_along_rays is all-reduced (MAX) across the shards, so z is identical
-    union = torch.cat([pix[f * npf: f * npf + 2 * half] for f in range(4)])
-    s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=union, jitter=jit)
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "reference_tiled" if mode == "union" else "per_ray")
+    part = npf // world
+    # the per-frame max(gt_depth) of sample_along_rays is global in both modes (all-reduced MAX / taken from the whole list)
+    whole = torch.cat([pix[f * npf: f * npf + world * part] for f in range(4)])
+    s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=whole, jitter=jit)
     loss, _ = mapper.iteration_loss(s, smooth=True, u_offset=u[0], u_jitter=u[1])
     loss.backward()
     ref = _grads(dec, mapper, ql, Tl)
@@ -172,4 +253,30 @@ def test_two_rank_shards_equal_union_batch_on_gpu():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from util import rel_err
     errs = [rel_err(a, b) for a, b in zip(sharded, ref)]
-    assert max(errs) < 2e-4, errs          # fp32 sums in a different order; everything else is exact
+    assert max(errs) < 1e-4, errs          # fp32 sums in a different order; everything else is exact
+
+
+@pytest.mark.gpu
+def test_tv_slabs_sum_to_the_cube_on_gpu():
+    """dns_tv_fwd / dns_tv_bwd with nx / halo: slab values and slab gradients (halo rows overlapping the next slab's first
+    plane) add up to the whole lattice's value and gradient."""
+    from dns_slam_amd import ops
+    from dns_slam_amd.dist import shard_range
+    g = torch.Generator().manual_seed(2)
+    n, L = 13, 3
+    lat = torch.randn(n * n * n, L, generator=g).to("cuda")
+    ref_in = lat.clone().requires_grad_(True)
+    ref = ops.tv_smoothness(ref_in, n, n + 1)
+    ref.backward()
+    for W in (2, 4, 5):
+        tot, grad = 0.0, torch.zeros_like(lat)
+        for r in range(W):
+            a, b = shard_range(n, W, r)
+            hi = min(b + 1, n)
+            slab = lat[a * n * n: hi * n * n].clone().requires_grad_(True)
+            v = ops.tv_smoothness(slab, n, n + 1, nx=hi - a, halo=hi > b)
+            v.backward()
+            tot = tot + float(v)
+            grad[a * n * n: hi * n * n] += slab.grad
+        assert abs(tot - float(ref)) <= 1e-5 * abs(float(ref))
+        assert float((grad - ref_in.grad).abs().max()) <= 1e-5 * float(ref_in.grad.abs().max())

@@ -108,11 +108,12 @@ def test_cfg3_mapper_iteration_with_feature_code_matches_oracle():
 def test_cfg3_track_frame_50_iterations_match_oracle_adam(monkeypatch):
     """The whole per-frame tracking loop -- 50 x (draw 512 pixels + jitter -> rays -> coarse / colour / logit networks with
     the feature code -> composite -> the three masked losses -> pose gradient -> Adam, keep-best) -- against the oracle on
-    the same draws, two ways.  (i) Evaluation parity, all 50 iterations: the oracle's loss AT THE POSE the product held in
-    iteration k equals the product's loss within 1e-4 relative.  (ii) Free-running: the oracle stepped by torch.optim.Adam
-    from the same start follows the same trajectory -- losses within 1e-3 relative (the loss is steep in the pose: a 1e-6
-    pose difference, i.e. 1e-3 of one Adam step, moves it by 1e-4), best-loss camera within 2e-5 (unit quaternion, metres) after
-    50 steps of <= 1e-3 each."""
+    the same draws, one step ahead: in every iteration the oracle is placed at the pose the product held, must report the
+    product's loss (1e-4 relative), and its torch.optim.Adam step -- moments accumulated from the oracle's OWN gradients of
+    all iterations so far -- must land on the product's next pose within 1e-6 absolute, i.e. 1e-3 of one step (lr 1e-3).
+    (A free-running second trajectory is not a usable yardstick here: against this randomly initialised scene the loss is so
+    steep in the pose that Adam amplifies a 6e-8 rounding difference of step 2 to 4e-4 by step 50 -- measured -- while every
+    single step agrees.)  Keep-best: the returned camera is exactly the pose of the smallest-loss iteration."""
     from dns_slam_amd import ops
     from dns_slam_amd.common import get_quad_from_c2w
     from dns_slam_amd.tracking import Tracker
@@ -163,30 +164,30 @@ def test_cfg3_track_frame_50_iterations_match_oracle_adam(monkeypatch):
         mask = (so["gt_depth"] > 0.01) & so["inside"]
         return sr.tracking_loss(om, so, mask, tracker.lambda_p, tracker.lambda_d, tracker.lambda_l)[0]
 
+    # the pose after the 50th step, from the optimiser track_frame used (groups: [T], [quat] -- slams/tracking.py:120-124)
+    last = tracker.last_optimizer.param_groups
+    poses.append((last[1]["params"][0].detach().cpu().clone(), last[0]["params"][0].detach().cpu().clone()))
     torch.manual_seed(77)
-    best_o, cam_o, worst_eval, worst_free = float("inf"), None, 0.0, 0.0
+    worst_eval, worst_step = 0.0, 0.0
     for it in range(50):
         pix, jit = tracker.draw_pixels(), tracker.draw_jitter()       # the draws track_frame made, in its order
-        with torch.no_grad():
-            at_product_pose = float(oracle_loss(poses[it][0], poses[it][1], pix, jit))
-        rel = abs(got[it] - at_product_pose) / abs(at_product_pose)
-        worst_eval = max(worst_eval, rel)
-        assert rel <= 1e-4, f"iteration {it}, loss at the product's pose: {got[it]} vs {at_product_pose}"
+        with torch.no_grad():                                         # the oracle is put AT the product's pose of iteration `it`
+            qo.copy_(poses[it][0])
+            To.copy_(poses[it][1])
         opt_o.zero_grad()
         lo = oracle_loss(qo, To, pix, jit)
-        if float(lo) < best_o:
-            best_o, cam_o = float(lo), torch.cat((qo, To)).detach().clone()
-        lo.backward()
-        opt_o.step()
         rel = abs(got[it] - float(lo)) / abs(float(lo))
-        worst_free = max(worst_free, rel)
-        assert rel <= 1e-3, f"iteration {it}, free-running: {got[it]} vs {float(lo)}"
+        worst_eval = max(worst_eval, rel)
+        assert rel <= 1e-4, f"iteration {it}, loss at the product's pose: {got[it]} vs {float(lo)}"
+        lo.backward()
+        opt_o.step()                                                  # moments: the oracle's own gradients so far
+        step = float(torch.cat((qo.detach() - poses[it + 1][0], To.detach() - poses[it + 1][1])).abs().max())
+        worst_step = max(worst_step, step)
+        assert step <= 1e-6, f"iteration {it}: pose after the step differs by {step:.3e} (one Adam step is <= {lr:.0e})"
     REPORT.append(("cfg3 track_frame: worst per-iteration loss deviation at the product's pose, 50 iterations", worst_eval, worst_eval / 1e-4, 1e-4))
-    REPORT.append(("cfg3 track_frame: worst per-iteration loss deviation, free-running oracle Adam, 50 iterations", worst_free, worst_free / 1e-3, 1e-3))
-    assert abs(float(best) - best_o) <= 1e-3 * abs(best_o)
-    # |q| drifts freely (the loss does not depend on it: Adam turns the rounding residue along q into +-lr steps), so the
-    # cameras are compared as what they are: unit quaternion (rotation) + translation
-    unit = lambda c: torch.cat((c[:4] / c[:4].norm(), c[4:]))
-    dev = float((unit(cam7.cpu()) - unit(cam_o)).abs().max())
-    REPORT.append(("cfg3 track_frame: best camera (unit quaternion, translation) vs free-running oracle Adam", dev, dev / 2e-5, 2e-5))
-    assert dev <= 2e-5, (unit(cam7.cpu()), unit(cam_o))
+    REPORT.append(("cfg3 track_frame: worst one-step-ahead pose deviation (absolute; quaternion, metres), 50 iterations", worst_step,
+                   worst_step / 1e-6, 1e-6))
+    # keep-best (slams/tracking.py:331-336): the returned camera is the pose held in the iteration of the smallest loss
+    k = min(range(50), key=lambda i: got[i])
+    assert float(best) == got[k]
+    assert torch.equal(cam7.cpu(), torch.cat(poses[k]))
