@@ -19,6 +19,7 @@ __global__ __launch_bounds__(1024) void k(uint32_t iters, uint32_t mask_lanes, f
       if (MODE == 2) atomicAdd(bl + (a & 16383u), 1ull);
       if (MODE == 3) { atomicAdd(bf + (a & 32766u), 1.0f); atomicAdd(bf + (a & 32766u) + 1, 1.0f); }
       if (MODE == 4) bf[a & 32767u] += 1.0f;     // plain RMW (racy) as a reference for the LDS pipe rate
+      if (MODE == 5) atomicAdd((double*)raw + (a & 16383u), 1.0);
     }
   }
   __syncthreads();
@@ -46,6 +47,7 @@ int main() {
     run<2>("ds_add_u64 random", lanes);
     run<3>("ds_add_f32 pair (x, x+1)", lanes);
     run<4>("plain ds rmw", lanes);
+    run<5>("ds_add_f64 random", lanes);
   }
   return 0;
 }

@@ -29,7 +29,7 @@ def load(d):
     for r in csv.DictReader(open(f)):
         if "dns::" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"]) * 1024.0
     return agg

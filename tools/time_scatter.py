@@ -3,6 +3,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dns_slam_amd import ops
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+if len(sys.argv) > 2:
+    ops.SCATTER_FORM = (int(sys.argv[2]), 0)
 pm = ops.GridMeta(16, 592)
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
@@ -25,4 +27,4 @@ for _ in range(10):
     y.backward(gy, retain_graph=True)
 e1.record()
 torch.cuda.synchronize()
-print(f"P={P}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per backward (incl. zeros_like + transpose)")
+print(f"P={P} form={ops.SCATTER_FORM[0]}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per backward (incl. zeros_like + transpose)")
