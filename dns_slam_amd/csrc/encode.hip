@@ -279,7 +279,7 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Table gradient by LDS binning in 64-bit fixed point.
+// Table gradient by LDS binning (float64 bins in the binned kernel, 64-bit fixed point in the queue kernel).
 //
 // Per-corner global atomics (one lane = one random row) run ~17x below the coalesced atomic rate on gfx950
 // and serialise on the 4096-cell coarse levels.  Instead a workgroup owns one CHUNK of one level (8192 rows held
@@ -287,11 +287,14 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
 // and accumulates the corners that fall in its chunk; the chunk then leaves as fully coalesced global float
 // atomics (256 B per wave instruction, the full-rate shape).
 //
-// The LDS accumulators are 64-bit FIXED POINT, not float: measured on MI355X (tools/lds_atomic_rate.hip) ds_add_f32
-// retires ~1 lane per 3 cycles per CU (195 cycles per wave instruction, 0.2 T lane-atomics/s chip-wide) while
-// ds_add_u64 takes 11.8 cycles per wave instruction (3.3 T/s) -- 16x.  Every contribution w*g (an fp32 product) is
-// scaled by a power of two chosen from max|dL/dy| of the launch (so the product converts to int64 exactly and 2^22
-// contributions cannot overflow) and added as an integer: the per-chunk sums are exact and order-independent.
+// The LDS accumulators are 64 bits wide, never fp32: measured on MI355X (tools/lds_atomic_rate.hip) ds_add_f32 retires
+// ~1 lane per 3 cycles per CU (195 cycles per wave instruction, 0.2 T lane-atomics/s chip-wide) while ds_add_u64 takes 11.9
+// cycles per wave instruction (3.3 T/s) and ds_add_f64 21.6.  (fp32 bins over 16 384-row chunks -- half the re-hashing --
+// were measured in round 2: 476 us against 312 us per 262 144 points.)  Round 1 added every contribution w*g as an integer
+// (scaled by a power of two chosen from max|dL/dy| of the launch so the fp32 product converts to int64 exactly): exact,
+// order-independent sums, at 11 vector instructions per converted value in a VALU-bound kernel.  The binned kernel now adds
+// the fp32 product into a float64 bin (ds_add_f64): 276 us, sums good to ~1e-16 whatever the order; the queue kernel (large
+// tables) keeps the fixed-point form.
 struct BinPlan {
   uint32_t n_levels;
   uint32_t chunk_rows;                    // rows per chunk
@@ -375,14 +378,17 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
                                                                     const float2* __restrict__ dg_t,
                                                                     const uint32_t* __restrict__ gmax,
                                                                     float* __restrict__ d_table) {
+  // Bins: one float64 per table float, added with ds_add_f64.  Every w*g product is formed in fp32 (as tcnn forms it) and
+  // summed in float64, so a cell's sum carries ~1e-16 of relative error whatever the order of the adds -- after the final
+  // rounding to fp32 the result is the correctly rounded sum except on near-ties.  Measured LDS atomic rates on MI355X
+  // (tools/lds_atomic_rate.hip, cycles per wave-instruction per CU): ds_add_u64 11.9, ds_add_f64 21.6, ds_add_f32 195.
+  // Round 1 used 64-bit fixed-point bins (ds_add_u64 of an 11-instruction exact float -> fixed conversion per value): this
+  // kernel is VALU-bound, the conversions cost more than the slower atomic (312 -> 276 us per 262 144 points).
   extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
+  double* const dbins = reinterpret_cast<double*>(bins);
   const float mx = __uint_as_float(*gmax);
   const bool poisoned = gmax[1] != 0u;           // NaN / Inf upstream (dgrid_transpose_kernel): NaN into the owned rows
   if (!(mx > 0.f) && !poisoned) return;          // all-zero upstream gradient: nothing to add (uniform exit)
-  int ex;
-  (void)frexpf(mx, &ex);                         // mx < 2^ex
-  const float scale = ldexpf(1.0f, 40 - ex);     // |w*g| * scale < 2^40; 2^22 contributions stay below 2^62
-  const double inv_scale = (double)ldexpf(1.0f, ex - 40);
   // job -> (level, chunk, slice).  All chunks of one (level, slice) group sweep the SAME points, so they should share
   // an L2: workgroups are dealt round-robin over the 8 XCDs (xcd = blockIdx % 8), hence group g goes to XCD g % 8 and
   // its chunks sit at consecutive q = blockIdx / 8 -- they start together on that XCD's 32 CUs and 7 of 8 point reads
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
     for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
     return;
   }
-  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) bins[i] = 0ull;
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) dbins[i] = 0.0;
   __syncthreads();
   const float s = lv.scale[l];
   const uint32_t res = lv.resolution[l], hashed = lv.hashed[l];
@@ -451,8 +457,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
   }
   // The kernel is VALU-bound (SQ counters: 77 % VALU-busy, 288 vector instructions per 64-point visit before this form):
   // the per-axis hash / stride terms are computed once per point (two quarter-rate multiplies instead of two per corner
-  // and again per hit), the dense / hashed split is hoisted to a uniform branch, and the float -> 64-bit fixed-point
-  // conversion is the 11-instruction split below instead of the library's generic f32 -> i64.
+  // and again per hit), the dense / hashed split is hoisted to a uniform branch, and the bins take the fp32 product as a
+  // float64 (one conversion) instead of a 64-bit fixed-point value (11 instructions).
   auto sweep = [&](auto hashed_tag) {
     constexpr bool HASHED = decltype(hashed_tag)::value;
     const uint32_t mask = size - 1u, res2 = res * res;
@@ -471,7 +477,6 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
         }
       }
       const bool work = live && !(gg.x == 0.f && gg.y == 0.f);
-      const float gs0 = gg.x * scale, gs1 = gg.y * scale;                  // exact: power-of-two scale
       float f[3];
       uint32_t g[3];
 #pragma unroll
@@ -506,8 +511,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
           hit_mask &= hit_mask - 1u;
           const uint32_t local = row_of((c & 1u) ? ax1 : ax0, (c & 2u) ? ay1 : ay0, (c & 4u) ? az1 : az0) - base;
           const float w = ((c & 1u) ? f[0] : 1.0f - f[0]) * ((c & 2u) ? f[1] : 1.0f - f[1]) * ((c & 4u) ? f[2] : 1.0f - f[2]);
-          atomicAdd(bins + 2 * local, (unsigned long long)fixed_rn(w * gs0));
-          atomicAdd(bins + 2 * local + 1, (unsigned long long)fixed_rn(w * gs1));
+          atomicAdd(dbins + 2 * local, (double)(w * gg.x));
+          atomicAdd(dbins + 2 * local + 1, (double)(w * gg.y));
         }
       }
     }
@@ -517,8 +522,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
   __syncthreads();
   float* out = d_table + 2 * ((size_t)lv.offset[l] + base);
   for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) {
-    const long long v = (long long)bins[i];
-    if (v != 0) atomicAdd(out + i, (float)((double)v * inv_scale));
+    const double v = dbins[i];
+    if (v != 0.0) atomicAdd(out + i, (float)v);
   }
 }
 

@@ -4,7 +4,7 @@ out = sys.argv[1]; flt = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:]
         if flt and flt not in r["Kernel_Name"]:
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
