@@ -9,12 +9,16 @@ One "step" = one full Mapper iteration (reference slams/mapping.py:881-910) on s
 draw pixels -> ray generation + depth-guided sampling -> OneBlob + hash grid -> coarse / per-class fine / colour /
 logit MLPs -> compositing -> the seven loss terms (incl. the 63^3-point smoothness lattice) -> backward to grid,
 MLPs and poses -> (N>1: one flat gradient all-reduce) -> Adam step.  Nothing is skipped inside the timed region.
-Workload = BASELINE.json configs[1]: 4096 rays x 64 samples per GPU, T=2^16 hash grid, 2x64 MLPs, mapping only.
-Weak scaling: every rank renders its own 4096 rays (global batch 4096*N).
+Workload = BASELINE.json configs[1]: 4096 rays x 64 samples per GPU, T=2^16 hash grid, 2x64 MLPs, mapping only
+(--workload cfg3 / cfg5 / cfg5_fp16 / ref: the other configurations).  The iteration is launched eagerly, the smoothness
+branch on a second stream.  N GPUs: weak scaling, every rank renders its own 4096 rays (global batch 4096*N);
+--union-batch = the N ranks share one 4096-ray batch (strong).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant HIP entry point, algorithmic bytes or flops / its summed
-event time, measured on the launch stream inside the timed region) and `cpu_baseline` (the oracle, PyTorch CPU, on
-this host's cores, bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (the kernel with the largest summed duration: algorithmic bytes or flops /
+its duration, from the library's own event pair around every kernel launch on the launch stream -- dns_kernel_timing --
+over K eagerly launched steps of the same workload; a replayed graph cannot be bracketed per kernel), `kernel_rooflines`
+(the same for every kernel), `iteration_roofline` (whole iteration incl. PMC traffic per step) and `cpu_baseline` (the
+oracle, PyTorch CPU, on this host's cores, bounded sample).
 """
 import argparse
 import math
@@ -145,7 +149,7 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False):
     mapper.static_shapes = True                              # sync-free iteration: capturable in a hipGraph
     mapper.overlap_smooth = overlap
     # the next iteration's pixel / jitter / lattice draws are enqueued on the side stream (same generator order)
-    mapper.prefetch_draws = overlap and os.environ.get("DNS_PREFETCH_DRAWS", "1") != "0"
+    mapper.prefetch_draws = overlap and not graph          # (a captured iteration makes its own draws: nothing to run ahead)
     mapper.set_decoder(frames)
     optimizer, quad_list, T_list = mapper.set_optimizer(frames, fused=True)     # csrc/adam.hip: one launch, step count on device
     for grp, lr in zip(optimizer.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):
@@ -187,8 +191,11 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False):
 
 
 def capture(step, n_warm=3):
-    """Capture one full iteration (sampling -> ... -> Adam) into a hipGraph; replays draw fresh rays (graph-safe
-    Philox offsets).  Returns a zero-argument callable."""
+    """Capture one full iteration (sampling -> ... -> Adam) into a hipGraph; replays draw fresh rays (graph-safe Philox
+    offsets).  Returns a zero-argument callable returning the (static) loss tensor.  NOT used by the benchmark: on this stack
+    (ROCm 7.0.51831, torch 2.10) a graph replayed after a host-side stream / device synchronisation that directly follows a
+    replay computes garbage or faults -- a pure-PyTorch control graph changes its result too (DESIGN.md section 5,
+    tools/graph_sync_*.py) -- and the timing contract needs exactly that synchronisation between warm-up and timed steps."""
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -198,8 +205,12 @@ def capture(step, n_warm=3):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        step()
-    return g.replay
+        loss = step()
+
+    def replay():
+        g.replay()
+        return loss                  # the graph's static output: holds the last replay's loss
+    return replay
 
 
 def host_cores():
@@ -284,8 +295,10 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="per-step progress on stderr")
     ap.add_argument("--no-render-forward", action="store_true", help="skip the secondary full-image render line")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the iteration from a hipGraph (one stream) instead of launching it eagerly on two streams")
-    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches; kept for older command lines")
+                    help="replay the iteration from a hipGraph (EXPERIMENT ONLY: results after the warm-up synchronisation are "
+                         "unreliable on this stack, see capture(); the run aborts when the final loss is not finite)")
+    ap.add_argument("--eager", "--no-graph", dest="eager", action="store_true",
+                    help="(default) launch the iteration eagerly, the smoothness branch on a second stream")
     ap.add_argument("--no-overlap", action="store_true", help="eager, but keep the smoothness branch on the main stream")
     ap.add_argument("--union-batch", action="store_true",
                     help="N>1: the N ranks share ONE batch of the configured size (shared-seed draws, rank slices of the rays and "
@@ -303,17 +316,19 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]
-    overlap = not args.graph and not args.no_overlap          # hipGraph replay serialises the two branches: no gain there
+    # Eager launches on two streams are the measured path.  A hipGraph replay of the iteration (--graph) is not: see capture().
+    use_graph = args.graph and not args.eager and ctx.world_size == 1
+    overlap = not use_graph and not args.no_overlap          # the smoothness branch on a second stream
     union = ctx.union
     cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + (0 if union else ctx.rank), dist_ctx=ctx, overlap=overlap,
-                                                  graph=args.graph and not args.no_graph)
+                                                  graph=use_graph)
     n_rays = 4 * sum(wl["rays"])
     job_rays = n_rays if union else n_rays * ctx.world_size          # rays the whole job renders per step
     S = wl["nu"] + wl["ns"]
 
     run = step
     graphed = False
-    if args.graph and not args.no_graph:
+    if use_graph:
         try:
             run = capture(step)
             graphed = True
@@ -339,7 +354,7 @@ def main():
     ctx.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    final_loss = float(last) if torch.is_tensor(last) else None        # after the clock stopped
+    final_loss = float(last.detach()) if torch.is_tensor(last) else None        # after the clock stopped
     if final_loss is not None and not math.isfinite(final_loss):
         raise RuntimeError(f"non-finite loss after the timed steps ({final_loss}): the measurement is void")
     elapsed = ctx.max_over_ranks(elapsed, device)

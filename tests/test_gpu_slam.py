@@ -558,6 +558,31 @@ def test_tracker_track_frame_eager_and_graphed_reduce_pose_error():
         assert err1 < err0 * 1.5                 # does not diverge (40 tiny-lr steps move the pose by <= 0.04)
 
 
+def test_tracker_graph_replay_equals_eager_loop():
+    """Tracker.track_frame(graph=True) -- one captured iteration replayed n_iters times -- against the eager loop with the
+    same device-side draws (static_shapes) from the same seed: the same keep-best loss (1e-5) and camera (2e-5: float atomics in the
+    pose-gradient reduction are the only run-to-run difference, amplified over 25 Adam steps; Philox offsets advance per
+    replay exactly as the eager generator does).  Reads happen only after the last
+    replay: on this stack a graph replayed after a host synchronisation that directly follows a replay is not reliable
+    (DESIGN.md section 5), so the tracker never does that."""
+    from dns_slam_amd.tracking import Tracker
+    cfg, bound, cam, frames, dec, mapper = _setup(64, 2, n_pixels=400)
+    cfg["tracking"]["n_pixels"] = 256
+    cur = {"gt_color": frames["gt_color"][2], "gt_depth": frames["gt_depth"][2], "gt_label": frames["gt_label"][2]}
+    c2w = frames["est_c2w"][2].clone()
+    c2w[:3, 3] += torch.tensor([0.02, -0.01, 0.015], dtype=c2w.dtype)
+    out = {}
+    for graph in (False, True):
+        tracker = Tracker(cfg, dec, bound, cam, device=DEV)
+        tracker.border = 5
+        tracker.static_shapes = True
+        torch.manual_seed(3)
+        cam7, best = tracker.track_frame(cur, c2w, n_iters=25, fused=True, graph=graph)
+        out[graph] = (cam7.detach().cpu().clone(), float(best))
+    assert abs(out[True][1] - out[False][1]) <= 1e-5 * abs(out[False][1]), (out[True][1], out[False][1])
+    assert float((out[True][0] - out[False][0]).abs().max()) <= 2e-5, (out[True][0], out[False][0])
+
+
 def test_optimize_driver_and_decoder_init():
     """Mapper.optimize (slams/mapping.py:839-949) end to end incl. the decoder warm-up (:764-836) for classes that appear
     after frame 50: the warm-up only draws rays of the new classes, the driver returns a valid pose and writes the

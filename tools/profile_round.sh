@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r02 [cfg2]
 # 1. rocprofv3 --kernel-trace --stats      -> profiles/<tag>_kernel_stats.csv      (per-kernel durations, one stream)
 # 2. rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, no trace domains) -> profiles/<tag>_pmc_traffic.txt + pmc_traffic.json
-# 3. the default bench line (two streams, with cpu_baseline)                      -> profiles/<tag>_bench_default.json
+# 3. the default bench line (eager, two streams, with cpu_baseline)                      -> profiles/<tag>_bench_default.json
 # Steps are joined with &&: a failed or killed GPU step starts no further one.
 set -o pipefail
 tag=$1; wl=${2:-cfg2}
@@ -11,7 +11,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out $root/profiles
 export TMPDIR=/tmp
-flags="--workload $wl --steps 3 --warmup 2 --no-overlap --no-cpu-baseline --no-kernel-timing --no-render-forward"
+flags="--workload $wl --steps 3 --warmup 2 --eager --no-overlap --no-cpu-baseline --no-kernel-timing --no-render-forward"
 cd /tmp &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $root/bench.py $flags > $out/stats.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 $root/bench.py $flags > $out/fetch.log 2>&1 &&
