@@ -63,8 +63,9 @@ def test_fullsize_properties(workload):
     g_all, = torch.autograd.grad(loss, table, retain_graph=False)
     assert bool(torch.isfinite(g_all).all()) and float(g_all.abs().max()) > 0
     # linearity of the scatter in the upstream gradient: grad(2 * loss) == 2 * grad(loss).  Every step up to the per-chunk
-    # fixed-point sums scales exactly; what remains is the order of the float atomics that add the <= 24 slice sums of a
-    # chunk into the table gradient (a few ulp of the largest partial sums: measured 2-3e-7 of max |g|)
+    # 64-bit LDS sums scales exactly (float64 bins of fp32 products / fixed point in the queue form); what remains is the order
+    # of the float atomics that add the <= 24 slice sums of a chunk into the table gradient (a few ulp of the largest partial
+    # sums: measured 2-3e-7 of max |g|)
     loss2, _ = mapper.iteration_loss(s, smooth=False)
     g2, = torch.autograd.grad(2.0 * loss2, table)
     assert float((g2 - 2.0 * g_all).abs().max()) <= 1e-5 * float(g_all.abs().max())
@@ -262,9 +263,10 @@ def test_cfg2_fullsize_matches_oracle():
     # of the two fp32 implementations, which changes THAT point's 128 cell contributions by a few per cent -- visible in the
     # fine levels' cells, which sum only a handful of points.  The scatter itself is therefore checked on its own, with no
     # network in between: the product's OWN upstream gradients (recorded above) through the oracle's float64 scatter must
-    # reproduce the product's table gradient in EVERY entry to 1e-5 |b| + 1e-6 A + 1e-10 max|b| (the binned sums are exact in
-    # 64-bit fixed point with a quantum of 2^-40 of the launch's largest |gradient| per contribution -- the last term --; what
-    # remains is one fp32 rounding per chunk flush and the float atomics that combine chunk slices).
+    # reproduce the product's table gradient in EVERY entry to 1e-5 |b| + 1e-6 A + 1e-10 max|b| (the binned sums are float64
+    # sums of fp32 products -- the queue form's 64-bit fixed point has a quantum of 2^-40 of the launch's largest |gradient|
+    # per contribution, the last term --; what remains is one fp32 rounding per chunk flush and the float atomics that
+    # combine chunk slices).
     from oracle import render_math as rm
     exp = torch.zeros_like(om.table)
     A2 = torch.zeros_like(om.table)

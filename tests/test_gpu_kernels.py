@@ -99,7 +99,7 @@ def test_encode_world_normalisation_fp64():
 @pytest.mark.parametrize("scatter", ["auto", "atomic", "queues"])
 @pytest.mark.parametrize("poison", [float("nan"), float("inf")])
 def test_table_gradient_propagates_non_finite(scatter, poison, monkeypatch):
-    """A NaN / Inf in the upstream grid gradient must reach d_table in every scatter form: the fixed-point LDS bins cannot
+    """A NaN / Inf in the upstream grid gradient must reach d_table in every scatter form: the 64-bit LDS bins of the queue form (fixed point) cannot
     carry it (fmaxf drops a NaN, the integer conversion of a non-finite product is undefined), so the transpose kernel flags
     it and the binned / queue kernels write NaN into their rows (csrc/encode.hip), as tcnn's float atomics would."""
     ops = _ops()
