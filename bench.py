@@ -129,7 +129,7 @@ def kernel_rooflines(spans, wl, steps, pmc):
     return rows
 
 
-def build(wl, device, seed, dist_ctx, overlap=False, graph=False):
+def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
@@ -149,7 +149,8 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False):
     mapper.static_shapes = True                              # sync-free iteration: capturable in a hipGraph
     mapper.overlap_smooth = overlap
     # the next iteration's pixel / jitter / lattice draws are enqueued on the side stream (same generator order)
-    mapper.prefetch_draws = overlap and not graph          # (a captured iteration makes its own draws: nothing to run ahead)
+    # (a captured iteration makes its own draws: nothing to run ahead; `prefetch` overrides, for the A/B test)
+    mapper.prefetch_draws = (overlap and not graph) if prefetch is None else bool(prefetch)
     mapper.set_decoder(frames)
     optimizer, quad_list, T_list = mapper.set_optimizer(frames, fused=True)     # csrc/adam.hip: one launch, step count on device
     for grp, lr in zip(optimizer.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):

@@ -329,11 +329,10 @@ def test_cfg2_prefetched_draws_same_trajectory_without_host_syncs(monkeypatch):
     from dns_slam_amd import dist as dd
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
     runs = []
-    for prefetch in ("0", "1", "1"):
-        monkeypatch.setenv("DNS_PREFETCH_DRAWS", prefetch)
+    for prefetch in (False, True, True):
         cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS["cfg2"], DEV, seed=100, dist_ctx=dd.DistCtx(),
-                                                            overlap=True)
-        assert mapper.prefetch_draws == (prefetch == "1")
+                                                            overlap=True, prefetch=prefetch)
+        assert mapper.prefetch_draws == prefetch
         losses = [step().detach() for _ in range(16)]
         torch.cuda.synchronize()
         runs.append(torch.stack(losses).cpu())
