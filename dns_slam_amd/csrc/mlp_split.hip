@@ -4,6 +4,9 @@
 
 namespace dns {
 namespace sp {
+#ifdef DNS_BWD_TRACE
+unsigned long long* g_bwd_trace = nullptr;
+#endif
 
 // ---- LDS layout of the forward kernel (bytes) ----
 template <int NN, int NL>
@@ -338,6 +341,9 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, hipStream_t st) {
   using namespace sp;
   BwdArgs a;
+#ifdef DNS_BWD_TRACE
+  a.trace = g_bwd_trace;
+#endif
   a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.dy = dy; a.lddy = lddy; a.params = params;
   a.n_in = n_in; a.n_out = n_out; a.dx = d_x; a.lddx = lddx;
   a.dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)acc1, (uint32_t)acc2};
@@ -384,3 +390,7 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
 }
 
 }  // namespace dns
+
+#ifdef DNS_BWD_TRACE
+extern "C" void dns_debug_bwd_trace(unsigned long long* buf) { dns::sp::g_bwd_trace = buf; }
+#endif

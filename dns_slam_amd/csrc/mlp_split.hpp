@@ -259,6 +259,10 @@ constexpr uint32_t STG_ROWS = 64;            // two row tables: the tile being c
 constexpr uint32_t STG_RMAX = 32;            // per-row maxima of the tile's input rows
 constexpr uint32_t STG_WAVE_FLOATS = STG_FLOATS + STG_ROWS + STG_RMAX;
 
+// (Measured in round 2: volatile staging accesses instead of this fence -- so that unrelated LDS reads, e.g. the next weight
+// fragments, may move across a staging round trip -- let hipcc hoist so much that every backward instance spilled 60-198
+// registers and the float4 accesses were split into dwords.  The fence doubles as the scheduling barrier that keeps the
+// register pressure where it is.)
 __device__ __forceinline__ void wave_lds_fence() {
   asm volatile("" ::: "memory");             // LDS instructions of one wave execute in order: compiler fence only
   __builtin_amdgcn_wave_barrier();
@@ -576,7 +580,20 @@ struct BwdArgs {
   const int32_t* row_index;
   const int32_t* tile_group;
   uint32_t param_stride, tiles_per_block;
+#ifdef DNS_BWD_TRACE
+  unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
+#endif
 };
+#ifdef DNS_BWD_TRACE
+extern unsigned long long* g_bwd_trace;
+#define DNS_TR(slot)                                                                                        \
+  do {                                                                                                      \
+    if (a.trace && lane == 0 && tr_tile < 6u)                                                               \
+      a.trace[((size_t)(blockIdx.x * 4u + wave) * 8u + tr_tile) * 8u + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define DNS_TR(slot) do { } while (0)
+#endif
 
 // per-(n_neurons, n_hidden_layers) launchers: one translation unit each (mlp_split_bwd_*.hip)
 int launch_bwd_32_1(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
