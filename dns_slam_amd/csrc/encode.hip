@@ -51,6 +51,43 @@ __device__ __forceinline__ float quartic_pdf(float v, float n) {
   return (15.0f / 16.0f) * n * t * t;
 }
 
+// G(b) of tcnn's kernel_one_blob at bin edge b (PDF: its derivative with respect to the distance): the kernel centred at x and
+// its two periodic images; edge n_bins is edge 0 one period on (+1 for the cdf).  Expression order as in the full loops.
+template <bool PDF>
+__device__ __forceinline__ float oneblob_edge(uint32_t b, uint32_t n_bins, float n, float xa) {
+  const uint32_t bb = b < n_bins ? b : 0u;
+  const float d = (float)bb / n - xa;
+  float g = PDF ? quartic_pdf(d, n) + quartic_pdf(d - 1.0f, n) + quartic_pdf(d + 1.0f, n)
+                : quartic_cdf(d, n) + quartic_cdf(d - 1.0f, n) + quartic_cdf(d + 1.0f, n);
+  if (!PDF && b >= n_bins) g += 1.0f;
+  return g;
+}
+
+// The quartic kernel has radius 1/n: away from x (and its images x -+ 1) the cdf terms are EXACTLY 0 or 1 (clamped) and the
+// pdf terms exactly 0, so a bin's value G(b+1) - G(b) is exactly zero unless one of its edges lies within one bin of
+// c = x n + s n, s in {-1, 0, 1}.  Only the five bins around floor(c) are evaluated (two bins of margin against rounding),
+// in ascending order, with the same expressions as the loop over all n + 1 edges: identical results for finite inputs
+// from 18 instead of 51 kernel evaluations per coordinate.  fn(bin, G(bin + 1) - G(bin)) is called for every bin that may be
+// non-zero.  (An Inf / NaN in a far bin's upstream gradient no longer turns 0 * Inf into NaN in the backward.)
+template <bool PDF, typename F>
+__device__ __forceinline__ void oneblob_windows(uint32_t n_bins, float n, float xa, F fn) {
+  const float xn = xa * n;
+#pragma unroll
+  for (int w = -1; w <= 1; ++w) {
+    const float c = xn + (float)w * n;
+    if (!(c > -3.0f && c < n + 3.0f)) continue;          // also skips NaN
+    const int k = (int)floorf(c);
+    const int j0 = max(k - 2, 0), j1 = min(k + 2, (int)n_bins - 1);
+    if (j0 > j1) continue;
+    float left = oneblob_edge<PDF>((uint32_t)j0, n_bins, n, xa);
+    for (int j = j0; j <= j1; ++j) {
+      const float right = oneblob_edge<PDF>((uint32_t)j + 1u, n_bins, n, xa);
+      fn((uint32_t)j, right - left);
+      left = right;
+    }
+  }
+}
+
 __device__ __forceinline__ void load_point(const float* __restrict__ in, const Bound6& bd, bool normalise,
                                            uint32_t p, float x[3]) {
 #pragma unroll
@@ -75,7 +112,7 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
                                                          const float2* __restrict__ table, GridLevels lv,
                                                          float* __restrict__ x_out, float* __restrict__ pe_out,
                                                          uint32_t ld_pe, float* __restrict__ grid_out,
-                                                         uint32_t ld_grid) {
+                                                         uint32_t ld_grid, float2* __restrict__ dydx) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
@@ -95,9 +132,14 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
     const uint32_t p0 = blockIdx.x * blockDim.x;
     const uint32_t rows = min(blockDim.x, P - p0);
     float* out = out_base + (size_t)p0 * ld;
+    // (row, column) advance incrementally: an integer division per element was this loop's cost
+    const uint32_t dr = blockDim.x / nc, dc = blockDim.x - dr * nc;
+    uint32_t r = threadIdx.x / nc, c = threadIdx.x - r * nc;
     for (uint32_t i = threadIdx.x; i < rows * nc; i += blockDim.x) {
-      const uint32_t r = i / nc, c = i - r * nc;
       out[(size_t)r * ld + c] = tile[r * ldt + c];
+      r += dr;
+      c += dc;
+      if (c >= nc) { c -= nc; ++r; }
     }
     __syncthreads();
   };
@@ -108,6 +150,11 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float xa = x[a];
+        if (n_bins >= 8u && fabsf(xa) < 4.0f) {            // windows of different images cannot overlap
+          for (uint32_t b = 0; b < n_bins; ++b) row[a * n_bins + b] = 0.f;
+          oneblob_windows<false>(n_bins, n, xa, [&](uint32_t j, float v) { row[a * n_bins + j] = v; });
+          continue;
+        }
         float first = 0.f, left = 0.f;
         for (uint32_t b = 0; b <= n_bins; ++b) {
           float g;
@@ -155,6 +202,22 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
         }
         row[2 * l] = a0;
         row[2 * l + 1] = a1;
+        if (dydx) {
+          // d(feature) / d(normalised coordinate), both features, per axis -- what tcnn's kernel_grid keeps as dy_dx when the
+          // input needs a gradient (the poses do, through pts): the backward then needs no second gather of the 8 corners.
+          // Layout [level][axis][point] float2: a wave's 64 points are 512 contiguous bytes per store.
+          const float wx0 = 1.0f - f[0], wx1 = f[0], wy0 = 1.0f - f[1], wy1 = f[1], wz0 = 1.0f - f[2], wz1 = f[2];
+          float2 jx, jy, jz;
+          jx.x = s * (wy0 * wz0 * (v[1].x - v[0].x) + wy1 * wz0 * (v[3].x - v[2].x) + wy0 * wz1 * (v[5].x - v[4].x) + wy1 * wz1 * (v[7].x - v[6].x));
+          jx.y = s * (wy0 * wz0 * (v[1].y - v[0].y) + wy1 * wz0 * (v[3].y - v[2].y) + wy0 * wz1 * (v[5].y - v[4].y) + wy1 * wz1 * (v[7].y - v[6].y));
+          jy.x = s * (wx0 * wz0 * (v[2].x - v[0].x) + wx1 * wz0 * (v[3].x - v[1].x) + wx0 * wz1 * (v[6].x - v[4].x) + wx1 * wz1 * (v[7].x - v[5].x));
+          jy.y = s * (wx0 * wz0 * (v[2].y - v[0].y) + wx1 * wz0 * (v[3].y - v[1].y) + wx0 * wz1 * (v[6].y - v[4].y) + wx1 * wz1 * (v[7].y - v[5].y));
+          jz.x = s * (wx0 * wy0 * (v[4].x - v[0].x) + wx1 * wy0 * (v[5].x - v[1].x) + wx0 * wy1 * (v[6].x - v[2].x) + wx1 * wy1 * (v[7].x - v[3].x));
+          jz.y = s * (wx0 * wy0 * (v[4].y - v[0].y) + wx1 * wy0 * (v[5].y - v[1].y) + wx0 * wy1 * (v[6].y - v[2].y) + wx1 * wy1 * (v[7].y - v[3].y));
+          dydx[((size_t)l * 3 + 0) * P + p] = jx;
+          dydx[((size_t)l * 3 + 1) * P + p] = jy;
+          dydx[((size_t)l * 3 + 2) * P + p] = jz;
+        }
       }
     }
     if (TILED) flush(grid_out, ld_grid, g_dim);
@@ -166,7 +229,8 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
                                                          const float2* __restrict__ table, GridLevels lv,
                                                          const float* __restrict__ d_pe, uint32_t ld_dpe,
                                                          const float* __restrict__ d_grid, uint32_t ld_dgrid,
-                                                         float* __restrict__ d_table, float* __restrict__ d_x) {
+                                                         float* __restrict__ d_table, float* __restrict__ d_x,
+                                                         const float2* __restrict__ dydx) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
@@ -181,9 +245,13 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
     const uint32_t p0 = blockIdx.x * blockDim.x;
     const uint32_t rows = min(blockDim.x, P - p0);
     const float* src = d_pe + (size_t)p0 * ld_dpe + col0;
+    const uint32_t dr = blockDim.x / nc, dc = blockDim.x - dr * nc;
+    uint32_t r = threadIdx.x / nc, c = threadIdx.x - r * nc;
     for (uint32_t i = threadIdx.x; i < rows * nc; i += blockDim.x) {
-      const uint32_t r = i / nc, c = i - r * nc;
       tile[r * ldt + c] = src[(size_t)r * ld_dpe + c];
+      r += dr;
+      c += dc;
+      if (c >= nc) { c -= nc; ++r; }
     }
     __syncthreads();
   };
@@ -201,6 +269,12 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float xa = x[a];
+      if (n_bins >= 8u && fabsf(xa) < 4.0f) {
+        float accw = 0.f;
+        oneblob_windows<true>(n_bins, n, xa, [&](uint32_t j, float v) { accw -= row[a * n_bins + j] * v; });
+        dx[a] += accw;
+        continue;
+      }
       float first = 0.f, left = 0.f, acc = 0.f;
       for (uint32_t b = 0; b <= n_bins; ++b) {
         float g;
@@ -218,7 +292,20 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
     }
   }
   if (TILED) stage(pe_dim, g_dim);
-  if (live && d_grid) {
+  if (live && d_grid && dydx && d_x && !d_table) {
+    // the forward kept d(features)/dx: a streaming dot product, no gather (coalesced 8-byte reads, lane = point).
+    // (Requesting all 48 values before the first staging barrier was measured: 96 more registers, 0.102 -> 0.113 ms.)
+    const float* row = TILED ? tile + threadIdx.x * ldt : d_grid + (size_t)p * ld_dgrid;
+#pragma unroll 4
+    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+      const float g0 = row[2 * l], g1 = row[2 * l + 1];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float2 j = dydx[((size_t)l * 3 + a) * P + p];
+        dx[a] += j.x * g0 + j.y * g1;
+      }
+    }
+  } else if (live && d_grid) {
     const float* row = TILED ? tile + threadIdx.x * ldt : d_grid + (size_t)p * ld_dgrid;
 #pragma unroll 2
     for (uint32_t l = 0; l < lv.n_levels; ++l) {
@@ -804,9 +891,11 @@ using namespace dns;
 
 extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
                               const DnsGridMeta* meta, float* x_out, float* pe_out, uint32_t ld_pe, float* grid_out,
-                              uint32_t ld_grid, void* stream) {
+                              uint32_t ld_grid, float* dy_dx, void* stream) {
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(in != nullptr, "dns_encode_fwd: in is NULL");
+  DNS_REQUIRE(!dy_dx || grid_out, "dns_encode_fwd: dy_dx needs the grid encoding");
+  DNS_REQUIRE(!dy_dx || (((uintptr_t)dy_dx) & 7u) == 0, "dns_encode_fwd: dy_dx must be 8-byte aligned");
   if (pe_out) DNS_REQUIRE(n_bins >= 1 && n_bins <= 64 && ld_pe >= 3 * n_bins, "dns_encode_fwd: n_bins %u / ld_pe %u", n_bins, ld_pe);
   GridLevels lv = {};
   if (grid_out) {
@@ -821,20 +910,23 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
   if (tiled) {
     const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
     DNS_LAUNCH(encode_fwd_kernel<true>, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound),
-                       bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid);
+                       bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid,
+                       (float2*)dy_dx);
   } else {
     DNS_LAUNCH(encode_fwd_kernel<false>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, in, make_bound(bound),
-                       bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid);
+                       bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid,
+                       (float2*)dy_dx);
   }
   return check_launch("dns_encode_fwd");
 }
 
 extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
                               const DnsGridMeta* meta, const float* d_pe, uint32_t ld_dpe, const float* d_grid,
-                              uint32_t ld_dgrid, float* d_table, float* d_x, float* ws, uint32_t flags, uint32_t queue_cap,
-                              void* stream) {
+                              uint32_t ld_dgrid, float* d_table, float* d_x, const float* dy_dx, float* ws, uint32_t flags,
+                              uint32_t queue_cap, void* stream) {
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
+  DNS_REQUIRE(!dy_dx || (((uintptr_t)dy_dx) & 7u) == 0, "dns_encode_bwd: dy_dx must be 8-byte aligned");
   DNS_REQUIRE((flags & ~DNS_SCATTER_MASK) == 0, "dns_encode_bwd: unknown flags 0x%x", flags);
   GridLevels lv = {};
   if (d_grid) {
@@ -861,10 +953,11 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       DNS_LAUNCH(encode_bwd_kernel<true>, dim3(blocks128), dim3(128),
                          (size_t)128 * ((3 * n_bins > 2 * lv.n_levels ? 3 * n_bins : 2 * lv.n_levels) + 1) * sizeof(float), st, x,
                          make_bound(bound), bound ? 1 : 0, P, n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid,
-                         d_table_direct, d_x);
+                         d_table_direct, d_x, (const float2*)dy_dx);
     } else {
       DNS_LAUNCH(encode_bwd_kernel<false>, dim3(blocks128), dim3(128), 0, st, x, make_bound(bound), bound ? 1 : 0, P,
-                         n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid, d_table_direct, d_x);
+                         n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid, d_table_direct, d_x,
+                         (const float2*)dy_dx);
     }
   }
   if (binned) {

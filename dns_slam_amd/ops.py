@@ -140,6 +140,7 @@ def _bound6(bound) -> Optional[C.Array]:
 # form), 2 LDS bins for every level, 3 per-chunk queues for every multi-chunk level; queue_cap 0 = sized by the library
 SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED, SCATTER_QUEUES = 0, 1, 2, 3
 SCATTER_FORM = (SCATTER_AUTO, 0)
+SAVE_DY_DX = True           # encode forward keeps d(grid)/dx when the points need a gradient (False: the backward re-gathers)
 
 
 class _EncodeFn(torch.autograd.Function):
@@ -156,18 +157,22 @@ class _EncodeFn(torch.autograd.Function):
         x = torch.empty(P, 3, device=pts.device, dtype=torch.float32) if b6 is not None else pts
         pe_ptr = ptr(out) if want_pe else None
         grid_ptr = C.c_void_p(out.data_ptr() + 4 * pe_dim) if want_grid else None
+        # the points need a gradient (poses, through pts): keep d(grid features)/dx like tcnn does -- 384 B per
+        # point written here instead of a second 8-corner gather per level in the backward
+        dydx = torch.empty(meta.n_levels * 3 * P * 2, device=pts.device, dtype=torch.float32) \
+            if (want_grid and pts.requires_grad and SAVE_DY_DX) else None
         check(lib.dns_encode_fwd(ptr(pts), b6, P, n_bins, ptr(table) if want_grid else None,
                                  C.byref(meta.c) if want_grid else None,
-                                 ptr(x) if b6 is not None else None, pe_ptr, ld, grid_ptr, ld, stream_ptr()),
+                                 ptr(x) if b6 is not None else None, pe_ptr, ld, grid_ptr, ld, ptr(dydx), stream_ptr()),
               "dns_encode_fwd")
-        ctx.save_for_backward(x, table if want_grid else None)
+        ctx.save_for_backward(x, table if want_grid else None, dydx)
         ctx.meta, ctx.b6, ctx.n_bins, ctx.pe_dim, ctx.g_dim = meta, b6, n_bins, pe_dim, g_dim
         ctx.need_x = pts.requires_grad
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        x, table = ctx.saved_tensors
+        x, table, dydx = ctx.saved_tensors
         P = x.shape[0]
         d_out = d_out.contiguous()
         ld = ctx.pe_dim + ctx.g_dim
@@ -182,7 +187,8 @@ class _EncodeFn(torch.autograd.Function):
                          dtype=torch.float32) if need_t else None
         check(lib.dns_encode_bwd(ptr(x), ctx.b6, P, ctx.n_bins, ptr(table) if ctx.g_dim else None,
                                  C.byref(ctx.meta.c) if ctx.g_dim else None, d_pe, ld, d_grid, ld,
-                                 ptr(d_table), ptr(d_x), ptr(ws), form, cap, stream_ptr()), "dns_encode_bwd")
+                                 ptr(d_table), ptr(d_x), ptr(dydx) if need_x else None, ptr(ws), form, cap, stream_ptr()),
+              "dns_encode_bwd")
         return d_x, d_table, None, None, None, None, None
 
 

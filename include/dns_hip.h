@@ -131,15 +131,19 @@ int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const double* cam,
  * (pts - b0)/(b1 - b0) of slams/mapping.py:608 / slams/tracking.py:190 when bound != NULL.
  * in [P,3]; if bound != NULL [host, 6 doubles] `in` holds world points and x_out [P,3] receives the
  * normalised fp32 coordinates (may be NULL).  pe_out [P, ld_pe] gets 3*n_bins channels (NULL = skip),
- * grid_out [P, ld_grid] gets n_levels*n_features channels (NULL = skip).  table [total_rows, F]. */
+ * grid_out [P, ld_grid] gets n_levels*n_features channels (NULL = skip).  table [total_rows, F].
+ * dy_dx (NULL = skip): [n_levels, 3, P, 2] floats, 8-byte aligned -- d(grid features)/d(normalised coordinate), what tcnn's
+ * kernel_grid keeps when the input needs a gradient; handed to dns_encode_bwd it replaces the second gather of
+ * the 8 corners per level by a streaming dot product. */
 int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_bins,
                    const float* table, const DnsGridMeta* meta,
                    float* x_out, float* pe_out, uint32_t ld_pe, float* grid_out, uint32_t ld_grid,
-                   void* stream);
+                   float* dy_dx, void* stream);
 
 /* Backward.  x [P,3] normalised coordinates.  d_pe / d_grid may be NULL.  d_table (+=) [total_rows,F]
  * (NULL = skip), d_x [P,3] (overwritten; NULL = skip) = dL/dx of the NORMALISED coordinate; if
- * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point).  ws: 8-byte aligned scratch of
+ * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point).  dy_dx: NULL, or what dns_encode_fwd wrote for the
+ * same points and table (then the grid part of d_x needs no table access).  ws: 8-byte aligned scratch of
  * dns_encode_bwd_ws_floats(P, meta, flags, queue_cap) floats for the LDS-binned table scatter (NULL = per-corner atomics).
  * flags selects the form of the table scatter (tcnn kernel_grid_backward): DNS_SCATTER_AUTO = LDS bins in 64-bit fixed
  * point, levels of >= 16 chunks through per-chunk queues; _ATOMIC = one float atomic per corner (tcnn's form);
@@ -154,7 +158,8 @@ int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_
 int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins,
                    const float* table, const DnsGridMeta* meta,
                    const float* d_pe, uint32_t ld_dpe, const float* d_grid, uint32_t ld_dgrid,
-                   float* d_table, float* d_x, float* ws, uint32_t flags, uint32_t queue_cap, void* stream);
+                   float* d_table, float* d_x, const float* dy_dx, float* ws, uint32_t flags, uint32_t queue_cap,
+                   void* stream);
 uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta, uint32_t flags, uint32_t queue_cap);
 
 /* Debug / parity: absolute table rows of the 8 corners of every level, [P, n_levels, 8] uint32. */

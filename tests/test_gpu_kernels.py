@@ -72,6 +72,30 @@ def test_encode_forward_backward(hash_size, res, P, scatter, cap, monkeypatch):
     assert bad.float().mean() < 0.002, f"d x mismatch on {int(bad.sum())} points"
 
 
+def test_encode_input_gradient_from_saved_jacobian_equals_regather(monkeypatch):
+    """dL/d(points) of the hash grid, two forms: the forward keeps d(features)/dx per level (ops.SAVE_DY_DX, tcnn's dy_dx,
+    SURVEY K3) and the backward is a streaming dot product, or the backward gathers the 8 corners again.  Same value up to
+    the order of fp32 operations (1e-5 of the scale), world-coordinate scaling included."""
+    ops = _ops()
+    from dns_slam_amd import synthetic
+    bound = synthetic.load_bound(synthetic.ROOM0_BOUND)
+    pm = ops.GridMeta(16, 592)
+    g = torch.Generator().manual_seed(4)
+    pts = (torch.rand(5000, 3, generator=g) * (bound[:, 1] - bound[:, 0]).float() + bound[:, 0].float()).to(DEV)
+    table = (torch.rand(pm.total_rows * 2, generator=g) * 2 - 1).to(DEV)
+    gy = torch.randn(5000, 80, generator=g).to(DEV)
+    grads = []
+    for keep in (True, False):
+        monkeypatch.setattr(ops, "SAVE_DY_DX", keep)
+        p_ = pts.clone().requires_grad_(True)
+        t_ = table.clone().requires_grad_(True)
+        (ops.encode(p_, t_, pm, bound, 16, True, True) * gy).sum().backward()
+        grads.append((p_.grad.clone(), t_.grad.clone()))
+    assert torch.equal(grads[0][1], grads[1][1]) or float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-5 * float(grads[1][1].abs().max())
+    assert float((grads[0][0] - grads[1][0]).abs().max()) <= 1e-5 * float(grads[1][0].abs().max())
+    assert float(grads[0][0].abs().max()) > 0
+
+
 def test_encode_world_normalisation_fp64():
     """Fused (pts - b0)/(b1 - b0) in fp64 (slams/mapping.py:608): normalised coordinates bit-exact."""
     ops = _ops()
@@ -91,7 +115,7 @@ def test_encode_world_normalisation_fp64():
     x_p = torch.empty(3000, 3, device=DEV)
     import ctypes as C
     b6 = ops._bound6(bound)
-    check(lib.dns_encode_fwd(ptr(pts.to(DEV)), b6, 3000, 16, None, None, ptr(x_p), None, 0, None, 0, stream_ptr()), "x")
+    check(lib.dns_encode_fwd(ptr(pts.to(DEV)), b6, 3000, 16, None, None, ptr(x_p), None, 0, None, 0, None, stream_ptr()), "x")
     assert torch.equal(x_p.cpu(), x_o)
     assert torch.equal(ops.hashgrid_rows(x_p, pm).cpu(), rows_o)
 
