@@ -591,8 +591,15 @@ extern unsigned long long* g_bwd_trace;
     if (a.trace && lane == 0 && tr_tile < 6u)                                                               \
       a.trace[((size_t)(blockIdx.x * 4u + wave) * 8u + tr_tile) * 8u + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
+// run-level stamps: record 7 of the wave, slots 0 run start, 1 images built, 2 tiles done, 3 weight gradients flushed
+#define DNS_TR_RUN(slot)                                                                                    \
+  do {                                                                                                      \
+    if (a.trace && lane == 0 && run0 == bt0)                                                                \
+      a.trace[((size_t)(blockIdx.x * 4u + wave) * 8u + 7u) * 8u + (slot)] = __builtin_readcyclecounter();   \
+  } while (0)
 #else
 #define DNS_TR(slot) do { } while (0)
+#define DNS_TR_RUN(slot) do { } while (0)
 #endif
 
 // per-(n_neurons, n_hidden_layers) launchers: one translation unit each (mlp_split_bwd_*.hip)

@@ -36,5 +36,9 @@ sel = ok.clone(); sel[:, 0] = False
 for k, nme in enumerate(names):
     print(f"  {nme:14s} {float(d[:, :, k][sel].mean()):10.1f}")
 print(f"  tile total     {float((t[:, :, 6] - t[:, :, 0])[sel].mean()):10.1f}")
+run = t[:, 7, :4]
+okr = (run[:, 0] > 0) & (run[:, 3] > 0)
+for k, nme in enumerate(["images (prologue)", "tile loop", "flush + barrier"]):
+    print(f"  run: {nme:18s} {float((run[:, k + 1] - run[:, k])[okr].mean()):10.1f}")
 gap = t[:, 1:6, 0] - t[:, 0:5, 6]
 print(f"  between tiles  {float(gap[ok[:, 1:6] & ok[:, 0:5]].mean()):10.1f}")
