@@ -72,6 +72,8 @@ def kernel_cost(entry, kernel, units, info, wl):
     k = kernel.split("<")[0]
     if k == "encode_fwd_kernel":
         return ("hbm", units * (16 * 8 * 2 * 4 + 12))                     # 128 table cells of 8 B gathered + the point
+    if k == "encode_bwd_kernel":
+        return ("hbm", units * (16 * 3 * 8 + 80 * 4 + 12 + 12))            # the forward's dy_dx + the gradient row + x in, d_x out
     if k == "dgrid_transpose_kernel":
         return ("hbm", units * 2 * 32 * 4)                                 # [P,32] gradient read, level-major copy written
     if k in ("hashgrid_bwd_binned_kernel", "hashgrid_bwd_queue_kernel"):
