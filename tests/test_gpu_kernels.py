@@ -618,3 +618,27 @@ def test_empty_batches_and_argument_errors():
     rc = lib.dns_mlp_fwd(p(x), 80, None, 0, 0, p(w), 80, 33, 64, 2, p(yb), 16, 256, None, None, 0, None, 0, None)
     assert rc != 0 and b"ldy" in lib.dns_last_error()
     torch.cuda.synchronize()                         # nothing faulted
+
+
+def test_kernel_timing_spans():
+    """dns_kernel_timing: every kernel of an armed call is bracketed on its launch stream; names and positive durations come
+    back per launch, attributed to the entry point that launched them (bench.py's per-kernel roofline)."""
+    ops = _ops()
+    pm = ops.GridMeta(16, 592)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(4096, 3, generator=g).to(DEV)
+    table = torch.rand(pm.total_rows * 2, generator=g).to(DEV).requires_grad_(True)
+    ops.timer.arm(kernels=True)
+    y = ops.encode(x, table, pm, None, 16, True, True)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    per_entry = ops.timer.disarm()
+    spans = ops.timer.kernel_spans
+    assert set(per_entry) == {"dns_encode_fwd", "dns_encode_bwd"}
+    names = [(e, k.split("<")[0]) for e, k, ms, units, info in spans]
+    assert ("dns_encode_fwd", "encode_fwd_kernel") in names
+    assert ("dns_encode_bwd", "dgrid_transpose_kernel") in names and ("dns_encode_bwd", "hashgrid_bwd_binned_kernel") in names
+    assert all(ms > 0 for _, _, ms, _, _ in spans) and all(units == 4096 for _, _, _, units, _ in spans)
+    # disarmed: nothing is recorded
+    ops.encode(x, table.detach(), pm, None, 16, True, True)
+    assert ops.timer.records is None
