@@ -195,10 +195,10 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None)
 
 def capture(step, n_warm=3):
     """Capture one full iteration (sampling -> ... -> Adam) into a hipGraph; replays draw fresh rays (graph-safe Philox
-    offsets).  Returns a zero-argument callable returning the (static) loss tensor.  NOT used by the benchmark: on this stack
-    (ROCm 7.0.51831, torch 2.10) a graph replayed after a host-side stream / device synchronisation that directly follows a
-    replay computes garbage or faults -- a pure-PyTorch control graph changes its result too (DESIGN.md section 5,
-    tools/graph_sync_*.py) -- and the timing contract needs exactly that synchronisation between warm-up and timed steps."""
+    offsets).  Returns a zero-argument callable returning the (static) loss tensor.  Valid since the library stopped issuing
+    hipMemsetAsync (memset nodes of a captured graph stop clearing their destination after a host synchronisation on ROCm
+    7.0.51831 -- DESIGN.md section 5), but not the default: replayed on one stream the iteration takes 2.51 ms, with the
+    smoothness branch captured as a parallel branch 2.56, launched eagerly on two streams 2.35."""
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -298,11 +298,11 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="per-step progress on stderr")
     ap.add_argument("--no-render-forward", action="store_true", help="skip the secondary full-image render line")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the iteration from a hipGraph (EXPERIMENT ONLY: results after the warm-up synchronisation are "
-                         "unreliable on this stack, see capture(); the run aborts when the final loss is not finite)")
+                    help="replay the iteration from a hipGraph on one stream (slower than the eager two-stream default, see capture())")
     ap.add_argument("--eager", "--no-graph", dest="eager", action="store_true",
                     help="(default) launch the iteration eagerly, the smoothness branch on a second stream")
     ap.add_argument("--no-overlap", action="store_true", help="eager, but keep the smoothness branch on the main stream")
+    ap.add_argument("--graph-branches", action="store_true", help="with --graph: capture the smoothness branch as a parallel branch")
     ap.add_argument("--union-batch", action="store_true",
                     help="N>1: the N ranks share ONE batch of the configured size (shared-seed draws, rank slices of the rays and "
                          "of the smoothness lattice; strong scaling) instead of one batch per rank (weak scaling, the default)")
@@ -319,9 +319,10 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]
-    # Eager launches on two streams are the measured path.  A hipGraph replay of the iteration (--graph) is not: see capture().
+    # Eager launches on two streams are the measured path; a hipGraph replay of the iteration (--graph) is slower: see capture().
     use_graph = args.graph and not args.eager and ctx.world_size == 1
-    overlap = not use_graph and not args.no_overlap          # the smoothness branch on a second stream
+    # the smoothness branch on a second stream (eager), or -- with --graph-branches -- as a parallel branch of the captured graph
+    overlap = (not use_graph or args.graph_branches) and not args.no_overlap
     union = ctx.union
     cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + (0 if union else ctx.rank), dist_ctx=ctx, overlap=overlap,
                                                   graph=use_graph)

@@ -55,6 +55,11 @@ struct KernelSpan {
     dns::KernelSpan _span(#kern, st);                                   \
     hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);        \
   } while (0)
+// Fill n_words 32-bit words with `value` by a KERNEL.  The library issues no hipMemsetAsync: captured into a hipGraph, memset
+// nodes misbehave on ROCm 7.0.51831 -- after a host synchronisation that follows a replay, later replays no longer clear
+// their destination (found in round 2 with tools/graph_sync_min.py: the sampling step is stable with the per-frame depth
+// maximum supplied, i.e. without its memset, and goes wrong with it).
+int fill_words(void* dst, uint32_t value, size_t n_words, hipStream_t st, const char* who);
 constexpr int MAX_DYN_LDS = 160 * 1024;      // gfx950: 160 KiB of LDS per CU, all of it available to one workgroup
 
 // Device-side copy of the level table, passed by value as a kernel argument.

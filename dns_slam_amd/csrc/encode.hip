@@ -1037,9 +1037,9 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     }
     const size_t lds_bytes = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
     uint32_t* gmax = (uint32_t*)(ws + (size_t)P * lv.n_levels * 2);
-    if (hipMemsetAsync(gmax, 0, 4 * sizeof(uint32_t), st) != hipSuccess) {   // max word, non-finite flag, pad
-      set_error("dns_encode_bwd: memset failed");
-      return DNS_E_LAUNCH;
+    {                                                                          // max word, non-finite flag, pad
+      const int rc = fill_words(gmax, 0u, 4, st, "dns_encode_bwd");
+      if (rc != DNS_OK) return rc;
     }
     DNS_REQUIRE(lv.n_levels <= 16, "dns_encode_bwd: binned scatter supports <= 16 levels");
     DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
@@ -1048,9 +1048,9 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     if (part) {
       uint32_t* qcount = gmax + 4;
       float* queues = reinterpret_cast<float*>(qcount + DNS_MAX_LEVELS * PART_MAX_CHUNKS);
-      if (hipMemsetAsync(qcount, 0, sizeof(uint32_t) * pp.qoff[pp.n], st) != hipSuccess) {
-        set_error("dns_encode_bwd: memset failed");
-        return DNS_E_LAUNCH;
+      {
+        const int rc = fill_words(qcount, 0u, pp.qoff[pp.n], st, "dns_encode_bwd");
+        if (rc != DNS_OK) return rc;
       }
       DNS_LAUNCH(hashgrid_bwd_partition_kernel, dim3((P + PART_THREADS - 1) / PART_THREADS), dim3(PART_THREADS), 0, st, x, P, lv,
                          pp, (const float2*)ws, qcount, queues, d_table);

@@ -57,6 +57,18 @@ int ensure_ready(hipStream_t st, const char* who) {
   return init_current_device();
 }
 
+// ---- fill by kernel (see common.hpp: no memset nodes in captured graphs) ----
+__global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ dst, uint32_t value, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = value;
+}
+int fill_words(void* dst, uint32_t value, size_t n_words, hipStream_t st, const char* who) {
+  if (n_words == 0) return DNS_OK;
+  const size_t want = (n_words + 255) / 256;
+  const uint32_t blocks = (uint32_t)(want < 2048 ? want : 2048);
+  DNS_LAUNCH(fill_words_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(dst), value, n_words);
+  return check_launch(who);
+}
+
 // ---- per-kernel event timing (measurement aid; see KernelSpan in common.hpp) ----
 struct SpanRec {
   const char* name;

@@ -358,9 +358,9 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
                              const float* z, float* sums, void* stream) {
   DNS_REQUIRE(lambdas && sums, "dns_loss_sums: NULL argument");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(float) * (S_TICKET + 1), st) != hipSuccess) {
-    set_error("dns_loss_sums: memset failed");
-    return DNS_E_LAUNCH;
+  {
+    const int rc = fill_words(sums, 0u, S_TICKET + 1, st, "dns_loss_sums");
+    if (rc != DNS_OK) return rc;
   }
   if (N == 0) return DNS_OK;
   DNS_REQUIRE(pred_color && pred_depth && gt_color && gt_depth, "dns_loss_sums: NULL ray tensor");

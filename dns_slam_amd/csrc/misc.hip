@@ -145,9 +145,9 @@ extern "C" int dns_tv_fwd(const float* lat, uint32_t ld, uint32_t nx, uint32_t n
   DNS_REQUIRE(!halo || nx >= 2, "dns_tv_fwd: a slab with a halo plane needs at least one plane of its own");
   DNS_REQUIRE((uint64_t)nx * n * n < (1ull << 31), "dns_tv_fwd: lattice too large");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) {
-    set_error("dns_tv_fwd: memset failed");
-    return DNS_E_LAUNCH;
+  {
+    const int rc = fill_words(out, 0u, 1, st, "dns_tv_fwd");
+    if (rc != DNS_OK) return rc;
   }
   const uint32_t total = nx * n * n;
   const uint32_t blocks = (total + 255) / 256 < 256 ? (total + 255) / 256 : 256;   // each ends in one atomic on ONE word
@@ -177,10 +177,10 @@ extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_
   hipStream_t st = (hipStream_t)stream;
   uint32_t* counts = ws;
   uint32_t* cursor = ws + GROUP_MAX;
-  if (hipMemsetAsync(counts, 0, sizeof(uint32_t) * GROUP_MAX, st) != hipSuccess ||
-      hipMemsetAsync(row_index, 0xFF, sizeof(int32_t) * n_slots, st) != hipSuccess) {   // -1 = padding slot
-    set_error("dns_group_slots: memset failed");
-    return DNS_E_LAUNCH;
+  {
+    int rc = fill_words(counts, 0u, GROUP_MAX, st, "dns_group_slots");
+    if (rc == DNS_OK) rc = fill_words(row_index, 0xFFFFFFFFu, n_slots, st, "dns_group_slots");   // -1 = padding slot
+    if (rc != DNS_OK) return rc;
   }
   if (P) {
     const uint32_t hb = (P + 255) / 256 < 512 ? (P + 255) / 256 : 512;

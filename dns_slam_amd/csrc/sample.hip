@@ -402,9 +402,9 @@ extern "C" int dns_raygen_sample(const int64_t* pix_idx, const float* color, con
   hipStream_t st = (hipStream_t)stream;
   const int wwin = W1 - W0;
   if (!depth_max_given) {
-    if (hipMemsetAsync(depth_max_ws, 0, sizeof(uint32_t) * n_frames, st) != hipSuccess) {
-      set_error("dns_raygen_sample: memset failed");
-      return DNS_E_LAUNCH;
+    {
+      const int rc = fill_words(depth_max_ws, 0u, (size_t)n_frames, st, "dns_raygen_sample");
+      if (rc != DNS_OK) return rc;
     }
     DNS_LAUNCH(depth_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pix_idx, depth, H, W, H0, W0, wwin, n_frames, n_per_frame, depth_max_ws);
   }
@@ -432,9 +432,9 @@ extern "C" int dns_sample_along_rays(const float* gt_depth, const double* far_bb
   DNS_REQUIRE(n_uniform == 0 || t_uniform, "dns_sample_along_rays: t_uniform is NULL");
   if (n_rays <= 0) return DNS_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(depth_max_ws, 0, sizeof(uint32_t), st) != hipSuccess) {
-    set_error("dns_sample_along_rays: memset failed");
-    return DNS_E_LAUNCH;
+  {
+    const int rc = fill_words(depth_max_ws, 0u, 1, st, "dns_sample_along_rays");
+    if (rc != DNS_OK) return rc;
   }
   DNS_LAUNCH(depth_max_flat_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, st, gt_depth, n_rays, depth_max_ws);
   const int S = n_uniform + n_surface;
@@ -455,9 +455,9 @@ extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const d
   const int n = n_frames * n_per_frame;
   if (n <= 0) return DNS_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, sizeof(float) * 12 * n_frames, st) != hipSuccess) {
-    set_error("dns_raygen_bwd: memset failed");
-    return DNS_E_LAUNCH;
+  {
+    const int rc = fill_words(ws, 0u, (size_t)12 * n_frames, st, "dns_raygen_bwd");
+    if (rc != DNS_OK) return rc;
   }
   DNS_LAUNCH(raygen_bwd_reduce_kernel, dim3((n_per_frame + 63) / 64, n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
                      n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);

@@ -562,9 +562,7 @@ def test_tracker_graph_replay_equals_eager_loop():
     """Tracker.track_frame(graph=True) -- one captured iteration replayed n_iters times -- against the eager loop with the
     same device-side draws (static_shapes) from the same seed: the same keep-best loss (1e-5) and camera (2e-5: float atomics in the
     pose-gradient reduction are the only run-to-run difference, amplified over 25 Adam steps; Philox offsets advance per
-    replay exactly as the eager generator does).  Reads happen only after the last
-    replay: on this stack a graph replayed after a host synchronisation that directly follows a replay is not reliable
-    (DESIGN.md section 5), so the tracker never does that."""
+    replay exactly as the eager generator does)."""
     from dns_slam_amd.tracking import Tracker
     cfg, bound, cam, frames, dec, mapper = _setup(64, 2, n_pixels=400)
     cfg["tracking"]["n_pixels"] = 256
@@ -581,6 +579,49 @@ def test_tracker_graph_replay_equals_eager_loop():
         out[graph] = (cam7.detach().cpu().clone(), float(best))
     assert abs(out[True][1] - out[False][1]) <= 1e-5 * abs(out[False][1]), (out[True][1], out[False][1])
     assert float((out[True][0] - out[False][0]).abs().max()) <= 2e-5, (out[True][0], out[False][0])
+
+
+def test_graph_replay_survives_host_synchronisation():
+    """Regression for the round-2 finding: memset nodes of a captured hipGraph stop clearing their
+    destination once a host synchronisation has followed a replay (ROCm 7.0.51831), so the library fills by kernel.  A whole
+    Mapper iteration with FIXED draws and no optimiser step, captured and replayed as 3 x replay + read, then 4 x (3 x
+    replay, torch.cuda.synchronize(), read): every read must give the same loss (float atomics: 1e-6)."""
+    cfg, bound, cam, frames, dec, mapper = _setup(64, 2, n_pixels=400)
+    mapper.static_shapes = True
+    mapper.is_BA = True
+    opt, ql, Tl = mapper.set_optimizer(frames, fused=True)
+    prep = mapper.prepare_frames(frames)
+    torch.manual_seed(5)
+    fixed = (mapper.draw_pixels(prep), mapper.draw_jitter(), torch.rand(3, device=DEV), torch.rand((1, 1, 1, 3), device=DEV))
+    params = [p for g in opt.param_groups for p in g["params"]]
+
+    def fn():
+        for p in params:
+            p.grad = None
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=fixed[0], jitter=fixed[1])
+        loss, _ = mapper.iteration_loss(s, smooth=True, u_offset=fixed[2], u_jitter=fixed[3])
+        loss.backward()
+        return loss + 0.0 * sum(p.grad.abs().sum() for p in params if p.grad is not None)
+
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn()
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        out = fn()
+    vals = []
+    for _ in range(3):
+        gr.replay()
+    vals.append(float(out.detach()))
+    for _ in range(4):
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        vals.append(float(out.detach()))
+    assert all(v == v for v in vals) and max(vals) - min(vals) <= 1e-6 * abs(vals[0]), vals
 
 
 def test_optimize_driver_and_decoder_init():
