@@ -67,7 +67,7 @@ __device__ __forceinline__ float oneblob_edge(uint32_t b, uint32_t n_bins, float
 // pdf terms exactly 0, so a bin's value G(b+1) - G(b) is exactly zero unless one of its edges lies within one bin of
 // c = x n + s n, s in {-1, 0, 1}.  Only the five bins around floor(c) are evaluated (two bins of margin against rounding),
 // in ascending order, with the same expressions as the loop over all n + 1 edges: identical results for finite inputs
-// from 18 instead of 51 kernel evaluations per coordinate.  fn(bin, G(bin + 1) - G(bin)) is called for every bin that may be
+// from 18 + 6 (the last bin, see below) instead of 51 kernel evaluations per coordinate.  fn(bin, G(bin + 1) - G(bin)) is called for every bin that may be
 // non-zero.  (An Inf / NaN in a far bin's upstream gradient no longer turns 0 * Inf into NaN in the backward.)
 template <bool PDF, typename F>
 __device__ __forceinline__ void oneblob_windows(uint32_t n_bins, float n, float xa, F fn) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ void oneblob_windows(uint32_t n_bins, float n, float 
     const float c = xn + (float)w * n;
     if (!(c > -3.0f && c < n + 3.0f)) continue;          // also skips NaN
     const int k = (int)floorf(c);
-    const int j0 = max(k - 2, 0), j1 = min(k + 2, (int)n_bins - 1);
+    const int j0 = max(k - 2, 0), j1 = min(k + 2, (int)n_bins - 2);     // the last bin: below
     if (j0 > j1) continue;
     float left = oneblob_edge<PDF>((uint32_t)j0, n_bins, n, xa);
     for (int j = j0; j <= j1; ++j) {
@@ -86,6 +86,11 @@ __device__ __forceinline__ void oneblob_windows(uint32_t n_bins, float n, float 
       left = right;
     }
   }
+  // The LAST bin is always evaluated: its right edge is DEFINED as edge 0 (+1 for the cdf) -- the wrap of kernel_one_blob --,
+  // so it is non-zero whenever edge 0 lies in ANY image's support (e.g. x = -0.96: edge 0 is inside the image at x + 1 and
+  // bin n-1 sees it although no image is near edge n), and for the cdf even with both edges saturated (x = 3: G = 0
+  // everywhere, bin n-1 = 1).
+  fn(n_bins - 1u, oneblob_edge<PDF>(n_bins, n_bins, n, xa) - oneblob_edge<PDF>(n_bins - 1u, n_bins, n, xa));
 }
 
 __device__ __forceinline__ void load_point(const float* __restrict__ in, const Bound6& bd, bool normalise,

@@ -72,6 +72,30 @@ def test_encode_forward_backward(hash_size, res, P, scatter, cap, monkeypatch):
     assert bad.float().mean() < 0.002, f"d x mismatch on {int(bad.sum())} points"
 
 
+@pytest.mark.parametrize("n_bins", [4, 8, 16])
+def test_oneblob_outside_the_unit_interval_and_small_bin_counts(n_bins):
+    """OneBlob is periodic (tcnn kernel_one_blob adds the images at x -+ 1): points outside [0, 1) -- rays that leave the
+    bound stay in a static-shape batch -- must encode and differentiate like the oracle.  The kernels evaluate the quartic
+    kernel on its support only (five bins around x n and its images) for n_bins >= 8 and walk all edges below that; x exactly
+    on bin edges and far outside (|x| up to 5: every term saturated) included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(4000, 3, generator=g) * 3.0 - 1.0                      # [-1, 2)
+    x[:64, 0] = torch.arange(64) / n_bins - 1.0                            # exactly on edges, both sides of the interval
+    x[64:96] = torch.rand(32, 3, generator=g) * 10.0 - 5.0
+    gy = torch.randn(4000, 3 * n_bins, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = tr.oneblob_forward(xo, n_bins)
+    (yo * gy).sum().backward()
+    xp = x.to(DEV).requires_grad_(True)
+    yp = ops.encode(xp, None, None, None, n_bins, True, False)
+    (yp * gy.to(DEV)).sum().backward()
+    assert_close(yp.cpu(), yo, rtol=1e-6, what=f"oneblob n={n_bins} outside [0,1)")
+    # the derivative is piecewise polynomial with kinks at the kernel's edge: compare where the oracle's own value is stable
+    d = (xp.grad.cpu() - xo.grad).abs()
+    assert float((d > 1e-4 * xo.grad.abs().max()).float().mean()) < 0.002, f"d x mismatch on {int((d > 1e-4 * xo.grad.abs().max()).sum())} entries"
+
+
 def test_encode_input_gradient_from_saved_jacobian_equals_regather(monkeypatch):
     """dL/d(points) of the hash grid, two forms: the forward keeps d(features)/dx per level (ops.SAVE_DY_DX, tcnn's dy_dx,
     SURVEY K3) and the backward is a streaming dot product, or the backward gathers the 8 corners again.  Same value up to
