@@ -118,6 +118,16 @@ def test_encode_input_gradient_from_saved_jacobian_equals_regather(monkeypatch):
     assert torch.equal(grads[0][1], grads[1][1]) or float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-5 * float(grads[1][1].abs().max())
     assert float((grads[0][0] - grads[1][0]).abs().max()) <= 1e-5 * float(grads[1][0].abs().max())
     assert float(grads[0][0].abs().max()) > 0
+    # grid channels only (the untiled kernel instances), normalised coordinates, a point count that is no multiple of 128
+    xs = torch.rand(777, 3, generator=g).to(DEV)
+    gg = torch.randn(777, 32, generator=g).to(DEV)
+    gx = []
+    for keep in (True, False):
+        monkeypatch.setattr(ops, "SAVE_DY_DX", keep)
+        x_ = xs.clone().requires_grad_(True)
+        (ops.encode(x_, table, pm, None, 16, False, True) * gg).sum().backward()
+        gx.append(x_.grad.clone())
+    assert float((gx[0] - gx[1]).abs().max()) <= 1e-5 * float(gx[1].abs().max()) and float(gx[1].abs().max()) > 0
 
 
 def test_encode_world_normalisation_fp64():
