@@ -280,3 +280,34 @@ def test_tv_slabs_sum_to_the_cube_on_gpu():
             grad[a * n * n: hi * n * n] += slab.grad
         assert abs(tot - float(ref)) <= 1e-5 * abs(float(ref))
         assert float((grad - ref_in.grad).abs().max()) <= 1e-5 * float(ref_in.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_union_mode_rank_slice_is_a_slice_of_the_whole_batch():
+    """Single process, a stand-in DistCtx (no collective is needed in union mode once the draws are known to agree): rank r of
+    W in union-batch mode gets exactly rays [a, b) of every frame's list -- samples, the per-sample feature code through the
+    truncation mask, and the tiled routing labels of the WHOLE batch."""
+    from dns_slam_amd.dist import DistCtx, shard_range
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "reference_tiled")
+    S = 32 + 15
+    g = torch.Generator().manual_seed(3)
+    code = (torch.rand(4 * npf, S, 32, generator=g) * 2 - 1).to("cuda:0")
+    whole = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit, features=code)
+    tiled = whole["gt_label"].repeat(1, S).flatten(0, 1).reshape(4 * npf, S)          # the reference's expression (mapping.py:613)
+
+    class Ctx(DistCtx):
+        def allreduce_max(self, t):          # one process: the ranks' draws agree by construction
+            pass
+
+    for W, r in ((2, 1), (3, 0), (4, 3)):
+        ctx = Ctx(W, r, mode="union")
+        assert ctx.union
+        mapper.dist = ctx
+        mapper._union_checked = False
+        part = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit, features=code)
+        a, b = shard_range(npf, W, r)
+        rows = torch.cat([torch.arange(f * npf + a, f * npf + b) for f in range(4)]).to("cuda:0")
+        for key in ("pts", "z_vals", "gt_depth", "gt_color", "rays_d", "features", "valid"):
+            assert torch.equal(part[key], whole[key][rows]), (W, r, key)
+        assert torch.equal(part["point_labels"], tiled[rows].reshape(-1)), (W, r)
+    mapper.dist = None
