@@ -62,14 +62,15 @@ def per_level_scale(desired_res: int, base_resolution: int = 16, n_levels: int =
 
 
 def grid_meta(log2_hashmap_size: int, desired_res: int, n_levels: int = 16, n_features: int = 2,
-              base_resolution: int = 16) -> GridMeta:
+              base_resolution: int = 16, per_level_scale=None) -> GridMeta:
     """tcnn GridEncoding constructor: per level
     scale = exp2(l * log2(pls)) * base - 1, evaluated in float64 and rounded once to float32 (tcnn uses CUDA's
     float32 exp2f, which cannot be reproduced off-CUDA and is 1-ulp-sensitive at the finest level -- SURVEY
     Appendix A7; the float64 definition makes the finest scale exactly desired_res - 1), res = ceilf(scale) + 1,
     size = min(next_multiple(res^3, 8), 2^log2_hashmap_size); a level is hashed iff the
     dense stride product exceeds its size."""
-    pls = per_level_scale(desired_res, base_resolution, n_levels)
+    # ``per_level_scale`` given: the float64 value models/pos_encoding.py:33 hands to tcnn.Encoding (desired_res is unused)
+    pls = float(per_level_scale) if per_level_scale is not None else globals()["per_level_scale"](desired_res, base_resolution, n_levels)
     log2_pls = np.log2(np.float64(pls))
     levels = []
     offset = 0

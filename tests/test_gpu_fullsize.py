@@ -252,7 +252,7 @@ def test_cfg2_fullsize_matches_oracle():
     # Table gradient, element by element.  A cell of a coarse level sums ~500 contributions w*g of either sign, so its fp32
     # error scales with A = sum |w g| of the cell, not with the (cancelled) sum: |a - b| <= 1e-4 |b| + 1e-5 A, where A is the
     # same scatter with |g| upstream (w >= 0), evaluated by the oracle in float64 -- the backward-error bound of an fp32
-    # accumulation whose terms are good to ~1e-5.  Up to 1e-4 of the 1.7 M entries may miss it (ReLU-kink flips of single
+    # accumulation whose terms are good to ~1e-5.  Up to 1e-2 of the 1.7 M entries (outlier_frac below) may miss it (ReLU-kink flips of single
     # points, see tests/util.py); every entry obeys the scale-relative 1e-4.
     taps = [t for t in om.taps.values() if "d_grid" in t]
     leaf = torch.zeros_like(om.table, requires_grad=True)
@@ -313,7 +313,8 @@ def test_cfg2_fullsize_matches_oracle():
             n_fine += 1
     assert n_fine == 8
     # Pose gradients: each is a sum over ~65 000 rays x 64 samples of terms of either sign, through the encoder's input
-    # gradient; both sides carry their own fp32 summation error (tolerances): 2e-4 of the vector's scale
+    # gradient; both sides carry their own fp32 summation error.  Held to 1e-4 (tangential part of d/dq, translation; radial
+    # residue <= 1e-3 |g|): util.assert_pose_grad_close
     for f in range(1, 4):
         assert_pose_grad_close(ql[f], ql[f].grad, qo[f].grad, Tl[f].grad, To[f].grad, what=f"full size frame {f}")
     assert ql[0].grad is None
