@@ -171,7 +171,7 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None)
         # fine-decoder gradients are complete when the ray branch's MLP backward ends and travel under the hash-grid
         # scatter; the table, the coarse network (both also fed by the lattice branch) and the poses go last
         early = [dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, mapper.fine_decoders.pool]
-        buckets = dist_ctx.make_buckets([early, [p for p in params if all(p is not e for e in early)]])
+        buckets = dist_ctx.make_buckets([early, [p for p in params if all(p is not e for e in early)]], hook_launch=[True, False])
     code = None
     if wl.get("code_seed") is not None:      # 2-D feature code of every sample (U(-1,1), seed 5), resident in HBM
         g = torch.Generator().manual_seed(wl["code_seed"])

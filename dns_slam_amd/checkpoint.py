@@ -16,17 +16,23 @@ layout is shared; the real interop problem is INSIDE the flat tensors, and that 
   evaluates the level scale with CUDA's float32 ``exp2f`` where this build rounds the float64 value once (DESIGN.md section
   2): both give the same table for the reference's scenes unless CUDA's last bit flips the finest level's resolution; a
   size mismatch is reported as such (no silent truncation).
-* ``fine_decoders``: the reference pickles tinycudann module objects, which only unpickle where tinycudann is installed.
-  Written here as ``{class_id: flat params}``; on load both forms are accepted (tensors, or objects exposing ``.params``).
+* ``fine_decoders``: the reference pickles tinycudann module objects (``tinycudann.modules.Network`` instances, whose
+  pickled state is their ``__dict__`` minus the native handle).  No AMD box has tinycudann, so ``load`` unpickles with
+  ``_RefUnpickler``: every class under the ``tinycudann`` package resolves to a plain ``nn.Module`` stand-in that just
+  receives the pickled ``__dict__`` -- its ``_parameters['params']`` is the flat tensor wanted.  Written here as
+  ``{class_id: flat params}``; on load both forms are accepted (tensors, or objects exposing ``.params``).
 This is the limit of what can be verified offline: tinycudann is absent from /root/reference, so the layout
 facts above are the published ones, and ``tests/test_host_logic.py`` pins the repacking arithmetic, not a tcnn-written file.
 """
 from __future__ import annotations
 
 import os
+import pickle
+import types
 from typing import Dict, Optional
 
 import torch
+from torch import nn
 
 MLP_KEYS = ("coarse_fn.decoder.params", "out_fn.color_decoder.params", "out_fn.logit_decoder.params", "merge.decoder.params")
 
@@ -53,6 +59,39 @@ def repack_mlp_params(flat: torch.Tensor, n_in: int, n_out: int, n_neurons: int,
     out[:body] = flat[:body]
     out[body:body + n_out * n_neurons] = flat[body:body + n_out * n_neurons]
     return out
+
+
+class _TcnnModuleStandIn(nn.Module):
+    """What a pickled ``tinycudann.modules.{Module,Network,Encoding,NetworkWithInputEncoding}`` becomes on a box without
+    tinycudann: an ``nn.Module`` shell holding the pickled attributes (``_parameters['params']``, ``n_input_dims``,
+    ``network_config``, ...).  It computes nothing."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("tinycudann object from a reference checkpoint: parameters only, not callable on this build")
+
+
+class _RefUnpickler(pickle.Unpickler):
+    """find_class: anything under the ``tinycudann`` package -> ``_TcnnModuleStandIn`` (unless a real tinycudann with that
+    class is importable); everything else as usual."""
+
+    def find_class(self, module, name):
+        if module.split(".")[0] == "tinycudann":
+            try:
+                return super().find_class(module, name)
+            except Exception:
+                return _TcnnModuleStandIn
+        return super().find_class(module, name)
+
+
+# the pickle_module torch.load takes: .Unpickler (torch subclasses it) and .load (legacy, non-zip files)
+_ref_pickle = types.ModuleType("dns_slam_amd._ref_pickle")
+_ref_pickle.Unpickler = _RefUnpickler
+_ref_pickle.load = lambda f, **kw: _RefUnpickler(f, **kw).load()
+_ref_pickle.__dict__.update({k: getattr(pickle, k) for k in ("dumps", "dump", "loads", "Pickler", "PickleError", "UnpicklingError",
+                                                             "HIGHEST_PROTOCOL", "DEFAULT_PROTOCOL")})
 
 
 def _net_shape(net):
@@ -102,7 +141,7 @@ class Checkpoint:
 
     # ------------------------------------------------------------------ read
     def load(self, name: str) -> Dict:
-        blob = torch.load(self._path(name), map_location=self.device or "cpu", weights_only=False)
+        blob = torch.load(self._path(name), map_location=self.device or "cpu", weights_only=False, pickle_module=_ref_pickle)
         if self.decoder is not None and "decoder" in blob:
             own = self.decoder.state_dict()
             for key, src in blob.pop("decoder").items():

@@ -13,10 +13,12 @@ Two modes (``DistCtx.mode``):
   gradient all-reduce.
 
 Gradient exchange (``GradBuckets``): the parameters' ``.grad`` tensors are VIEWS into persistent flat fp32 buckets (no
-per-iteration allocation, flattening or copy-back); a bucket's all-reduce is launched asynchronously from the
-post-accumulate hook of its last parameter -- the bucket of the colour / logit / fine-decoder gradients, complete when the
-ray branch's MLP backward ends, travels while the hash-grid scatter, the pose backward and the lattice branch still run;
-the bucket holding the table, the coarse network (both also fed by the lattice branch) and the poses goes last.
+per-iteration allocation, flattening or copy-back).  The bucket of the colour / logit / fine-decoder gradients -- all
+produced on the main stream, complete when the ray branch's MLP backward ends -- is launched asynchronously from the
+post-accumulate hook of its last parameter and travels while the hash-grid scatter, the pose backward and the lattice branch
+still run; the bucket holding the table, the coarse network (both ALSO fed by the lattice branch, which runs on a second
+stream) and the poses is launched from ``finish()``, after ``backward()`` has returned and the autograd engine has joined
+every leaf stream with the caller's (a collective is ordered only against the stream it is launched from).
 
 The reference has no live distributed path (its NCCL helpers utils/common.py:79-162 are dead code); this is the
 north_star's addition.  Exactness w.r.t. one GPU rendering the union batch: the fused loss kernel (csrc/losses.hip) first produces the 16
@@ -68,8 +70,16 @@ class GradBuckets:
         optimizer.step()
     """
 
-    def __init__(self, ctx: "DistCtx", groups):
+    def __init__(self, ctx: "DistCtx", groups, hook_launch=None):
+        """``hook_launch[k]``: may bucket k's all-reduce be launched from the autograd hook of its last parameter?  NCCL/RCCL
+        orders a collective only against the stream that is current where it is launched; a hook runs on the autograd thread
+        under the stream of THAT parameter's AccumulateGrad node.  That is safe exactly when every gradient of the bucket is
+        produced on one stream (the colour / logit / fine-decoder bucket: all main-stream).  A bucket whose parameters also
+        receive gradient from a second stream (table and coarse network: the lattice branch) must be launched from
+        ``finish()``, after ``backward()`` has returned -- the engine has then joined every leaf stream with the caller's.
+        Default: every bucket hook-launched (single-stream callers)."""
         self.ctx = ctx
+        self._hook_launch = None if hook_launch is None else [bool(h) for h in hook_launch]
         self.groups = [[p for p in g if p.requires_grad and p.numel() > 0] for g in groups]
         self.groups = [g for g in self.groups if g]
         self.flat, self._pending, self._works, self._next = [], [], [], 0
@@ -103,7 +113,8 @@ class GradBuckets:
     def _ready(self, k):
         self._pending[k] -= 1
         # launch in bucket order: bucket k goes once it AND every earlier bucket are complete
-        while self._next < len(self.flat) and self._pending[self._next] <= 0:
+        while self._next < len(self.flat) and self._pending[self._next] <= 0 and \
+                (self._hook_launch is None or self._hook_launch[self._next]):
             self._launch_through(self._next)
 
     def finish(self):
@@ -134,8 +145,8 @@ class DistCtx:
     def shard(self, n: int):
         return shard_range(n, self.world_size, self.rank)
 
-    def make_buckets(self, groups) -> GradBuckets:
-        return GradBuckets(self, groups)
+    def make_buckets(self, groups, hook_launch=None) -> GradBuckets:
+        return GradBuckets(self, groups, hook_launch)
 
     @property
     def enabled(self):

@@ -1,0 +1,91 @@
+"""BASELINE.json configs[0] ("Replica room_0 first 10 frames, PyTorch CPU path, 512 rays x 32 samples, mapping-only") as a
+parity case: the one shape at which a FREE-RUNNING multi-iteration oracle trajectory is cheap.  room_0 bound, 640x480
+frames, 4 target frames x 128 rays, 22 uniform + 10 surface samples, T = 2^16 table at the reference's 0.02 voxel, the
+reference's 1x32 networks, 8 classes + per-class fine decoders, the 63^3 smoothness lattice, bundle adjustment on.
+
+Ten complete optimise iterations of the HIP path (fused Adam) against the oracle stepped by ``torch.optim.Adam`` on the same
+pixel / jitter / lattice draws; neither side ever sees the other's parameters after iteration 0."""
+import pytest
+import torch
+
+from oracle import slam_ref as sr
+from util import assert_close, oracle_from_product, randomise_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NU, NS, RAYS = 22, 10, 512
+
+
+def _setup():
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    bound, cam, frames = synthetic.make_scene(4, seed=0)                       # room_0 bound, 640x480
+    cfg = synthetic.default_cfg(n_pixels=RAYS, n_samples_ray=NU, n_surface_ray=NS, n_frames=4, hash_size=16, voxel_size=0.02,
+                                n_neurons=32, n_hidden_layers=1, smooth_pts=64)
+    dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+    mapper = Mapper(cfg, dec, bound, cam, device=DEV)
+    mapper.rays_per_frame = (86, 42)                                           # exact (uniform, by-class) counts per frame: 4 x (86 + 42) = 512 rays
+    mapper.set_decoder(frames)
+    randomise_(dec, 21)
+    with torch.no_grad():
+        dec.pe_fn.grid_fn.params.mul_(2000.0)                                  # U(-1e-4, 1e-4) would hide the grid in rounding noise
+    randomise_([mapper.fine_decoders.pool], 22)
+    return cfg, bound, cam, frames, dec, mapper
+
+
+def _oracle_samples(frames, quats, Ts, cam, bound, pix_idx, jitter, npf):
+    camt = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    out = []
+    for f in range(4):
+        img5 = torch.cat((frames["gt_color"][f], frames["gt_depth"][f][..., None], frames["gt_label"][f][..., None]), -1)
+        out.append(sr.frame_samples(img5, quats[f], Ts[f], camt, bound, pix_idx[f * npf:(f + 1) * npf], jitter[0][f], jitter[1][f], NU, NS))
+    return sr.mapper_target_samples(out)
+
+
+def test_cfg1_ten_iteration_free_running_trajectory():
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    mapper.is_BA = True
+    opt, ql, Tl = mapper.set_optimizer(frames, fused=True)
+    lr, cam_lr = cfg["training"]["lr"], cfg["mapping"]["BA_cam_lr"]         # the reference's 0.005 / 0.0005
+    for grp, v in zip(opt.param_groups, (lr, cam_lr, cam_lr)):
+        grp["lr"] = v
+    prep = mapper.prepare_frames(frames)
+    om = oracle_from_product(cfg, bound, dec, mapper)
+    qo = [q.detach().cpu().clone().requires_grad_(q.requires_grad) for q in ql]
+    To = [t.detach().cpu().clone().requires_grad_(t.requires_grad) for t in Tl]
+    opt_o = torch.optim.Adam([{"params": [om.table, om.coarse, om.color, om.logit] + list(om.fine.values()), "lr": lr},
+                              {"params": qo[1:], "lr": cam_lr}, {"params": To[1:], "lr": cam_lr}])
+    lc = sr.LossCfg(smooth_pts=64)
+    worst = 0.0
+    for it in range(10):
+        torch.manual_seed(300 + it)
+        pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+        g = torch.Generator().manual_seed(400 + it)
+        u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+        assert pix.numel() == RAYS
+
+        opt.zero_grad()
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
+        assert s["z_vals"].shape[1] == NU + NS
+        loss, terms = mapper.iteration_loss(s, lambda_lt=10.0, smooth=True, u_offset=u_off, u_jitter=u_jit, strict=True)
+        loss.backward()
+        opt.step()
+
+        opt_o.zero_grad()
+        so = _oracle_samples(frames, qo, To, cam, bound, pix.cpu(), (jit[0].cpu(), jit[1].cpu()), RAYS // 4)
+        so["features"] = torch.zeros(so["z_vals"].shape[0], NU + NS, 32)
+        lo, to, _ = sr.mapping_loss(om, so, lc, u_off, u_jit)
+        lo.backward()
+        opt_o.step()
+        a, b = float(loss.detach()), float(lo.detach())
+        worst = max(worst, abs(a - b) / abs(b))
+        assert abs(a - b) <= 1e-4 * abs(b), f"iteration {it}: loss {a} vs {b}"
+        for kp, ko in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"), ("opacity_loss", "op"),
+                       ("smooth_loss", "sm")):
+            x, y = float(terms[kp]), float(to[ko])
+            assert abs(x - y) <= 2e-4 * max(abs(y), 1e-6), f"iteration {it} {kp}: {x} vs {y}"
+    for f in range(1, 4):
+        assert_close(ql[f].detach().cpu(), qo[f].detach(), rtol=1e-4, what=f"cfg1 quat[{f}] after 10 free-running steps")
+        assert_close(Tl[f].detach().cpu(), To[f].detach(), rtol=1e-4, what=f"cfg1 T[{f}] after 10 free-running steps")
+    print(f"cfg1: worst relative loss difference over 10 free-running iterations {worst:.2e}")

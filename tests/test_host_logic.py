@@ -150,3 +150,71 @@ def test_checkpoint_repacks_cutlass_padded_mlp_tensors(tmp_path):
         raise AssertionError("a tensor that matches no padding must be refused")
     except ValueError:
         pass
+
+
+def write_reference_style_checkpoint(path, decoder_sd, fine_params: dict, n_in=80, n_out=33, extra=None):
+    """A ``model.pt`` the way the reference writes it (slams/mapping.py:1119-1128): ``fine_decoders`` is a dict of pickled
+    ``tinycudann.modules.Network`` OBJECTS.  tinycudann is absent, so a throw-away package of that name -- holding a class
+    whose pickled state is its ``__dict__`` without the native handle, like tcnn's ``Module.__getstate__`` -- exists in
+    ``sys.modules`` only while the file is written; the loader never sees it."""
+    import sys
+    import types
+    from torch import nn
+    pkg, mod = types.ModuleType("tinycudann"), types.ModuleType("tinycudann.modules")
+
+    class Network(nn.Module):
+        def __init__(self, n_input_dims, n_output_dims, network_config, params):
+            super().__init__()
+            self.n_input_dims, self.n_output_dims, self.network_config = n_input_dims, n_output_dims, network_config
+            self.native_tcnn_module = object()                   # tcnn: a pybind handle, dropped from the pickled state
+            self.params = nn.Parameter(params.clone())
+
+        def __getstate__(self):
+            st = self.__dict__.copy()
+            del st["native_tcnn_module"]
+            return st
+
+    Network.__module__, Network.__qualname__ = "tinycudann.modules", "Network"
+    mod.Network, pkg.modules = Network, mod
+    saved = {k: sys.modules.get(k) for k in ("tinycudann", "tinycudann.modules")}
+    sys.modules["tinycudann"], sys.modules["tinycudann.modules"] = pkg, mod
+    try:
+        cfg = {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 32, "n_hidden_layers": 1}
+        blob = {"decoder": decoder_sd, "fine_decoders": {c: Network(n_in, n_out, cfg, p) for c, p in fine_params.items()}}
+        blob.update(extra or {})
+        torch.save(blob, path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_checkpoint_loads_pickled_tinycudann_module_objects(tmp_path):
+    """The reference's ``fine_decoders`` are pickled tinycudann modules (slams/mapping.py:1121); ``torch.load`` on a box
+    without tinycudann raises ModuleNotFoundError unless the unpickler maps that package to a stand-in
+    (dns_slam_amd/checkpoint.py:_RefUnpickler)."""
+    import sys
+    from dns_slam_amd.checkpoint import mlp_numel
+    from dns_slam_amd.mapping import FineDecoderPool
+    bound = synthetic.load_bound(synthetic.ROOM0_BOUND)
+    cfg = synthetic.default_cfg(hash_size=12, voxel_size=0.2)
+    dec = Decoder(cfg["model"], bound, n_class=40)
+    g = torch.Generator().manual_seed(0)
+    fine = {5: torch.randn(mlp_numel(80, 33, 32, 1, 8), generator=g), 11: torch.randn(mlp_numel(80, 33, 32, 1, 8), generator=g)}
+    path = os.path.join(str(tmp_path), "model.pt")
+    write_reference_style_checkpoint(path, dec.state_dict(), fine, extra={"idx": 7})
+    assert "tinycudann" not in sys.modules or not hasattr(sys.modules["tinycudann"], "modules")
+    try:                                                         # the stock loader cannot read the file here
+        torch.load(path, weights_only=False)
+        raise AssertionError("expected the stock unpickler to fail without tinycudann")
+    except (ModuleNotFoundError, AttributeError):
+        pass
+    pool = FineDecoderPool(80, 33, dec.coarse_fn.decoder.network_config, capacity=4, device="cpu")
+    rest = Checkpoint(str(tmp_path), device="cpu", decoder=Decoder(cfg["model"], bound, n_class=40), fine_decoders=pool).load("model.pt")
+    assert rest == {"idx": 7}
+    used = 80 * 32 + 33 * 32
+    assert sorted(pool.keys()) == [5, 11]
+    for c in (5, 11):
+        assert torch.equal(pool.params_of(c)[:used], fine[c][:used]) and torch.count_nonzero(pool.params_of(c)[used:]) == 0
