@@ -8,7 +8,7 @@ n_in, n_out, acc = (int(v) for v in (sys.argv[1:4] + ["80", "33", "0"][len(sys.a
 P, nn, nl = 262144, 64, 2
 dev = "cuda"
 numel = nn * n_in + nn * nn + ((n_out + 15) // 16 * 16) * nn
-w = (torch.randn(numel, device=dev) * 0.1).requires_grad_(True)
+w = (torch.randn(numel, device=dev) * 0.1).requires_grad_(os.environ.get("DNS_NO_DW") is None)
 x = torch.randn(P, n_in, device=dev, requires_grad=True)
 gy = torch.randn(P, n_out, device=dev)
 trace = torch.zeros(256 * 4 * 8 * 8, device=dev, dtype=torch.int64)
@@ -30,7 +30,7 @@ raw.dns_debug_bwd_trace(None)
 t = trace.cpu().reshape(256 * 4, 8, 8).double()
 ok = (t[:, :, 0] > 0) & (t[:, :, 6] > 0)
 d = t[:, :, 1:7] - t[:, :, 0:6]
-names = ["A recompute", "B dH_last", "C dW_out", "D dH1 + dW_h", "E dh1 store", "E dX tiles"]
+names = ["A recompute", "B dH_last", "C dW_out", "D dH1 + dW_h", "E dW_in", "E dX tiles"]
 print(f"{n_in}->{nn}x{nl}->{n_out}: cycles (s_memtime, 100 MHz ticks x ?) per phase, mean over {int(ok.sum())} tiles (tiles 1..5 of each wave)")
 sel = ok.clone(); sel[:, 0] = False
 for k, nme in enumerate(names):
