@@ -146,12 +146,17 @@ __device__ __forceinline__ uint32_t w_off(uint32_t row, uint32_t ch, uint32_t cs
 
 enum KOrder { K_NAT = 0, K_CHAIN = 1 };
 
-// A = M: lane (r, h) element j = M[32 t + r][k(s, h, j)]
+// A = M: lane (r, h) element j = M[32 t + r][k(s, h, j)].  K_CHAIN_PERM: the image was built with w_image_build<true>, which
+// swaps the two middle 4-column blocks of every 16 columns (column 16 s + 8 a + 4 b + e is stored at 16 s + 8 b + 4 a + e), so
+// that the CHAIN order's eight elements of a lane half are ONE 16-byte chunk: a ds_read_b128 like the NAT read, conflict-free.
+// Reading the CHAIN order from an unpermuted image takes two 8-byte reads per plane, which hipcc merges into
+// ds_read2st64_b64 (banked mod 32, 16-lane groups): 4-way conflicts -- measured as an LDS-bound forward kernel (round 3).
+enum { K_CHAIN_PERM = 2 };
 template <int ORDER>
 __device__ __forceinline__ Frag3 w_row_frag(const unsigned char* lds, const WImg& w, uint32_t t, uint32_t s, uint32_t lane) {
   Frag3 f;
   const uint32_t row = 32u * t + (lane & 31u), h = lane >> 5;
-  if (ORDER == K_NAT) {
+  if (ORDER == K_NAT || ORDER == K_CHAIN_PERM) {
     const uint32_t o = w.base + w_off(row, 2u * s + h, w.cs);
     f.h = as_bf16x8(lds_read16(lds, o));
     f.m = as_bf16x8(lds_read16(lds, o + w.plane));
@@ -210,19 +215,33 @@ __device__ __forceinline__ Quad3 split4(float4 v) {
   return q;
 }
 
-// the whole workgroup writes M [R x C] (C % 4 == 0, rows beyond R / columns beyond C stay zero) into its image
+// the whole workgroup writes M [R x C] (C % 4 == 0, rows beyond R / columns beyond C stay zero) into its image;
+// PERM: columns stored in the chain-permuted order (see w_row_frag).  MAXQ >= ceil(R C / 4 / blockDim.x): every thread's
+// float4 loads are issued FIRST and split afterwards -- as a plain loop (load, wait, split, store per iteration) the prologue
+// paid one L2 round trip per quad, ~13 us of a 60 us launch whose waves only run four tiles each.
+template <int MAXQ, bool PERM = false>
 __device__ __forceinline__ void w_image_build(unsigned char* lds, const WImg& w, const float* __restrict__ M, uint32_t R, uint32_t C) {
   const uint32_t qpr = C >> 2, nq = R * qpr;
   const bool vec = (((uintptr_t)M) & 15u) == 0;
-  for (uint32_t e = threadIdx.x; e < nq; e += blockDim.x) {
-    const uint32_t row = e / qpr, c4 = (e - row * qpr) * 4u;
+  float4 v[MAXQ];
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const uint32_t e = min(threadIdx.x + k * blockDim.x, nq - 1u);
     const float* src = M + (size_t)e * 4u;
-    const float4 v = vec ? *reinterpret_cast<const float4*>(src) : make_float4(src[0], src[1], src[2], src[3]);
-    const Quad3 q = split4(v);
-    const uint32_t o = w.base + w_off(row, c4 >> 3, w.cs) + 2u * (c4 & 7u);
-    lds_write8(lds, o, q.h);
-    lds_write8(lds, o + w.plane, q.m);
-    lds_write8(lds, o + 2u * w.plane, q.l);
+    v[k] = vec ? *reinterpret_cast<const float4*>(src) : make_float4(src[0], src[1], src[2], src[3]);
+  }
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const uint32_t e = threadIdx.x + k * blockDim.x;
+    if (e < nq) {
+      const uint32_t row = e / qpr, c4 = (e - row * qpr) * 4u;
+      const Quad3 q = split4(v[k]);
+      const uint32_t cp = PERM ? ((c4 & ~15u) | ((c4 & 4u) << 1) | ((c4 & 8u) >> 1)) : c4;
+      const uint32_t o = w.base + w_off(row, cp >> 3, w.cs) + 2u * (cp & 7u);
+      lds_write8(lds, o, q.h);
+      lds_write8(lds, o + w.plane, q.m);
+      lds_write8(lds, o + 2u * w.plane, q.l);
+    }
   }
 }
 
@@ -473,41 +492,26 @@ __device__ __forceinline__ void flush_tile(const f32x16& a, float* __restrict__ 
   __syncthreads();
 }
 
-struct BwdArgs {
-  const float* x;
-  uint32_t ldx;
-  XSeg seg;
-  const float* dy;
-  uint32_t lddy;
-  const float* params;
-  uint32_t n_in, n_out;
-  float* dx;
-  uint32_t lddx;
-  DxSeg dseg;
-  float* d_params;
-  uint32_t n_slots;
-  const int32_t* row_index;
-  const int32_t* tile_group;
-  uint32_t param_stride, tiles_per_block;
-#ifdef DNS_BWD_TRACE
-  unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
-#endif
-};
-#ifdef DNS_BWD_TRACE
-#define M3_TR(slot)                                                                                         \
-  do {                                                                                                      \
-    if (a.trace && lane == 0 && tr_tile < 6u)                                                               \
-      a.trace[((size_t)(blockIdx.x * 4u + wave) * 8u + tr_tile) * 8u + (slot)] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define M3_TR(slot) do { } while (0)
-#endif
-
-// per-(n_neurons, n_hidden_layers) launchers: one translation unit each (mlp3_bwd_*.hip)
-int launch_bwd3_32_1(const BwdArgs& a, uint32_t blocks, hipStream_t st);
-int launch_bwd3_32_2(const BwdArgs& a, uint32_t blocks, hipStream_t st);
-int launch_bwd3_64_1(const BwdArgs& a, uint32_t blocks, hipStream_t st);
-int launch_bwd3_64_2(const BwdArgs& a, uint32_t blocks, hipStream_t st);
+// a: 32 output features x 32 points -> y[row][col0 + f], f < ncols (any ldy / alignment: dword stores with lane = feature,
+// two rows x 128 contiguous bytes per instruction), rows through the tile's row table
+__device__ __forceinline__ void store_tile_rows_plain(float* __restrict__ y, uint32_t ldy, uint32_t col0, uint32_t ncols,
+                                                      const int* __restrict__ rows_lds, const f32x16& a,
+                                                      float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t f = lane & 31u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t r = (lane >> 5) + 2 * i;
+    const int row = rows_lds[r];
+    const float v = stg[r * STG_LD + f];
+    if (row >= 0 && f < ncols) y[(size_t)row * ldy + col0 + f] = v;
+  }
+  wave_lds_fence();
+}
 
 }  // namespace m3
 }  // namespace dns

@@ -288,18 +288,21 @@ struct XChunk {                              // 32 columns of the tile's 32 rows
   float4 v[4];                               // float4 j of rows r8, r8+8, r8+16, r8+24
 };
 
+// Unconditional loads (no exec-masked branches: the four requests leave back to back): a padding slot reads row 0 and a column
+// past n_in reads the row's last four -- finite stand-ins that cannot reach any result: a padding slot's outputs are not
+// stored and its dY is zero (hence every gradient it feeds), the weight images' columns past n_in are zero, and a duplicate of
+// a valid column cannot raise the row maximum the point's scale comes from.
 __device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restrict__ x, uint32_t ldx, const XSeg& seg,
                                               uint32_t n_in, const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
-  const uint32_t col = 32u * c + 4u * (lane & 7u);
+  const uint32_t col = min(32u * c + 4u * (lane & 7u), n_in - 4u);
   const bool second = seg.x2 != nullptr && col >= seg.n_in1;
   const float* base = second ? seg.x2 + (col - seg.n_in1) : x + col;
   const uint32_t ld = second ? seg.ldx2 : ldx;
+  int rows[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = rows_lds[(lane >> 3) + 8 * i];
-    xc.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row >= 0 && col < n_in) xc.v[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld);
-  }
+  for (int i = 0; i < 4; ++i) rows[i] = max(rows_lds[(lane >> 3) + 8 * i], 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xc.v[i] = *reinterpret_cast<const float4*>(base + (size_t)(uint32_t)rows[i] * ld);
 }
 
 // max |x| of every row of the tile over all its chunks (still in the load layout: 8 lanes share a row) -> rmax[32] in LDS.
@@ -441,7 +444,10 @@ __device__ __forceinline__ void dx_old_issue(DxOld& o, const float* __restrict__
   const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
   const uint32_t col = col0 + c4;
   const bool second = seg.dx2 != nullptr && col >= n_in1;
-  const bool acc = second ? seg.acc2 != 0 : seg.acc1 != 0;
+  // (selecting the two FIELDS by a lane condition makes hipcc index the kernel-argument segment with a vector load, whose
+  //  s_waitcnt vmcnt(0) then drains every request the wave has in flight -- found in the ISA in round 3)
+  const bool a1 = seg.acc1 != 0, a2 = seg.acc2 != 0;
+  const bool acc = (second && a2) || (!second && a1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = rows_lds[rr + 8 * i];
@@ -503,7 +509,8 @@ __device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ d
       const uint32_t col = col0 + f;
       const bool second = seg.dx2 != nullptr && col >= n_in1;
       float* p = second ? seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1) : dst1 + (size_t)row * ld1 + col;
-      if (second ? seg.acc2 : seg.acc1) v += *p;
+      const bool a1 = seg.acc1 != 0, a2 = seg.acc2 != 0;
+      if ((second && a2) || (!second && a1)) v += *p;
       *p = v;
     }
   }
