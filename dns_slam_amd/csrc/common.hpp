@@ -96,14 +96,4 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, hipStream_t st);
 
-// three-part-bf16 forward kernels (mlp3_fwd_{32,64}.hip): the fp32-grade forward
-namespace m3 {
-int launch_fwd3_32(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* params, uint32_t n_in,
-                   uint32_t n_out, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots, const int32_t* row_index,
-                   const int32_t* tile_group, uint32_t param_stride, hipStream_t st);
-int launch_fwd3_64(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* params, uint32_t n_in,
-                   uint32_t n_out, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots, const int32_t* row_index,
-                   const int32_t* tile_group, uint32_t param_stride, hipStream_t st);
-}  // namespace m3
-
 }  // namespace dns

@@ -47,13 +47,6 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   }
   const int rc = ensure_ready((hipStream_t)stream, "dns_mlp_fwd");
   if (rc != DNS_OK) return rc;
-  if (!(flags & DNS_MLP_FP16) && !h_save) {   // fp32-grade arithmetic: three-part bf16 operands (mlp3.hpp)
-    if (n_neurons == 32)
-      return m3::launch_fwd3_32(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_hidden_layers, y, ldy, n_slots, row_index, tile_group,
-                                param_stride, (hipStream_t)stream);
-    return m3::launch_fwd3_64(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_hidden_layers, y, ldy, n_slots, row_index, tile_group,
-                              param_stride, (hipStream_t)stream);
-  }
   return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
                               row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, (hipStream_t)stream);
 }
