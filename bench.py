@@ -366,6 +366,20 @@ def main():
     if final_loss is not None and not math.isfinite(final_loss):
         raise RuntimeError(f"non-finite loss after the timed steps ({final_loss}): the measurement is void")
     elapsed = ctx.max_over_ranks(elapsed, device)
+    # spread: the same K steps once more with an event pair around every step (outside the timed region; the events sit on the
+    # main stream, which every step's side-stream work joins before the optimiser step)
+    spread = None
+    if ctx.world_size == 1:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for e0, e1 in evs:
+            e0.record()
+            run()
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        spread = {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1], "p90": ts[int(0.9 * (len(ts) - 1))],
+                  "note": "per-step event spans of a second pass of the same K steps (enqueue-ahead makes a single step's span "
+                          "shorter than ms_per_step when the host runs ahead of the GPU)"}
     # per-kernel durations for the roofline: the same K steps launched eagerly with an event pair around every
     # C-ABI call (a replayed graph cannot be bracketed per kernel; kernels and shapes are identical)
     kernel_times, spans = {}, []
@@ -421,7 +435,7 @@ def main():
                 "traffic = sum of the PMC FETCH+WRITE bytes of every kernel of one iteration (profiles/pmc_traffic.json)"}
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "step_ms_spread": spread, "higher_is_better": True,
         "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
                   "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "final_loss": final_loss,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,

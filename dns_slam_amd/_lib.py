@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class DnsGridMeta(C.Structure):
@@ -62,6 +62,8 @@ SIGNATURES = {
     "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P]),
     "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P, _P]),
     "dns_group_slots": (C.c_int, [_P, _U, _U, _U, _U, _P, _P, _P, _P]),
+    "dns_group_scatter": (C.c_int, [_P, _U, _U, _P, _U, _P, _P]),
+    "dns_device_error": (C.c_int, [C.c_int]),
     "dns_adam_step": (C.c_int, [C.POINTER(DnsAdamTensor), _U, C.c_float, C.c_float, C.c_float, _P, _P]),
     "dns_composite_fwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P]),
     "dns_composite_bwd": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -10,13 +10,19 @@ namespace dns {
 
 void set_error(const char* fmt, ...);
 
+// Sticky per-device error word in pinned host memory (host.cpp): kernels that consume device counters set a bit instead of
+// storing out of bounds; poll_device_error() is a plain host read, no synchronisation.
+constexpr uint32_t DNS_DEVERR_GROUP_CURSOR = 1u;
+uint32_t* device_error_word();               // device-visible pointer for kernel arguments (NULL before dns_init)
+int poll_device_error(const char* what);     // DNS_OK, or DNS_E_LAUNCH + message while the word is non-zero
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return DNS_E_LAUNCH;
   }
-  return DNS_OK;
+  return poll_device_error(what);
 }
 
 #define DNS_REQUIRE(cond, ...)                 \

@@ -1046,7 +1046,6 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       const int rc = fill_words(gmax, 0u, 4, st, "dns_encode_bwd");
       if (rc != DNS_OK) return rc;
     }
-    DNS_REQUIRE(lv.n_levels <= 16, "dns_encode_bwd: binned scatter supports <= 16 levels");
     DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
     if (jobs)
       DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);

@@ -26,6 +26,27 @@ AttrRegistrar::AttrRegistrar(AttrInitFn fn) {
   if (g_n_attr_fns < 16) g_attr_fns[g_n_attr_fns++] = fn;
 }
 
+// ---- sticky device-side error word (see common.hpp / dns_hip.h) ----
+static uint32_t* g_err_host[64];             // pinned + mapped, one word per device, allocated by init_current_device()
+static uint32_t* g_err_dev[64];
+
+uint32_t* device_error_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return g_err_dev[dev];
+}
+
+int poll_device_error(const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_err_host[dev]) return DNS_OK;
+  const uint32_t w = *reinterpret_cast<volatile uint32_t*>(g_err_host[dev]);
+  if (!w) return DNS_OK;
+  set_error("%s: a kernel of this library hit a device-side capacity check (error word 0x%x%s); results since then are "
+            "incomplete -- dns_device_error(1) clears the word", what, w,
+            (w & DNS_DEVERR_GROUP_CURSOR) ? ": group cursor past n_slots in dns_group_slots / dns_group_scatter" : "");
+  return DNS_E_LAUNCH;
+}
+
 static int init_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
@@ -38,6 +59,18 @@ static int init_current_device() {
   for (int i = 0; i < g_n_attr_fns; ++i) {
     const int rc = g_attr_fns[i]();
     if (rc != DNS_OK) return rc;
+  }
+  if (!g_err_host[dev]) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      set_error("dns_init: cannot allocate the pinned error word: %s", hipGetErrorString(hipGetLastError()));
+      return DNS_E_LAUNCH;
+    }
+    *reinterpret_cast<volatile uint32_t*>(h) = 0u;
+    g_err_host[dev] = reinterpret_cast<uint32_t*>(h);
+    g_err_dev[dev] = reinterpret_cast<uint32_t*>(d);
   }
   g_ready_devices.fetch_or(1ull << dev, std::memory_order_release);
   return DNS_OK;
@@ -87,8 +120,12 @@ KernelSpan::KernelSpan(const char* name_, hipStream_t st_) : name(name_), st(st_
 }
 KernelSpan::~KernelSpan() {
   if (!on) return;
-  hipEvent_t e1;
-  if (hipEventCreate(&e1) != hipSuccess || hipEventRecord(e1, st) != hipSuccess) return;
+  hipEvent_t e1 = nullptr;
+  if (hipEventCreate(&e1) != hipSuccess || hipEventRecord(e1, st) != hipSuccess) {
+    (void)hipEventDestroy(e0);                     // no span without both ends: nothing is kept, nothing leaks
+    if (e1) (void)hipEventDestroy(e1);
+    return;
+  }
   std::lock_guard<std::mutex> lock(g_span_mutex);
   g_spans.push_back({name, e0, e1});
 }
@@ -121,6 +158,14 @@ extern "C" int dns_kernel_timing_get(int i, char* name, int name_cap, float* ms)
 }
 
 extern "C" int dns_init(void) { return dns::init_current_device(); }
+extern "C" int dns_device_error(int clear) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !dns::g_err_host[dev]) return 0;
+  volatile uint32_t* w = reinterpret_cast<volatile uint32_t*>(dns::g_err_host[dev]);
+  const uint32_t v = *w;
+  if (clear) *w = 0u;
+  return (int)v;
+}
 extern "C" int dns_abi_version(void) { return DNS_ABI_VERSION; }
 extern "C" const char* dns_last_error(void) { return dns::g_err; }
 

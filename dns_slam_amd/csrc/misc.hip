@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void group_scan_kernel(const uint32_t* __restr
 }
 
 __global__ __launch_bounds__(256) void group_scatter_kernel(const int64_t* __restrict__ slot, uint32_t P, uint32_t G,
-                                                            uint32_t* __restrict__ cursor, int32_t* __restrict__ row_index) {
+                                                            uint32_t* __restrict__ cursor, int32_t* __restrict__ row_index,
+                                                            uint32_t n_slots, uint32_t* __restrict__ err) {
   // workgroup-aggregated cursors: LDS integer atomics rank the points of the workgroup inside each group, one global
   // atomic per (workgroup, group) reserves the range
   __shared__ uint32_t cnt[GROUP_MAX];
@@ -132,7 +133,13 @@ __global__ __launch_bounds__(256) void group_scatter_kernel(const int64_t* __res
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) base[i] = cnt[i] ? atomicAdd(cursor + i, cnt[i]) : 0u;
   __syncthreads();
-  if (s >= 0) row_index[base[(uint32_t)s] + rank] = (int32_t)p;
+  if (s >= 0) {
+    // The cursors are DEVICE state (written by group_scan_kernel, advanced by atomics): a stale or corrupted one must end as
+    // an error code, not as a store past the table (round 2's memory-access fault was exactly such a consumer)
+    const uint32_t at = base[(uint32_t)s] + rank;
+    if (at < n_slots) row_index[at] = (int32_t)p;
+    else if (err) atomicOr(err, DNS_DEVERR_GROUP_CURSOR);
+  }
 }
 
 }  // namespace dns
@@ -178,7 +185,8 @@ extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_
   uint32_t* counts = ws;
   uint32_t* cursor = ws + GROUP_MAX;
   {
-    int rc = fill_words(counts, 0u, GROUP_MAX, st, "dns_group_slots");
+    int rc = ensure_ready(st, "dns_group_slots");
+    if (rc == DNS_OK) rc = fill_words(counts, 0u, GROUP_MAX, st, "dns_group_slots");
     if (rc == DNS_OK) rc = fill_words(row_index, 0xFFFFFFFFu, n_slots, st, "dns_group_slots");   // -1 = padding slot
     if (rc != DNS_OK) return rc;
   }
@@ -187,6 +195,21 @@ extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_
     DNS_LAUNCH(group_hist_kernel, dim3(hb), dim3(256), 0, st, slot_of_point, P, n_groups, counts);
   }
   DNS_LAUNCH(group_scan_kernel, dim3(1), dim3(256), 0, st, counts, n_groups, min_count, n_slots / 128u, cursor, tile_group);
-  if (P) DNS_LAUNCH(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index);
+  if (P)
+    DNS_LAUNCH(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index, n_slots,
+               device_error_word());
   return check_launch("dns_group_slots");
+}
+
+extern "C" int dns_group_scatter(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t* cursor, uint32_t n_slots,
+                                 int32_t* row_index, void* stream) {
+  DNS_REQUIRE(slot_of_point && cursor && row_index, "dns_group_scatter: NULL argument");
+  DNS_REQUIRE(n_groups >= 1 && n_groups <= GROUP_MAX, "dns_group_scatter: n_groups %u out of range [1,%u]", n_groups, GROUP_MAX);
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = ensure_ready(st, "dns_group_scatter");
+  if (rc != DNS_OK) return rc;
+  if (P)
+    DNS_LAUNCH(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index, n_slots,
+               device_error_word());
+  return check_launch("dns_group_scatter");
 }

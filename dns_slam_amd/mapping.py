@@ -121,6 +121,7 @@ class Mapper:
         self.is_BA = True
         self.keyframe_dict, self.keyframe_list = [], []  # filled by the caller's frame loop (reference Mapper.run :975,1085)
         self.keyframe_selector = None                    # optional host-side keyframe choice (set_target_refer_frames)
+        self.mapping_mode = "global"                     # 'global' | 'overlap' (slams/mapping.py:350-356; run() alternates them)
         self.encoder = None                              # frozen image stem (dns_slam_amd.encoder.ResNet) or None
         self.dist = None                                 # dns_slam_amd.dist.DistCtx for ray-batch data parallelism
         self.static_shapes = False                       # True: sync-free iteration (hipGraph-capturable)
@@ -134,6 +135,9 @@ class Mapper:
         # host -> device copy (tensor.to(device)) is not capturable -- issued by the first iteration inside a hipGraph
         # capture it invalidates the capture (round-1 segfault in capture_end, DESIGN.md section 4 "stream capture").
         if str(device) != "cpu":
+            from ._lib import ensure_init
+            ensure_init()        # kernel attributes + the pinned error word NOW: the C side's lazy first-use init is refused
+            #                      inside a stream capture, and PyTorch captures in global mode (any stream of the device)
             self._jitter_consts()
             self._ensure_lattice(tr.get("smooth_pts", 64), 0.1, 0.05)
 
@@ -766,14 +770,50 @@ class Mapper:
             optimizer.step()
         return loss
 
+    # ------------------------------------------------------------------ slams/mapping.py:171-236
+    def keyframe_selection_overlap(self, gt_color, gt_depth, c2w, keyframe_dict, k, N_samples=16, pixels=100, th=0.0):
+        """The reference's overlap test: ``pixels`` rays of the current frame (get_samples: one uniform draw on the device
+        generator, :199), ``N_samples`` points per ray between 0.8 d and d + 0.5, projected into every keyframe's estimated
+        camera (x flipped, K, :223-226); a keyframe's score is the fraction of the points that land more than 10 px inside
+        its image with z < 0 (:228-232).  Keyframes scoring above ``th``, most overlap first, are shuffled with
+        ``np.random.permutation`` and the first k are returned (:235-239) -- the reference's draw order, so a seeded run picks
+        the same keyframes.  Host-side control flow around the hot path (two tiny device kernels + one [n_kf] read-back)."""
+        import numpy as np
+        from .common import get_samples
+        dev = self.device
+        H, W, fx, fy, cx, cy = self.H, self.W, self.fx, self.fy, self.cx, self.cy
+        c2w = torch.as_tensor(c2w).to(dev).float()
+        img = torch.cat((gt_color.to(dev).float(), gt_depth.to(dev).float().unsqueeze(-1)), -1)
+        rays_o, rays_d, samples = get_samples(0, H, 0, W, pixels, H, W, fx, fy, cx, cy, c2w[:3, :3], c2w[:3, -1], img, dev)
+        d = samples[:, -1].reshape(-1, 1)
+        t_vals = torch.linspace(0.0, 1.0, steps=N_samples, device=dev)
+        z_vals = (d * 0.8) * (1.0 - t_vals) + (d + 0.5) * t_vals
+        pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)              # [pixels * N_samples, 3]
+        if len(keyframe_dict) == 0:
+            return []
+        w2c = torch.linalg.inv(torch.stack([torch.as_tensor(kf["est_c2w"]).to(dev).float() for kf in keyframe_dict]))
+        cam = torch.einsum("kij,nj->kni", w2c[:, :3, :3], pts) + w2c[:, None, :3, 3]                     # [n_kf, n, 3]
+        x, y, zc = -cam[..., 0], cam[..., 1], cam[..., 2]
+        z = zc + 1e-5
+        u, v = (fx * x + cx * zc) / z, (fy * y + cy * zc) / z
+        edge = 10
+        inside = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge) & (z < 0)
+        percent = inside.float().mean(dim=1).cpu().numpy()
+        self.last_overlap_percent = percent                      # inspection / tests
+        order = sorted(range(len(keyframe_dict)), key=lambda i: percent[i], reverse=True)
+        selected = [i for i in order if percent[i] > th]
+        return [int(i) for i in np.random.permutation(np.array(selected))[:k]]
+
     # ------------------------------------------------------------------ slams/mapping.py:329-435
     def set_target_refer_frames(self, cur_gt_color, cur_gt_depth, cur_gt_label, cur_gt_c2w, cur_c2w):
         """Target / reference frame bundles of one ``optimize()`` call from ``self.keyframe_dict`` / ``self.keyframe_list``
         (filled by the caller's frame loop, reference ``Mapper.run`` :975,1085) -- the data layout of the reference's
         function, which is what the hot path consumes.  WHICH old keyframes join is host-side control flow outside the path
-        (component 4): ``self.keyframe_selector(cur_color, cur_depth, cur_c2w, keyframe_dict[:-1], k)``
-        if set (e.g. the reference's overlap test :171-236), else the reference's 'global' mode -- k uniform draws with
-        replacement (``random_select`` :160-168).  Always joined: the latest keyframe and the current frame (index -1);
+        (component 4): ``self.mapping_mode`` as in the reference -- 'overlap' = ``keyframe_selection_overlap``
+        with th = 0.05 (:353-356), 'global' = k uniform draws with replacement (``random_select`` :160-168); the reference's
+        ``run`` alternates the two between its outer joint iterations (:1031-1035), which is the caller's loop here.  A
+        ``self.keyframe_selector(cur_color, cur_depth, cur_c2w, keyframe_dict[:-1], k)`` callable, if set, overrides both.
+        Always joined: the latest keyframe and the current frame (index -1);
         keyframe 0 never is (:361).  Per target frame two reference keyframes (its neighbours) plus itself (:399-419)."""
         import numpy as np
         kfs, n_kf = self.keyframe_dict, len(self.keyframe_list)
@@ -783,6 +823,8 @@ class Mapper:
         if n_kf >= 2:
             if getattr(self, "keyframe_selector", None) is not None:
                 picked = list(self.keyframe_selector(cur_gt_color, cur_gt_depth, cur_c2w, kfs[:-1], k))
+            elif getattr(self, "mapping_mode", "global") == "overlap":
+                picked = self.keyframe_selection_overlap(cur_gt_color, cur_gt_depth, cur_c2w, kfs[:-1], k, th=0.05)
             else:
                 picked = [int(v) for v in np.random.choice(np.arange(n_kf - 1), size=k, replace=True)] if n_kf - 1 > 0 else [0]
             picked = sorted({int(i) for i in picked + [n_kf - 1]} - {0})

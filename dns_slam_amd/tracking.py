@@ -38,6 +38,8 @@ class Tracker:
         self.static_shapes = False        # True: device-side jitter draws, no host work per iteration (hipGraph-capturable)
         self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
         if str(device) != "cpu":
+            from ._lib import ensure_init
+            ensure_init()                         # dns_init() outside any capture (see Mapper.__init__)
             self._jitter_consts()                 # built on the device now: nothing is copied host -> device inside a capture
 
     def _jitter_consts(self):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 4
+#define DNS_ABI_VERSION 5
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -145,9 +145,11 @@ int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_
  * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point).  dy_dx: NULL, or what dns_encode_fwd wrote for the
  * same points and table (then the grid part of d_x needs no table access).  ws: 8-byte aligned scratch of
  * dns_encode_bwd_ws_floats(P, meta, flags, queue_cap) floats for the LDS-binned table scatter (NULL = per-corner atomics).
- * flags selects the form of the table scatter (tcnn kernel_grid_backward): DNS_SCATTER_AUTO = LDS bins in 64-bit fixed
- * point, levels of >= 16 chunks through per-chunk queues; _ATOMIC = one float atomic per corner (tcnn's form);
- * _BINNED / _QUEUES = force one binned form for every level.  queue_cap: 0, or the entry capacity of each queue (what does
+ * flags selects the form of the table scatter (tcnn kernel_grid_backward): DNS_SCATTER_AUTO = LDS bins for levels of < 16
+ * chunks (FLOAT64 bins, ds_add_f64: sums good to ~1e-16 of the terms but dependent on their order, i.e. not bit-reproducible
+ * from run to run), per-chunk queues for levels of >= 16 chunks (64-bit FIXED-POINT bins: exact, order-independent sums);
+ * _ATOMIC = one float atomic per corner (tcnn's form; order-dependent fp32 sums); _BINNED / _QUEUES = force one binned form
+ * for every level.  queue_cap: 0, or the entry capacity of each queue (what does
  * not fit falls back to float atomics) -- same value in both calls.  A NaN / Inf in d_grid gives a non-finite d_table in
  * every form. */
 #define DNS_SCATTER_AUTO 0u
@@ -275,6 +277,19 @@ int dns_tv_bwd(const float* lat, uint32_t ld, uint32_t nx, uint32_t n, int halo,
  * skipped, mapping.py:597).  n_slots: multiple of 128, >= P + 127 * n_groups.  ws: 512 uint32 of scratch. */
 int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t min_count, uint32_t n_slots,
                     uint32_t* ws, int32_t* row_index, int32_t* tile_group, void* stream);
+
+/* Device-side error word.  Kernels that consume DEVICE counters (the cursors of dns_group_slots: a stale or corrupted cursor
+ * would otherwise be an out-of-bounds store, not an error code) clamp to their buffers' capacity and, when they had to, set a
+ * bit of a sticky per-device word in pinned host memory (allocated by dns_init(); never device memory).  Every entry point
+ * polls the word after its launches -- no synchronisation: the bit shows up once the faulting kernel has run -- and from
+ * then on returns DNS_E_LAUNCH with the cause in dns_last_error() until the word is cleared.
+ *   dns_device_error(0) -> the word (0 = none), dns_device_error(1) -> the word, then cleared.
+ *   bit 0: dns_group_slots / dns_group_scatter: a group's cursor ran past n_slots
+ * dns_group_scatter is the scatter step of dns_group_slots alone, on caller-supplied cursors [n_groups] (uint32, the first
+ * free slot of every group; advanced): the hardening test drives it with a deliberately stale cursor. */
+int dns_device_error(int clear);
+int dns_group_scatter(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t* cursor, uint32_t n_slots,
+                      int32_t* row_index, void* stream);
 
 /* ---- 2-D feature lookup (feature_matching / feature_searching, utils/common.py:632-673) --------
  * pts [P,3] world points, w2c [R,16] row-major world->camera of the R reference frames, K [host, 9 floats] intrinsics,

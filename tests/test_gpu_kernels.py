@@ -609,6 +609,36 @@ def test_group_slots_layout():
             assert int(tg[t]) == -1 or int((slot == int(tg[t])).sum()) >= 2
 
 
+def test_group_scatter_stale_cursor_is_an_error_code_not_an_out_of_bounds_store():
+    """A consumer of DEVICE counters must not trust them: the scatter step of dns_group_slots driven with a deliberately stale
+    cursor (its group would run 990 slots past the table) stores nothing out of bounds, sets the sticky device error word,
+    and from then on every entry point returns DNS_E_LAUNCH until the word is cleared (include/dns_hip.h, dns_device_error)."""
+    import ctypes as C
+    from dns_slam_amd._lib import check, ensure_init, lib, ptr, stream_ptr
+    ensure_init()
+    assert lib.dns_device_error(1) == 0
+    P, G, n_slots, guard = 1000, 3, 1280, 4096
+    slot = torch.zeros(P, dtype=torch.int64, device=DEV)                 # every point in group 0
+    table = torch.full((n_slots + guard,), -7, dtype=torch.int32, device=DEV)
+    cursor = torch.tensor([n_slots - 10, 0, 0], dtype=torch.int32, device=DEV)     # stale: room for 10 of the 1000 points
+    rc = lib.dns_group_scatter(ptr(slot), P, G, ptr(cursor), n_slots, ptr(table), stream_ptr())
+    torch.cuda.synchronize()
+    assert rc in (0, -2)
+    t = table.cpu()
+    assert int((t[:n_slots - 10] != -7).sum()) == 0 and int((t[n_slots:] != -7).sum()) == 0     # nothing outside [n_slots-10, n_slots)
+    assert int((t[n_slots - 10:n_slots] >= 0).sum()) == 10                                       # the 10 that fit were placed
+    assert lib.dns_device_error(0) & 1
+    # sticky: an unrelated, well-formed call now reports the fault ...
+    ops = _ops()
+    with pytest.raises(RuntimeError, match="device-side capacity check"):
+        ops.group_slots(torch.zeros(256, dtype=torch.int64, device=DEV), 2, 2)
+    # ... until the word is cleared
+    assert lib.dns_device_error(1) & 1 and lib.dns_device_error(0) == 0
+    ri, tg, ns = ops.group_slots(torch.zeros(256, dtype=torch.int64, device=DEV), 2, 2)
+    torch.cuda.synchronize()
+    assert int((ri >= 0).sum()) == 256 and lib.dns_device_error(0) == 0
+
+
 # ----------------------------------------------------------------------------------------- degenerate sizes, argument errors
 def test_empty_batches_and_argument_errors():
     """Zero points / rays / slots pass through every op (empty outputs, zero parameter gradients, no launch fault), a

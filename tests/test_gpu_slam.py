@@ -741,3 +741,57 @@ def test_optimize_reference_signature_with_keyframes_and_stem():
         run[mode] = (c2w.cpu(), float(out["p_loss"]), float(out["d_loss"]))
     assert_close(run["reference"][0], run["frames"][0], rtol=1e-5, what="optimize adapter pose")
     assert abs(run["reference"][1] - run["frames"][1]) <= 1e-4 * abs(run["frames"][1])
+
+
+def test_keyframe_selection_overlap_matches_the_reference_procedure():
+    """Mapper.keyframe_selection_overlap (slams/mapping.py:171-236): the per-keyframe overlap fractions against a numpy
+    restatement of the reference's loop on the SAME sampled rays (device generator re-seeded), the threshold / ordering /
+    ``np.random.permutation`` selection against the same steps on those fractions, and mapping_mode = 'overlap' routing in
+    set_target_refer_frames (th = 0.05, :353-356)."""
+    import numpy as np
+    from dns_slam_amd import common
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    H, W, fx, fy, cx, cy = cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    kfs = [{"gt_color": frames["gt_color"][k], "gt_depth": frames["gt_depth"][k], "gt_label": frames["gt_label"][k],
+            "gt_c2w": frames["gt_c2w"][k], "est_c2w": frames["est_c2w"][k].clone()} for k in range(3)]
+    color, depth, c2w = frames["gt_color"][3].to(DEV), frames["gt_depth"][3].to(DEV), frames["est_c2w"][3].to(DEV)
+    torch.manual_seed(11)
+    np.random.seed(5)
+    picked = mapper.keyframe_selection_overlap(color, depth, c2w, kfs, 2, th=0.05)
+    got = mapper.last_overlap_percent
+    # the reference's loop, restated in numpy on the same rays
+    torch.manual_seed(11)
+    img = torch.cat((color, depth.unsqueeze(-1)), -1)
+    ro, rd, smp = common.get_samples(0, H, 0, W, 100, H, W, fx, fy, cx, cy, c2w[:3, :3], c2w[:3, -1], img, DEV)
+    d = smp[:, -1].reshape(-1, 1).repeat(1, 16)
+    t = torch.linspace(0.0, 1.0, steps=16, device=DEV)
+    z_vals = d * 0.8 * (1.0 - t) + (d + 0.5) * t
+    vertices = (ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]).reshape(-1, 3).cpu().numpy()
+    K = np.array([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+    want = []
+    for kf in kfs:
+        w2c = np.linalg.inv(kf["est_c2w"].cpu().numpy())
+        homo = np.concatenate([vertices, np.ones_like(vertices[:, :1])], axis=1).reshape(-1, 4, 1)
+        cc = (w2c @ homo)[:, :3]
+        cc[:, 0] *= -1
+        uv = K @ cc
+        z = uv[:, -1:] + 1e-5
+        uv = (uv[:, :2] / z).astype(np.float32)
+        m = (uv[:, 0] < W - 10) * (uv[:, 0] > 10) * (uv[:, 1] < H - 10) * (uv[:, 1] > 10)
+        m = (m & (z[:, :, 0] < 0)).reshape(-1)
+        want.append(m.sum() / uv.shape[0])
+    want = np.array(want)
+    assert np.abs(got - want).max() <= 2.0 / vertices.shape[0], (got, want)      # a point within rounding of an edge may flip
+    np.random.seed(5)
+    order = sorted(range(3), key=lambda i: got[i], reverse=True)
+    sel = [i for i in order if got[i] > 0.05]
+    assert picked == [int(i) for i in np.random.permutation(np.array(sel))[:2]]
+    # routing: mapping_mode 'overlap' takes this path in set_target_refer_frames
+    for k in range(3):
+        mapper.keyframe_list.append(5 * k)
+        mapper.keyframe_dict.append(kfs[k])
+    mapper.mapping_mode = "overlap"
+    torch.manual_seed(11)
+    np.random.seed(5)
+    idx, tf, rf = mapper.set_target_refer_frames(color, depth, frames["gt_label"][3].to(DEV), frames["gt_c2w"][3].to(DEV), c2w)
+    assert idx[-1] == -1 and 2 in idx and 0 not in idx and all(i in (1, 2, -1) for i in idx)
