@@ -356,14 +356,21 @@ __device__ __forceinline__ void store_tile_rows_scalar(float* __restrict__ y, ui
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
   wave_lds_fence();
+  // every row and value is read from LDS FIRST, the sixteen stores follow under their masks: with the guard around each
+  // (read, read, store) triple hipcc emits ds_read, s_waitcnt lgkmcnt(0), branch, store sixteen times over (round 3, ISA)
   const uint32_t f = lane & 31u;
+  int rows[16];
+  float v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const uint32_t r = (lane >> 5) + 2 * i;
-    const int row = rows_lds[r];
-    const float v = stg[r * STG_LD + f];
-    if (row >= 0 && f < ncols) y[(size_t)row * ldy + col0 + f] = v;
+    rows[i] = rows_lds[r];
+    v[i] = stg[r * STG_LD + f];
   }
+  const bool colok = f < ncols;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (rows[i] >= 0 && colok) y[(size_t)(uint32_t)rows[i] * ldy + col0 + f] = v[i];
   wave_lds_fence();
 }
 
@@ -524,12 +531,17 @@ struct DyChunk {
 
 __device__ __forceinline__ void dy_chunk_issue(DyChunk& d, const float* __restrict__ dy, uint32_t lddy, uint32_t n_out,
                                                const int* __restrict__ rows_lds, uint32_t c, uint32_t lane) {
+  // unconditional loads from clamped addresses (a padding slot reads row 0, a column past n_out the last one), zeroed by a
+  // select afterwards: sixteen requests back to back instead of sixteen (LDS read, wait, branch, load) rounds
   const uint32_t col = 32u * c + (lane & 31u);
+  const uint32_t colc = min(col, n_out - 1u);
+  int rows[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = rows_lds[(lane >> 5) + 2 * i];
-    d.v[i] = (row >= 0 && col < n_out) ? dy[(size_t)row * lddy + col] : 0.f;
-  }
+  for (int i = 0; i < 16; ++i) rows[i] = rows_lds[(lane >> 5) + 2 * i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d.v[i] = dy[(size_t)(uint32_t)max(rows[i], 0) * lddy + colc];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d.v[i] = (rows[i] >= 0 && col < n_out) ? d.v[i] : 0.f;
 }
 
 __device__ __forceinline__ void dy_chunk_commit(const DyChunk& d, float* __restrict__ stg, uint32_t lane) {

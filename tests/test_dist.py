@@ -1,4 +1,4 @@
-"""Multi-GPU path (dns_slam_amd/dist.py): world_size 2 and 4.
+"""Multi-GPU path (dns_slam_amd/dist.py): world_size 2, 4 and 8.
 
 CPU (gloo): the gradient exchange -- the flat all-reduce and the persistent two-bucket form whose all-reduces are launched
 from post-accumulate hooks -- and the loss-sum all-reduce give, for per-rank losses of the form (local numerators) /
@@ -65,7 +65,9 @@ def _cpu_worker(rank, world, port, q, buckets):
     if buckets:
         # launch order [w, frozen] then [b, rare]; autograd finishes b (the last op of the forward) BEFORE w: the second
         # bucket is complete first and must wait for the first; `frozen` never fires its hook: finish() launches the rest
-        bk = ctx.make_buckets([[w, frozen], [b, rare]])
+        # buckets == "late": only the first bucket may be launched from its hook, the second goes out from finish() -- what
+        # bench.py uses for the bucket whose gradients are produced on two streams (dist.py GradBuckets)
+        bk = ctx.make_buckets([[w, frozen], [b, rare]], hook_launch=[True, False] if buckets == "late" else None)
         ptrs = [p.grad.data_ptr() for p in (w, frozen, b, rare)]
     for it in range(2):                                 # two iterations: the persistent views survive and are re-zeroed
         if buckets:
@@ -91,7 +93,7 @@ def _cpu_worker(rank, world, port, q, buckets):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,buckets", [(2, False), (2, True), (4, False), (4, True)])
+@pytest.mark.parametrize("world,buckets", [(2, False), (2, True), (2, "late"), (4, False), (4, True), (8, "late"), (8, True)])
 def test_gloo_sum_of_shard_grads_is_union_grad(world, buckets):
     port = _free_port()
     ctxm = mp.get_context("spawn")
@@ -125,7 +127,7 @@ def test_union_mode_shard_arithmetic():
     n = 11
     occ = torch.randn(n, n, n, generator=g, dtype=torch.float64)
     tv = lambda o: ((o[1:] - o[:-1]) ** 2).sum() + ((o[:, 1:] - o[:, :-1]) ** 2).sum() + ((o[:, :, 1:] - o[:, :, :-1]) ** 2).sum()
-    for W in (2, 3, 4):
+    for W in (2, 3, 4, 8):
         tot = 0.0
         for r in range(W):
             a, b = shard_range(n, W, r)
@@ -137,7 +139,7 @@ def test_union_mode_shard_arithmetic():
     K, npf, S = 3, 10, 4
     lab = torch.randint(0, 8, (K * npf,), generator=g)
     tiled = lab.repeat(1, S).flatten(0, 1)                              # the reference's expression on the whole batch
-    for W in (2, 4):
+    for W in (2, 4, 8):
         for r in range(W):
             a, b = shard_range(npf, W, r)
             got = union_point_labels(lab, K, npf, a, b, S)

@@ -9,3 +9,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA
   echo "pass $i ($set) rc=$?"
   i=$((i+1))
 done
+( cd $root && timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $out/pass9 -o p -- "$@" > /dev/null 2>&1 ); echo "pass coexec rc=$?"
