@@ -323,7 +323,12 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]
-    # Eager launches on two streams are the measured path; a hipGraph replay of the iteration (--graph) is slower: see capture().
+    # Launch mode.  Eager launches on two streams overlap the smoothness branch with the ray branch but need ~2 ms of host
+    # enqueue per step; a hipGraph replay needs none but runs the branches one after the other.  Which wins depends on the
+    # workload and on the box's host (cfg2: eager 2.31 vs graph 2.44 ms; cfg3 / ref on a slow host: eager is HOST-bound at
+    # 2.96 / 1.91 ms while their kernels need 2.4 / 1.5).  Default (neither --graph nor --eager, one GPU): both are built,
+    # timed for a few untimed steps, and the faster one runs the timed region -- reported as launch_mode / launch_trial_ms.
+    auto_mode = not args.graph and not args.eager and not args.no_overlap and ctx.world_size == 1
     use_graph = args.graph and not args.eager and ctx.world_size == 1
     # the smoothness branch on a second stream (eager), or -- with --graph-branches -- as a parallel branch of the captured graph
     overlap = (not use_graph or args.graph_branches) and not args.no_overlap
@@ -347,21 +352,68 @@ def main():
             except Exception:
                 pass
             run = step
+    trial = None
+    if auto_mode:
+        def timed(fn, n=8):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) * 1e3 / n
+        trial = {"eager_2_streams": timed(step)}
+        try:
+            mapper.overlap_smooth, mapper.prefetch_draws = False, False      # a captured iteration makes its own draws, one stream
+            mapper._pending_draws = None
+            replay = capture(step)
+            trial["graph"] = timed(replay)
+            if trial["graph"] < trial["eager_2_streams"]:
+                run, graphed, overlap = replay, True, False
+        except Exception as e:
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+        if not graphed:
+            mapper.overlap_smooth, mapper.prefetch_draws = True, True
+            mapper._pending_draws = None
+            replay = None                                   # the losing graph and its memory pool go away before the timed region
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         tw = time.perf_counter()
         run()
         if args.verbose:
             torch.cuda.synchronize()
             print(f"[bench] warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+    # The interpreter's cyclic garbage collector is parked for the timed region (as timeit does): a generation-2 pass over the
+    # autograd objects of a step showed up as one 55-60 ms step in a hundred (step_ms_spread.max), i.e. +0.6 ms on the mean.
+    import gc
+    gc.collect()
+    gc.disable()
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    marks = []
+    for i in range(args.steps):
         last = run()
+        if args.verbose and i % 10 == 9:
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter() - t0)
+    if marks:
+        print("[bench] cumulative s at every 10th timed step:", [round(m, 4) for m in marks], file=sys.stderr, flush=True)
     ctx.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     final_loss = float(last.detach()) if torch.is_tensor(last) else None        # after the clock stopped
     if final_loss is not None and not math.isfinite(final_loss):
         raise RuntimeError(f"non-finite loss after the timed steps ({final_loss}): the measurement is void")
@@ -437,7 +489,8 @@ def main():
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "step_ms_spread": spread, "higher_is_better": True,
         "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
-                  "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "final_loss": final_loss,
+                  "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "launch_mode": "hipGraph replay" if graphed else "eager",
+        "launch_trial_ms": trial, "final_loss": final_loss,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,
                    "global_rays": job_rays,
                    "parallelism": f"dp{ctx.world_size} (" + ("union batch: rank slices of one shared-seed batch and of the lattice"
