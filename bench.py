@@ -135,7 +135,7 @@ def kernel_rooflines(spans, wl, steps, pmc):
     return rows
 
 
-def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None):
+def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None, fused_step=True):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
@@ -178,6 +178,17 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None)
         code = (torch.rand(4 * n_per_frame, wl["nu"] + wl["ns"], 32, generator=g) * 2 - 1).to(device)
 
     mapper.bench_code = code
+    if fused_step and not dist_ctx.union:
+        # the iteration as a fixed launch sequence over preallocated buffers (dns_slam_amd/fused_step.py): same kernels and
+        # draws as the autograd-driven step below, without autograd's glue launches and host time
+        from dns_slam_amd.fused_step import MapStep
+        ms = mapper.map_step = MapStep(mapper, frames, quad_list, T_list, prep=prep, features=code, lambda_lt=10.0, smooth=True)
+
+        def step():
+            ms.step()
+            return ms.out[6]                 # the ray-batch loss (a view: no launch); ms.losses() adds the smoothness term
+
+        return cfg, bound, cam, frames, mapper, step
 
     def step():
         if buckets is not None:
@@ -307,6 +318,9 @@ def main():
                     help="(default) launch the iteration eagerly, the smoothness branch on a second stream")
     ap.add_argument("--no-overlap", action="store_true", help="eager, but keep the smoothness branch on the main stream")
     ap.add_argument("--graph-branches", action="store_true", help="with --graph: capture the smoothness branch as a parallel branch")
+    ap.add_argument("--autograd-step", action="store_true",
+                    help="drive the iteration through torch.autograd (Mapper.iteration_loss + backward + FusedAdam) instead of "
+                         "the fixed launch sequence of dns_slam_amd/fused_step.py")
     ap.add_argument("--union-batch", action="store_true",
                     help="N>1: the N ranks share ONE batch of the configured size (shared-seed draws, rank slices of the rays and "
                          "of the smoothness lattice; strong scaling) instead of one batch per rank (weak scaling, the default)")
@@ -334,7 +348,7 @@ def main():
     overlap = (not use_graph or args.graph_branches) and not args.no_overlap
     union = ctx.union
     cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + (0 if union else ctx.rank), dist_ctx=ctx, overlap=overlap,
-                                                  graph=use_graph)
+                                                  graph=use_graph, fused_step=not args.autograd_step)
     n_rays = 4 * sum(wl["rays"])
     job_rays = n_rays if union else n_rays * ctx.world_size          # rays the whole job renders per step
     S = wl["nu"] + wl["ns"]
@@ -414,6 +428,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if getattr(mapper, "map_step", None) is not None:
+        last = mapper.map_step.losses()[0]
     final_loss = float(last.detach()) if torch.is_tensor(last) else None        # after the clock stopped
     if final_loss is not None and not math.isfinite(final_loss):
         raise RuntimeError(f"non-finite loss after the timed steps ({final_loss}): the measurement is void")
@@ -490,6 +506,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "step_ms_spread": spread, "higher_is_better": True,
         "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
                   "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "launch_mode": "hipGraph replay" if graphed else "eager",
+        "step_driver": "fixed launch sequence (fused_step.MapStep)" if getattr(mapper, "map_step", None) is not None else "torch.autograd",
         "launch_trial_ms": trial, "final_loss": final_loss,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,
                    "global_rays": job_rays,

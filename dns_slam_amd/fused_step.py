@@ -1,0 +1,360 @@
+"""One mapping iteration as a fixed launch sequence (slams/mapping.py:870-912: sample -> render -> losses -> backward -> Adam).
+
+``Mapper.optimize_frames`` drives the kernels through torch.autograd: correct for any caller, but the iteration is ~90
+launches of which more than half are autograd's own glue (gradient accumulation, zero fills, ``stack`` / ``cat`` / slices,
+one workspace allocation per backward node) and the host needs ~2.0 ms to enqueue a 2.3 ms iteration.  ``MapStep`` is the
+same iteration written out by hand for the static-shape case (``mapper.static_shapes``): forward and backward are a fixed
+list of C-ABI calls (include/dns_hip.h) over buffers allocated ONCE, every gradient lands in one flat buffer that a single
+fill clears, the lattice (smoothness) branch -- forward AND backward, it meets the ray branch only in the parameter
+gradients -- runs on the side stream, and Adam (csrc/adam.hip) steps all parameters from a prebuilt tensor list.
+
+Same kernels, same arithmetic, same random draws (``Mapper._take_draws``) as the autograd path: tests/test_gpu_fused_step.py
+holds the two against each other (losses, every parameter after several iterations).  No CPU path: the constructor raises
+off-GPU like every op here.
+
+Multi-GPU (``mapper.dist`` in weak mode, dist.py): the MAX of the per-frame sampled depth and the SUM of the 16 loss
+numerators are all-reduced where the autograd path does it; the gradient buffer is laid out [colour | logit | fine pool |
+table | coarse | poses] so that the first three -- complete when the ray branch's MLP backward ends -- travel (asynchronous
+all-reduce) under the hash-grid scatter, and the rest after the two streams have joined.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import ops
+from ._lib import DnsAdamTensor, check, ptr
+from .common import get_quad_from_c2w, get_rotation_from_quad
+
+_V = C.c_void_p
+
+
+class MapStep:
+    def __init__(self, mapper, target_frames, quad_list=None, T_list=None, prep=None, features=None, lambda_lt=10.0,
+                 smooth=True, betas=(0.9, 0.999), eps=1e-8):
+        m = self.m = mapper
+        dev = self.dev = torch.device(m.device)
+        if dev.type != "cuda":
+            raise ValueError("dns_slam_amd ops run on the GPU only; there is no CPU fallback")
+        if not (m.static_shapes and m.fused_losses):
+            raise ValueError("MapStep needs mapper.static_shapes and mapper.fused_losses (the sync-free iteration)")
+        if m.dist is not None and m.dist.union:
+            raise ValueError("MapStep: union-batch mode runs through the autograd path")
+        if features is not None and features.dim() != 3:
+            raise ValueError("MapStep takes the per-sample code [N, S, C] (stem feature maps run through the autograd path)")
+        self.world = m.dist.world_size if (m.dist is not None and m.dist.enabled) else 1
+        self.frames = target_frames
+        self.prep = prep if prep is not None else m.prepare_frames(target_frames)
+        self.features = None if features is None else features.to(dev).float().contiguous()
+        self.lambda_lt, self.smooth = float(lambda_lt), bool(smooth)
+        self.betas, self.eps = betas, eps
+        K = self.K = m.n_target_frame
+        dec, pool = m.decoder, m.fine_decoders
+        self.pe_dim, self.grid_dim, self.hid = m.pe_dim, m.grid_dim, m.hidden_dim
+        nets = (dec.coarse_fn.decoder, dec.out_fn.color_decoder, dec.out_fn.logit_decoder)
+        if any(getattr(n, "fp16", False) != getattr(nets[0], "fp16", False) for n in nets):
+            raise ValueError("MapStep: the networks must share one operand precision")
+        self.fp16 = ops.MLP_FP16_FLAG if getattr(nets[0], "fp16", False) else 0
+        shp = lambda n: (n.n_input_dims, n.n_output_dims, n.n_neurons, n.n_hidden_layers)
+        self.shp_c, self.shp_col, self.shp_log = (shp(n) for n in nets)
+        self.shp_f = (self.pe_dim + self.grid_dim, self.hid + 1, pool.nn_, pool.nl)
+        self.n_feat = self.hid + (self.hid if features is None else self.features.shape[-1])
+        if not (self.pe_dim % 4 == 0 and self.pe_dim <= 64 and self.n_feat <= 64 and self.n_feat % 4 == 0
+                and self.shp_col[0] == self.pe_dim + self.n_feat):
+            raise ValueError("MapStep: network shapes outside the two-segment input form (ops.render_nets has the same limits)")
+        self.n_class = self.shp_log[1]
+
+        # ---- poses: one [K,4] / [K,3] pair is the parameter; frame 0 stays fixed when K > 1 (slams/mapping.py:447-455)
+        if quad_list is None:
+            quad_list = [get_quad_from_c2w(target_frames["est_c2w"][k]).to(dev) for k in range(K)]
+            T_list = [target_frames["est_c2w"][k][:3, 3].detach().clone().to(dev) for k in range(K)]
+        self.quad_list, self.T_list = quad_list, T_list
+        self.Q = torch.stack([q.detach().float() for q in quad_list]).contiguous()
+        self.T = torch.stack([t.detach().float() for t in T_list]).contiguous()
+        self.is_BA = bool(m.is_BA)
+        self.pose_row0 = 0 if K == 1 else 1
+
+        # ---- parameters and the flat gradient buffer  [colour | logit | pool | table | coarse | quat | trans]
+        self.p_table = dec.pe_fn.grid_fn.params
+        self.meta = dec.pe_fn.grid_fn.meta
+        self.n_bins = dec.pe_fn.pe_fn.n_bins
+        self.p_coarse, self.p_color, self.p_logit = (n.params for n in nets)
+        self.p_pool = pool.pool
+        plist = [self.p_color, self.p_logit, self.p_pool, self.p_table, self.p_coarse, self.Q, self.T]
+        for p in plist:
+            if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
+                raise ValueError("MapStep: parameters must be contiguous fp32 CUDA tensors")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in plist]                  # 16-byte aligned segments
+        self.G = torch.zeros(sum(sizes), device=dev)
+        offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        seg = lambda i: self.G[offs[i]:offs[i] + plist[i].numel()]
+        self.g_color, self.g_logit, self.g_pool, self.g_table, self.g_coarse, self.g_quat, self.g_trans = (seg(i) for i in range(7))
+        self.G_early, self.G_late = self.G[:offs[3]], self.G[offs[3]:]
+        self.M, self.V = torch.zeros_like(self.G), torch.zeros_like(self.G)
+        self.adam_state = torch.zeros(3, device=dev)
+        lr_pose = float(m.BA_cam_lr) * float(self.is_BA)
+        items = [(plist[i], offs[i], plist[i].numel(), float(m.lr)) for i in range(5)]
+        if self.is_BA:
+            a4, a3 = 4 * self.pose_row0, 3 * self.pose_row0
+            items.append((self.Q.view(-1)[a4:], offs[5] + a4, self.Q.numel() - a4, lr_pose))
+            items.append((self.T.view(-1)[a3:], offs[6] + a3, self.T.numel() - a3, lr_pose))
+        items = [it for it in items if it[2] > 0]
+        self.adam_items = (DnsAdamTensor * len(items))()
+        for k, (p, o, n, lr) in enumerate(items):
+            it = self.adam_items[k]
+            it.p, it.g = p.data_ptr(), self.G.data_ptr() + 4 * o
+            it.m, it.v = self.M.data_ptr() + 4 * o, self.V.data_ptr() + 4 * o
+            it.n, it.lr = n, lr
+        self.n_adam = len(items)
+
+        # ---- ray-branch buffers
+        npf = self.npf = self.prep["n1"] + self.prep["n2"]
+        nu = 0 if m.t_uniform is None else m.t_uniform.numel()
+        ns = m.n_surface_ray
+        N, S = K * npf, nu + ns
+        P = N * S
+        self.N, self.S, self.P, self.nu, self.ns = N, S, P, nu, ns
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        self.rays_o, self.rays_d, self.gt_color, self.gt_depth = f(N, 3), f(N, 3), f(N, 3), f(N)
+        self.gt_label = torch.empty(N, device=dev, dtype=torch.int64)
+        self.inside = torch.empty(N, device=dev, dtype=torch.uint8)
+        self.z, self.pts = f(N, S), f(N, S, 3)
+        self.dmax_ws = torch.empty(K, device=dev, dtype=torch.int32)
+        ld = self.ld = self.pe_dim + self.grid_dim
+        self.x3, self.buf = f(P, 3), f(P, ld)
+        self.dydx = f(self.meta.n_levels * 3 * P * 2) if self.is_BA else None
+        nf = self.hid + 1
+        self.coarse, self.fine = f(P, nf), f(P, nf)
+        n_groups = self.n_groups = max(len(pool), 1)
+        self.n_slots = (P + 127) // 128 * 128 + 128 * n_groups
+        self.row_index = torch.empty(self.n_slots, device=dev, dtype=torch.int32)
+        self.tile_group = torch.empty(self.n_slots // 128, device=dev, dtype=torch.int32)
+        self.group_ws = torch.empty(512, device=dev, dtype=torch.int32)
+        self.feat = f(P, self.n_feat)
+        if self.features is None:
+            self.feat.zero_()                                             # the code columns stay zero
+        self.raw, self.logit = f(P, 4), f(P, self.n_class)
+        self.depth, self.var, self.rgb, self.weights, self.sem = f(N), f(N), f(N, 3), f(N, S), f(N, self.n_class)
+        self.sums_ws, self.out = f(ops.LOSS_SUMS_FLOATS), f(16)
+        self.one = torch.ones(1, device=dev)
+        self.d_color, self.d_depth, self.d_sem = f(N, 3), f(N), f(N, self.n_class)
+        self.d_fine, self.d_coarse = f(P, nf), f(P, nf)
+        self.d_raw, self.d_logit, self.d_col = f(P, 4), f(P, self.n_class), f(P, 4)
+        self.d_buf, self.d_featx = f(P, ld), f(P, 4 + self.n_feat)
+        self.d_ft = f(P, nf)
+        self.d_x3 = f(P, 3)
+        self.ray_ws = f(12 * K)
+        raw_lib = ops.lib._raw
+        mlp_ws = lambda n_slots, s: f(max(int(raw_lib.dns_mlp_bwd_ws_floats(n_slots, s[2], s[3])), 4))
+        self.ws_mlp = max((mlp_ws(self.n_slots, s) for s in (self.shp_f, self.shp_c, self.shp_col, self.shp_log)),
+                          key=lambda t: t.numel())
+        self.scatter_form, self.scatter_cap = ops.SCATTER_FORM
+        enc_ws = lambda n: f(max(int(raw_lib.dns_encode_bwd_ws_floats(n, C.byref(self.meta.c), self.scatter_form, self.scatter_cap)), 4))
+        self.ws_enc = enc_ws(P)
+        tr = m.cfg["training"]
+        self.lam = (C.c_float * 8)(m.lambda_p, m.lambda_d, m.lambda_l, self.lambda_lt, m.lambda_fs, m.lambda_opacity,
+                                   tr["opacity_sigma"], 0.05)
+        self.camv = (C.c_double * 4)(float(m.fx), float(m.fy), float(m.cx), float(m.cy))
+        self.b6 = ops._bound6(m.bound)
+
+        # ---- lattice branch (slams/mapping.py:129-159)
+        if self.smooth:
+            sp = self.sp = tr["smooth_pts"]
+            m._ensure_lattice(sp, 0.1, 0.05)
+            n = self.n_lat = sp - 1
+            Pl = self.Pl = n ** 3
+            self.bufl, self.occ, self.d_occ, self.d_bufl = f(Pl, ld), f(Pl, 1), f(Pl, 1), f(Pl, ld)
+            self.tv = f(1)
+            self.w_sm = torch.full((1,), m.lambda_sm / self.world, device=dev)
+            self.ws_mlp_l = mlp_ws(Pl, self.shp_c)
+            self.ws_enc_l = enc_ws(Pl)
+        if getattr(m, "_side_stream", None) is None:
+            m._side_stream = torch.cuda.Stream(device=dev)
+        self.side = m._side_stream
+        self.steps = 0
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _lattice_branch(self, r6, st):
+        """Forward and backward of the smoothness term on the side stream: its loss weight is a constant, so its backward
+        needs nothing from the ray branch."""
+        m, lib = self.m, ops.lib
+        _, c_vox, c_off, c_mar = m._lattice_consts
+        r = r6.to(torch.float64)
+        b = torch.addcmul(torch.addcmul(c_mar, r[:3], c_off), r[3:], c_vox)
+        pts = torch.addcmul(b, m._lattice, c_vox).reshape(-1, 3).float()
+        Pl, ld, pe = self.Pl, self.ld, self.pe_dim
+        meta = C.byref(self.meta.c)
+        grid_l = _V(self.bufl.data_ptr() + 4 * pe)
+        check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
+                                 grid_l, ld, None, st), "dns_encode_fwd")
+        n_in, _, nn, nl = self.shp_c
+        check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
+                              None, None, 0, None, self.fp16, st), "dns_mlp_fwd")
+        check(lib.dns_tv_fwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.tv), st), "dns_tv_fwd")
+        check(lib.dns_tv_bwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ), st),
+              "dns_tv_bwd")
+        check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
+                              ptr(self.d_bufl), ld, None, 0, ptr(self.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, None,
+                              self.fp16, st), "dns_mlp_bwd")
+        d_grid_l = _V(self.d_bufl.data_ptr() + 4 * pe)
+        check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
+                                 ptr(self.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),
+              "dns_encode_bwd")
+        self._keep = pts                       # alive until the next step's side-stream work is behind it
+
+    def _code(self):
+        """The truncated per-sample code (slams/mapping.py:553-556) into the feature block's upper columns."""
+        d = self.gt_depth[:, None]
+        z = self.z
+        trunc = (1.0 - (z < d * 0.95).float()) * (1.0 - (z > d * 1.05).float()) * (d > 0.0).float()
+        torch.mul(self.features, trunc[..., None], out=self.feat.view(self.N, self.S, -1)[..., self.hid:])
+
+    @torch.no_grad()
+    def step(self):
+        """One iteration; returns nothing (``losses()`` reads the terms of the last step)."""
+        m, lib = self.m, ops.lib
+        main = torch.cuda.current_stream()
+        st = _V(main.cuda_stream)
+        K, npf, N, S, P, ld, pe = self.K, self.npf, self.N, self.S, self.P, self.ld, self.pe_dim
+        self.G.zero_()
+        # mapper.prefetch_draws: this step's draws were made on the side stream a step ago, the next ones are enqueued there
+        # now; mapper.overlap_smooth: the lattice branch runs on the side stream (both off inside a one-stream graph capture)
+        prefetch = getattr(m, "prefetch_draws", False)
+        d = m._take_draws(self.prep) if prefetch else m._draw_all(self.prep)
+        pix, (t_surf, t_zero), r6 = d["pix"], d["jitter"], d["r6"]
+        m._lattice_r6 = None
+        on_side = self.smooth and getattr(m, "overlap_smooth", False)
+        if on_side:
+            if not prefetch:
+                self.side.wait_stream(main)    # (_take_draws has done it): after the gradient fill and the last Adam step
+            with torch.cuda.stream(self.side):
+                self._lattice_branch(r6, _V(self.side.cuda_stream))
+        elif self.smooth:
+            self._lattice_branch(r6, st)
+
+        # ---- rays, samples (utils/common.py:248-264, 561-599)
+        dmax = None
+        if self.world > 1:
+            dmax = torch.gather(self.prep["depth"].reshape(K, -1), 1, pix.reshape(K, npf)).amax(dim=1).clamp_min(0.0)
+            m.dist.allreduce_max(dmax)
+            dmax = dmax.float().contiguous().view(torch.int32)
+        jstride = self.ns if t_surf.dim() == 2 else 0
+        prep = self.prep
+        H, W = m.H, m.W
+        check(lib.dns_raygen_sample(ptr(pix), ptr(prep["color"]), ptr(prep["depth"]), ptr(prep["label"]), ptr(self.Q),
+                                    ptr(self.T), self.camv, self.b6, H, W, 0, H, 0, W, K, npf, ptr(m.t_uniform), ptr(t_surf),
+                                    ptr(t_zero), self.nu, self.ns, jstride, ptr(self.dmax_ws if dmax is None else dmax),
+                                    0 if dmax is None else 1, ptr(self.rays_o), ptr(self.rays_d), ptr(self.gt_color),
+                                    ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(self.z), ptr(self.pts), st),
+              "dns_raygen_sample")
+        # ---- encoding (slams/mapping.py:608 + models/decoder.py:45-48)
+        meta = C.byref(self.meta.c)
+        grid = _V(self.buf.data_ptr() + 4 * pe)
+        check(lib.dns_encode_fwd(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf),
+                                 ld, grid, ld, ptr(self.dydx), st), "dns_encode_fwd")
+        # ---- the four networks (slams/mapping.py:616-626)
+        fp16 = self.fp16
+
+        def fwd(x2, n_in1, params, shape, y, ri, tg, n_slots, stride):
+            n_in, n_out, nn, nl = shape
+            check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
+                                  nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, None, fp16, st), "dns_mlp_fwd")
+
+        fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0)
+        if m.label_layout == "reference_tiled":
+            classes = self.gt_label.repeat(1, S).flatten(0, 1)             # :613 -- tiles, SURVEY D1
+        else:
+            classes = self.gt_label.repeat_interleave(S)
+        slot = m._class_slots(classes, False)
+        check(lib.dns_group_slots(ptr(slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(self.row_index),
+                                  ptr(self.tile_group), st), "dns_group_slots")
+        self.fine.zero_()
+        fwd(None, 0, self.p_pool, self.shp_f, self.fine, self.row_index, self.tile_group, self.n_slots, self.p_pool.shape[-1])
+        self.feat[:, :self.hid] = self.fine[:, 1:]
+        if self.features is not None:
+            self._code()
+        fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0)
+        fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0)
+        self.raw.sigmoid_()
+        self.raw[:, 3] = self.fine[:, 0]
+        # ---- compositing + losses (utils/common.py:506-537, slams/mapping.py:887-907)
+        Cn, L = self.n_class, self.hid + 1
+        check(lib.dns_composite_fwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
+                                    ptr(self.rgb), ptr(self.weights), ptr(self.sem), st), "dns_composite_fwd")
+        lam = self.lam
+        check(lib.dns_loss_sums(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
+                                ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(self.fine), ptr(self.coarse),
+                                ptr(self.z), ptr(self.sums_ws), st), "dns_loss_sums")
+        if self.world > 1:
+            m.dist.allreduce_sums(self.sums_ws[:16])
+        check(lib.dns_loss_finalize(lam, N, S, Cn, L, 0, ptr(self.sums_ws), ptr(self.out), st), "dns_loss_finalize")
+
+        # ---- backward
+        check(lib.dns_loss_bwd(lam, N, S, Cn, L, 0, ptr(self.out), ptr(self.one), ptr(self.rgb), ptr(self.depth), None,
+                               ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside),
+                               ptr(self.fine), ptr(self.coarse), ptr(self.z), ptr(self.d_color), ptr(self.d_depth), None,
+                               ptr(self.d_sem), ptr(self.d_fine), ptr(self.d_coarse), st), "dns_loss_bwd")
+        check(lib.dns_composite_bwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), None,
+                                    ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), st),
+              "dns_composite_bwd")
+
+        def bwd(x2, n_in1, dy, params, shape, d_x2, d_p, ri, tg, n_slots, stride, acc):
+            n_in, n_out, nn, nl = shape
+            check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
+                                  ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
+                                  0 if d_x2 is None else d_x2.stride(0), ptr(d_p), ptr(self.ws_mlp), n_slots, ptr(ri), ptr(tg),
+                                  stride, None, acc | fp16, st), "dns_mlp_bwd")
+
+        d_feat = self.d_featx[:, 4:]
+        bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, self.g_coarse, None, None, P, 0, 0)
+        torch.ops.aten.sigmoid_backward.grad_input(self.d_raw, self.raw, grad_input=self.d_col)
+        self.d_featx[:, 3] = self.d_raw[:, 3]
+        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, self.g_color, None, None, P, 0, 1)
+        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, self.g_logit, None, None, P, 0, 3)
+        torch.add(self.d_fine, self.d_featx[:, 3:3 + L], out=self.d_ft)
+        bwd(None, 0, self.d_ft, self.p_pool, self.shp_f, None, self.g_pool, self.row_index, self.tile_group, self.n_slots,
+            self.p_pool.shape[-1], 1)
+        work = None
+        if self.world > 1:
+            import torch.distributed as dist
+            work = dist.all_reduce(self.G_early, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
+        d_grid = _V(self.d_buf.data_ptr() + 4 * pe)
+        check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld, d_grid, ld,
+                                 ptr(self.g_table), ptr(self.d_x3) if self.is_BA else None, ptr(self.dydx), ptr(self.ws_enc),
+                                 self.scatter_form, self.scatter_cap, st), "dns_encode_bwd")
+        if self.is_BA:
+            check(lib.dns_raygen_bwd(ptr(pix), ptr(self.Q), self.camv, 0, H, 0, W, K, npf, S, ptr(self.z), ptr(self.d_x3), None,
+                                     None, ptr(self.ray_ws), ptr(self.g_quat), ptr(self.g_trans), st), "dns_raygen_bwd")
+        if on_side:
+            main.wait_stream(self.side)
+        if self.world > 1:
+            import torch.distributed as dist
+            work2 = dist.all_reduce(self.G_late, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
+            work.wait()
+            work2.wait()
+        check(lib.dns_adam_step(self.adam_items, self.n_adam, self.betas[0], self.betas[1], self.eps, ptr(self.adam_state), st),
+              "dns_adam_step")
+        self.steps += 1
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def losses(self):
+        """(total, terms) of the last step, as ``Mapper.iteration_loss`` returns them (device tensors, no sync)."""
+        t = self.out
+        terms = {"p_loss": t[0], "d_loss": t[1], "l_loss": t[2], "lt_loss": t[3], "fs_loss": t[4], "opacity_loss": t[5]}
+        total = t[6]
+        if self.smooth:
+            terms["smooth_loss"] = self.tv[0]
+            total = total + self.w_sm[0] * self.tv[0]
+        return total, terms
+
+    @torch.no_grad()
+    def write_back(self):
+        """Poses into the caller's per-frame tensors (``set_optimizer``'s quad_list / T_list)."""
+        for k in range(self.K):
+            self.quad_list[k].data.copy_(self.Q[k])
+            self.T_list[k].data.copy_(self.T[k])
+
+    def pose(self, k):
+        bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self.dev)
+        return torch.cat([torch.cat((get_rotation_from_quad(self.Q[k]), self.T[k][:, None]), -1), bottom], dim=0)
