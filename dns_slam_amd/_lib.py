@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class DnsGridMeta(C.Structure):
@@ -57,7 +57,12 @@ SIGNATURES = {
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                _P, _P, _P]),
+                                _P, _P, _U, _P]),
+    "dns_class_slots": (C.c_int, [_P, _U, _U, _I, _P, _U, _P, _P]),
+    "dns_feature_block": (C.c_int, [_P, _U, _U, _P, _U, _P, _P, _U, _U, _P, _U, _P, _P]),
+    "dns_rgb_sigmoid": (C.c_int, [_P, _U, _P]),
+    "dns_raw_bwd": (C.c_int, [_P, _P, _U, _P, _P, _U, _I, _P]),
+    "dns_lattice_points": (C.c_int, [_P, _P, _U, _P, _P]),
     "dns_feature_gather": (C.c_int, [_P, _P, _P, _P, _U, _U, _U, _I, _I, _I, _I, _P, _P, _P]),
     "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P]),
     "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P, _P]),

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
                                                              const float* __restrict__ z,
                                                              const float* __restrict__ gt_depth,
                                                              const uint8_t* __restrict__ valid, float* __restrict__ d_fine,
-                                                             float* __restrict__ d_coarse) {
+                                                             float* __restrict__ d_coarse, uint32_t ldd_fine) {
   const uint32_t E = c.N * c.S * c.L;
   const float g = g_total[0];
   const float clt = g * out[O_CLT], cfs = g * out[O_CFS], cop = g * out[O_COP];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
         df += docc * 10.f * occ * (1.f - occ);
       }
     }
-    d_fine[e] = df;
+    d_fine[(size_t)p * ldd_fine + k] = df;
     d_coarse[e] = dc;
   }
 }
@@ -394,8 +394,9 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
                             const float* pred_var, const float* pred_logits, const float* gt_color,
                             const float* gt_depth, const int64_t* gt_label, const uint8_t* valid, const float* fine,
                             const float* coarse, const float* z, float* d_color, float* d_depth, float* d_var,
-                            float* d_logits, float* d_fine, float* d_coarse, void* stream) {
+                            float* d_logits, float* d_fine, float* d_coarse, uint32_t ldd_fine, void* stream) {
   if (N == 0) return DNS_OK;
+  DNS_REQUIRE(ldd_fine == 0 || ldd_fine >= L, "dns_loss_bwd: ldd_fine %u < L %u", ldd_fine, L);
   DNS_REQUIRE(lambdas && out && g_total && d_color && d_depth, "dns_loss_bwd: NULL argument");
   DNS_REQUIRE(C == 0 || d_logits, "dns_loss_bwd: C > 0 needs d_logits");
   DNS_REQUIRE(tracker || (d_fine && d_coarse), "dns_loss_bwd: mapper mode needs d_fine and d_coarse");
@@ -407,7 +408,7 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
     const uint64_t E = (uint64_t)N * S * L;
     const uint32_t blocks = (uint32_t)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
     DNS_LAUNCH(loss_point_bwd_kernel, dim3(blocks), dim3(256), 0, st, c, out, g_total, fine, coarse, z, gt_depth,
-                       valid, d_fine, d_coarse);
+                       valid, d_fine, d_coarse, ldd_fine ? ldd_fine : L);
   }
   return check_launch("dns_loss_bwd");
 }

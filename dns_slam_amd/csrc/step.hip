@@ -1,0 +1,159 @@
+// Glue of one mapping iteration (slams/mapping.py:590-627, 553-556, 129-143) as single launches.  Each of these is a
+// handful of elementwise torch ops in the reference (and in this package's autograd path); written out they cost one launch
+// each and no intermediate tensors.  HBM-bound streaming kernels, no LDS, no matrix work.
+#include "common.hpp"
+
+namespace dns {
+
+// class id of point p (tiled: label[p mod N], the reference's layout; else label[p / S]) -> row of the pooled
+// per-class parameters through the class -> row table (-1: no network)
+__global__ __launch_bounds__(256) void class_slots_kernel(const int64_t* __restrict__ labels, uint32_t N, uint32_t S, uint32_t tiled,
+                                                          const int64_t* __restrict__ lut, uint32_t n_lut,
+                                                          int64_t* __restrict__ slot) {
+  const uint32_t P = N * S;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int64_t c = labels[tiled ? p % N : p / S];
+    slot[p] = (c >= 0 && c < (int64_t)n_lut) ? lut[c] : (int64_t)-1;
+  }
+}
+
+// feat[p] = (fine[p, 1 : 1 + hidden] | code[p] * trunc(p)),  raw[p, 3] = fine[p, 0]
+// trunc = (1 - [z < 0.95 d]) (1 - [z > 1.05 d]) [d > 0]   (slams/mapping.py:553-556; d = the ray's measured depth)
+// One thread per (point, 4-column group) of the output row.
+__global__ __launch_bounds__(256) void feature_block_kernel(const float* __restrict__ fine, uint32_t ld_fine, uint32_t hidden,
+                                                            const float* __restrict__ code, uint32_t C,
+                                                            const float* __restrict__ z, const float* __restrict__ gt_depth,
+                                                            uint32_t P, uint32_t S, float* __restrict__ feat, uint32_t ld_feat,
+                                                            float* __restrict__ raw) {
+  const uint32_t q_row = (hidden + C) / 4u;                // float4 groups per output row
+  const uint64_t total = (uint64_t)P * q_row;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t p = (uint32_t)(i / q_row), q = (uint32_t)(i - (uint64_t)p * q_row);
+    const uint32_t col = 4u * q;
+    float4 v;
+    if (col < hidden) {
+      const float* f = fine + (size_t)p * ld_fine + 1u + col;         // 4-byte aligned only: scalar loads
+      v = make_float4(f[0], f[1], f[2], f[3]);
+      if (q == 0 && raw) raw[(size_t)p * 4u + 3u] = f[-1];
+    } else if (code) {
+      const float d = gt_depth[p / S], zz = z[p];
+      const float front = zz < d * 0.95f ? 1.f : 0.f, back = zz > d * 1.05f ? 1.f : 0.f, pos = d > 0.f ? 1.f : 0.f;
+      const float t = (1.f - front) * (1.f - back) * pos;
+      const float4 cv = *reinterpret_cast<const float4*>(code + (size_t)p * C + (col - hidden));
+      v = make_float4(cv.x * t, cv.y * t, cv.z * t, cv.w * t);
+    } else {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *reinterpret_cast<float4*>(feat + (size_t)p * ld_feat + col) = v;
+  }
+}
+
+__device__ __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + expf(-x)); }
+
+// raw[p, 0:3] = sigmoid(raw[p, 0:3]) in place; column 3 (the occupancy logit) is left alone
+__global__ __launch_bounds__(256) void rgb_sigmoid_kernel(float4* __restrict__ raw, uint32_t P) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    float4 v = raw[p];
+    v.x = sigmoid1(v.x); v.y = sigmoid1(v.y); v.z = sigmoid1(v.z);
+    raw[p] = v;
+  }
+}
+
+// d_col[p, 0:3] = d_raw[p, 0:3] * s (1 - s)  (s = raw[p, 0:3], the sigmoid's output), d_col[p, 3] = 0;
+// d_occ[p * ld_occ] (+)= d_raw[p, 3]
+__global__ __launch_bounds__(256) void raw_bwd_kernel(const float4* __restrict__ d_raw, const float4* __restrict__ raw, uint32_t P,
+                                                      float4* __restrict__ d_col, float* __restrict__ d_occ, uint32_t ld_occ,
+                                                      uint32_t accumulate) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const float4 g = d_raw[p], s = raw[p];
+    d_col[p] = make_float4(g.x * (1.f - s.x) * s.x, g.y * (1.f - s.y) * s.y, g.z * (1.f - s.z) * s.z, 0.f);
+    float* o = d_occ + (size_t)p * ld_occ;
+    *o = accumulate ? *o + g.w : g.w;
+  }
+}
+
+// pts[i, j, k] = float( (c_mar + r_off * c_off + r_jit * c_vox) + (i, j, k) * c_vox )  in float64 -- the normalised
+// coordinates of the smoothness lattice (slams/mapping.py:133-143 folded to one affine map, Mapper.smoothness)
+struct LatticeConsts { double vox[3], off[3], mar[3]; };
+__global__ __launch_bounds__(256) void lattice_points_kernel(const float* __restrict__ r6, LatticeConsts c, uint32_t n,
+                                                             float* __restrict__ pts) {
+  const uint32_t total = n * n * n;
+  double b[3];
+  for (int a = 0; a < 3; ++a) {
+    const double t = c.mar[a] + (double)r6[a] * c.off[a];          // addcmul, then addcmul: two rounded steps each
+    b[a] = t + (double)r6[3 + a] * c.vox[a];
+  }
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
+    pts[3u * e + 0u] = (float)(b[0] + (double)i * c.vox[0]);
+    pts[3u * e + 1u] = (float)(b[1] + (double)j * c.vox[1]);
+    pts[3u * e + 2u] = (float)(b[2] + (double)k * c.vox[2]);
+  }
+}
+
+}  // namespace dns
+
+using namespace dns;
+
+static inline uint32_t grid_for(uint64_t n, uint32_t cap = 8192) {
+  const uint64_t b = (n + 255) / 256;
+  return (uint32_t)(b < cap ? (b ? b : 1) : cap);
+}
+
+extern "C" int dns_class_slots(const int64_t* labels, uint32_t N, uint32_t S, int tiled, const int64_t* lut, uint32_t n_lut,
+                               int64_t* slot_of_point, void* stream) {
+  if ((uint64_t)N * S == 0) return DNS_OK;
+  DNS_REQUIRE(labels && lut && slot_of_point, "dns_class_slots: NULL argument");
+  DNS_REQUIRE((uint64_t)N * S < (1ull << 31), "dns_class_slots: too many points");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(class_slots_kernel, dim3(grid_for((uint64_t)N * S)), dim3(256), 0, st, labels, N, S, tiled ? 1u : 0u, lut, n_lut,
+             slot_of_point);
+  return check_launch("dns_class_slots");
+}
+
+extern "C" int dns_feature_block(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C,
+                                 const float* z, const float* gt_depth, uint32_t N, uint32_t S, float* feat, uint32_t ld_feat,
+                                 float* raw, void* stream) {
+  const uint64_t P = (uint64_t)N * S;
+  if (P == 0) return DNS_OK;
+  DNS_REQUIRE(fine && feat, "dns_feature_block: NULL argument");
+  DNS_REQUIRE(P < (1ull << 31), "dns_feature_block: too many points");
+  DNS_REQUIRE(hidden % 4 == 0 && C % 4 == 0 && hidden + C > 0 && ld_feat % 4 == 0 && ld_feat >= hidden + C &&
+              ld_fine >= hidden + 1, "dns_feature_block: hidden %u / C %u / ld_feat %u / ld_fine %u", hidden, C, ld_feat, ld_fine);
+  DNS_REQUIRE(((uintptr_t)feat & 15) == 0 && (!code || ((uintptr_t)code & 15) == 0), "dns_feature_block: feat / code must be 16-byte aligned");
+  DNS_REQUIRE(!code || (z && gt_depth), "dns_feature_block: a code needs z and gt_depth");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(feature_block_kernel, dim3(grid_for(P * ((hidden + C) / 4), 16384)), dim3(256), 0, st, fine, ld_fine, hidden, code, C, z,
+             gt_depth, (uint32_t)P, S, feat, ld_feat, raw);
+  return check_launch("dns_feature_block");
+}
+
+extern "C" int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream) {
+  if (P == 0) return DNS_OK;
+  DNS_REQUIRE(raw && ((uintptr_t)raw & 15) == 0, "dns_rgb_sigmoid: raw must be a 16-byte aligned [P,4] array");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(rgb_sigmoid_kernel, dim3(grid_for(P)), dim3(256), 0, st, reinterpret_cast<float4*>(raw), P);
+  return check_launch("dns_rgb_sigmoid");
+}
+
+extern "C" int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, float* d_col, float* d_occ, uint32_t ld_occ,
+                           int accumulate, void* stream) {
+  if (P == 0) return DNS_OK;
+  DNS_REQUIRE(d_raw && raw && d_col && d_occ && ld_occ >= 1, "dns_raw_bwd: NULL argument");
+  DNS_REQUIRE((((uintptr_t)d_raw | (uintptr_t)raw | (uintptr_t)d_col) & 15) == 0, "dns_raw_bwd: [P,4] arrays must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(raw_bwd_kernel, dim3(grid_for(P)), dim3(256), 0, st, reinterpret_cast<const float4*>(d_raw),
+             reinterpret_cast<const float4*>(raw), P, reinterpret_cast<float4*>(d_col), d_occ, ld_occ, accumulate ? 1u : 0u);
+  return check_launch("dns_raw_bwd");
+}
+
+extern "C" int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, float* pts, void* stream) {
+  if (n == 0) return DNS_OK;
+  DNS_REQUIRE(r6 && consts9 && pts, "dns_lattice_points: NULL argument");
+  DNS_REQUIRE((uint64_t)n * n * n < (1ull << 30), "dns_lattice_points: lattice too large");
+  LatticeConsts c;
+  for (int a = 0; a < 3; ++a) { c.vox[a] = consts9[a]; c.off[a] = consts9[3 + a]; c.mar[a] = consts9[6 + a]; }
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(lattice_points_kernel, dim3(grid_for((uint64_t)n * n * n)), dim3(256), 0, st, r6, c, n, pts);
+  return check_launch("dns_lattice_points");
+}

@@ -132,17 +132,16 @@ class MapStep:
         self.tile_group = torch.empty(self.n_slots // 128, device=dev, dtype=torch.int32)
         self.group_ws = torch.empty(512, device=dev, dtype=torch.int32)
         self.feat = f(P, self.n_feat)
-        if self.features is None:
-            self.feat.zero_()                                             # the code columns stay zero
+        self.slot = torch.empty(P, device=dev, dtype=torch.int64)
         self.raw, self.logit = f(P, 4), f(P, self.n_class)
         self.depth, self.var, self.rgb, self.weights, self.sem = f(N), f(N), f(N, 3), f(N, S), f(N, self.n_class)
         self.sums_ws, self.out = f(ops.LOSS_SUMS_FLOATS), f(16)
         self.one = torch.ones(1, device=dev)
         self.d_color, self.d_depth, self.d_sem = f(N, 3), f(N), f(N, self.n_class)
-        self.d_fine, self.d_coarse = f(P, nf), f(P, nf)
+        self.d_coarse = f(P, nf)
         self.d_raw, self.d_logit, self.d_col = f(P, 4), f(P, self.n_class), f(P, 4)
-        self.d_buf, self.d_featx = f(P, ld), f(P, 4 + self.n_feat)
-        self.d_ft = f(P, nf)
+        self.d_buf = f(P, ld)
+        self.d_featx = torch.zeros(P, 4 + self.n_feat, device=dev)        # zeroed once: the code columns only accumulate
         self.d_x3 = f(P, 3)
         self.ray_ws = f(12 * K)
         raw_lib = ops.lib._raw
@@ -165,6 +164,9 @@ class MapStep:
             n = self.n_lat = sp - 1
             Pl = self.Pl = n ** 3
             self.bufl, self.occ, self.d_occ, self.d_bufl = f(Pl, ld), f(Pl, 1), f(Pl, 1), f(Pl, ld)
+            self.pts_l = f(Pl, 3)
+            _, c_vox, c_off, c_mar = m._lattice_consts                    # float64 [3] each, on the device: read once
+            self.lat_consts = (C.c_double * 9)(*[float(v) for t in (c_vox, c_off, c_mar) for v in t.cpu().tolist()])
             self.tv = f(1)
             self.w_sm = torch.full((1,), m.lambda_sm / self.world, device=dev)
             self.ws_mlp_l = mlp_ws(Pl, self.shp_c)
@@ -178,12 +180,10 @@ class MapStep:
     def _lattice_branch(self, r6, st):
         """Forward and backward of the smoothness term on the side stream: its loss weight is a constant, so its backward
         needs nothing from the ray branch."""
-        m, lib = self.m, ops.lib
-        _, c_vox, c_off, c_mar = m._lattice_consts
-        r = r6.to(torch.float64)
-        b = torch.addcmul(torch.addcmul(c_mar, r[:3], c_off), r[3:], c_vox)
-        pts = torch.addcmul(b, m._lattice, c_vox).reshape(-1, 3).float()
+        lib = ops.lib
         Pl, ld, pe = self.Pl, self.ld, self.pe_dim
+        pts = self.pts_l
+        check(lib.dns_lattice_points(ptr(r6), self.lat_consts, self.n_lat, ptr(pts), st), "dns_lattice_points")
         meta = C.byref(self.meta.c)
         grid_l = _V(self.bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
@@ -201,18 +201,11 @@ class MapStep:
         check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
                                  ptr(self.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),
               "dns_encode_bwd")
-        self._keep = pts                       # alive until the next step's side-stream work is behind it
-
-    def _code(self):
-        """The truncated per-sample code (slams/mapping.py:553-556) into the feature block's upper columns."""
-        d = self.gt_depth[:, None]
-        z = self.z
-        trunc = (1.0 - (z < d * 0.95).float()) * (1.0 - (z > d * 1.05).float()) * (d > 0.0).float()
-        torch.mul(self.features, trunc[..., None], out=self.feat.view(self.N, self.S, -1)[..., self.hid:])
 
     @torch.no_grad()
-    def step(self):
-        """One iteration; returns nothing (``losses()`` reads the terms of the last step)."""
+    def step(self, draws=None):
+        """One iteration; returns nothing (``losses()`` reads the terms of the last step).  ``draws``: {'pix': [K * n_per_frame]
+        int64 pixel indices, 'jitter': (t_surf, t_zero), 'r6': [6] lattice offset | jitter} instead of the generator's (tests)."""
         m, lib = self.m, ops.lib
         main = torch.cuda.current_stream()
         st = _V(main.cuda_stream)
@@ -221,7 +214,10 @@ class MapStep:
         # mapper.prefetch_draws: this step's draws were made on the side stream a step ago, the next ones are enqueued there
         # now; mapper.overlap_smooth: the lattice branch runs on the side stream (both off inside a one-stream graph capture)
         prefetch = getattr(m, "prefetch_draws", False)
-        d = m._take_draws(self.prep) if prefetch else m._draw_all(self.prep)
+        if draws is not None:
+            prefetch, d = False, draws
+        else:
+            d = m._take_draws(self.prep) if prefetch else m._draw_all(self.prep)
         pix, (t_surf, t_zero), r6 = d["pix"], d["jitter"], d["r6"]
         m._lattice_r6 = None
         on_side = self.smooth and getattr(m, "overlap_smooth", False)
@@ -262,22 +258,19 @@ class MapStep:
                                   nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, None, fp16, st), "dns_mlp_fwd")
 
         fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0)
-        if m.label_layout == "reference_tiled":
-            classes = self.gt_label.repeat(1, S).flatten(0, 1)             # :613 -- tiles, SURVEY D1
-        else:
-            classes = self.gt_label.repeat_interleave(S)
-        slot = m._class_slots(classes, False)
-        check(lib.dns_group_slots(ptr(slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(self.row_index),
+        lut = m.fine_decoders.lut(0)                                       # class id -> pool row; :613 tiles the labels
+        check(lib.dns_class_slots(ptr(self.gt_label), N, S, 1 if m.label_layout == "reference_tiled" else 0, ptr(lut), lut.numel(),
+                                  ptr(self.slot), st), "dns_class_slots")
+        check(lib.dns_group_slots(ptr(self.slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(self.row_index),
                                   ptr(self.tile_group), st), "dns_group_slots")
-        self.fine.zero_()
+        self.fine.zero_()                                                  # points without a network keep zeros (:592)
         fwd(None, 0, self.p_pool, self.shp_f, self.fine, self.row_index, self.tile_group, self.n_slots, self.p_pool.shape[-1])
-        self.feat[:, :self.hid] = self.fine[:, 1:]
-        if self.features is not None:
-            self._code()
+        # (latents | truncated 2-D code) for the colour / logit networks, occupancy into the compositing input (:553-556, :622-627)
+        check(lib.dns_feature_block(ptr(self.fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
+                                    ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
         fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0)
         fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0)
-        self.raw.sigmoid_()
-        self.raw[:, 3] = self.fine[:, 0]
+        check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
         # ---- compositing + losses (utils/common.py:506-537, slams/mapping.py:887-907)
         Cn, L = self.n_class, self.hid + 1
         check(lib.dns_composite_fwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
@@ -290,11 +283,16 @@ class MapStep:
             m.dist.allreduce_sums(self.sums_ws[:16])
         check(lib.dns_loss_finalize(lam, N, S, Cn, L, 0, ptr(self.sums_ws), ptr(self.out), st), "dns_loss_finalize")
 
-        # ---- backward
+        # ---- backward.  d_featx [P, 4 + n_feat]: column 3 = d occupancy, columns 4.. = the feature-block gradient of the colour /
+        # logit networks, so columns 3 .. 3 + L are the fine network's output gradient in one strided view.  The losses write
+        # their d_fine THERE, compositing adds d occupancy, the colour and logit networks add (+=) their feature gradients: no
+        # [P, L] sum kernel.  (The 2-D code's columns only ever accumulate; nothing reads them -- the code has no gradient.)
+        ldf = 4 + self.n_feat
+        d_fine_dst = _V(self.d_featx.data_ptr() + 4 * 3)
         check(lib.dns_loss_bwd(lam, N, S, Cn, L, 0, ptr(self.out), ptr(self.one), ptr(self.rgb), ptr(self.depth), None,
                                ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside),
                                ptr(self.fine), ptr(self.coarse), ptr(self.z), ptr(self.d_color), ptr(self.d_depth), None,
-                               ptr(self.d_sem), ptr(self.d_fine), ptr(self.d_coarse), st), "dns_loss_bwd")
+                               ptr(self.d_sem), d_fine_dst, ptr(self.d_coarse), ldf, st), "dns_loss_bwd")
         check(lib.dns_composite_bwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), None,
                                     ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), st),
               "dns_composite_bwd")
@@ -308,13 +306,11 @@ class MapStep:
 
         d_feat = self.d_featx[:, 4:]
         bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, self.g_coarse, None, None, P, 0, 0)
-        torch.ops.aten.sigmoid_backward.grad_input(self.d_raw, self.raw, grad_input=self.d_col)
-        self.d_featx[:, 3] = self.d_raw[:, 3]
-        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, self.g_color, None, None, P, 0, 1)
+        check(lib.dns_raw_bwd(ptr(self.d_raw), ptr(self.raw), P, ptr(self.d_col), d_fine_dst, ldf, 1, st), "dns_raw_bwd")
+        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, self.g_color, None, None, P, 0, 3)
         bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, self.g_logit, None, None, P, 0, 3)
-        torch.add(self.d_fine, self.d_featx[:, 3:3 + L], out=self.d_ft)
-        bwd(None, 0, self.d_ft, self.p_pool, self.shp_f, None, self.g_pool, self.row_index, self.tile_group, self.n_slots,
-            self.p_pool.shape[-1], 1)
+        bwd(None, 0, self.d_featx[:, 3:3 + L], self.p_pool, self.shp_f, None, self.g_pool, self.row_index, self.tile_group,
+            self.n_slots, self.p_pool.shape[-1], 1)
         work = None
         if self.world > 1:
             import torch.distributed as dist

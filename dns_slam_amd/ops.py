@@ -721,7 +721,7 @@ class _LossFn(torch.autograd.Function):
         check(lib.dns_loss_bwd(lam, N, S, Cn, L, tracker, ptr(out), ptr(g), ptr(pred_color), ptr(pred_depth), ptr(pred_var),
                                ptr(pred_logits), ptr(gt_color), ptr(gt_depth), ptr(gt_label), ptr(valid), ptr(fine),
                                ptr(coarse), ptr(z), ptr(d_color), ptr(d_depth), ptr(d_var), ptr(d_logits), ptr(d_fine),
-                               ptr(d_coarse), stream_ptr()), "dns_loss_bwd")
+                               ptr(d_coarse), 0, stream_ptr()), "dns_loss_bwd")
         return (d_color, d_depth, d_var, d_logits, d_fine, d_coarse) + (None,) * 8
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 5
+#define DNS_ABI_VERSION 6
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -228,7 +228,8 @@ int dns_composite_bwd(const float* raw, const float* z, const float* logits, uin
  * the buffer must hold DNS_LOSS_SUMS_FLOATS floats, the rest is reduction workspace),
  * dns_loss_finalize turns it into out[16] = {p, d, l, lt, fs, op, total, -, coefficients...},
  * dns_loss_bwd writes d(total * g_total)/d(inputs): d_color, d_depth, d_var (tracker; may be NULL), d_logits,
- * d_fine, d_coarse (overwritten). */
+ * d_fine, d_coarse (overwritten).  ldd_fine: row stride of d_fine in floats (0 = L, contiguous) -- lets the caller place the
+ * fine decoder's loss gradient straight into a wider row that later kernels add to (fused_step.MapStep). */
 #define DNS_LOSS_SUMS_FLOATS (32 + 5 * 1024)
 int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
                   const float* pred_color, const float* pred_depth, const float* pred_var, const float* pred_logits,
@@ -241,7 +242,7 @@ int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint3
                  const float* pred_var, const float* pred_logits, const float* gt_color, const float* gt_depth,
                  const int64_t* gt_label, const uint8_t* valid, const float* fine, const float* coarse, const float* z,
                  float* d_color, float* d_depth, float* d_var, float* d_logits, float* d_fine, float* d_coarse,
-                 void* stream);
+                 uint32_t ldd_fine, void* stream);
 
 /* ---- fused Adam --------------------------------------------------------------------------------
  * torch.optim.Adam.step with default betas / eps, no weight decay, no amsgrad (reference slams/mapping.py:464,910,
@@ -290,6 +291,29 @@ int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups,
 int dns_device_error(int clear);
 int dns_group_scatter(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t* cursor, uint32_t n_slots,
                       int32_t* row_index, void* stream);
+
+/* ---- glue of one mapping iteration as single launches (csrc/step.hip) ---------------------------
+ * Each replaces a handful of elementwise torch ops of the reference's iteration; used by dns_slam_amd/fused_step.py.
+ * dns_class_slots: slot_of_point[p] = lut[label of p] (-1 when the label is outside [0, n_lut)); the label of point p is
+ *   labels[p mod N] when tiled (the reference's gt_label.repeat(1, S) layout, slams/mapping.py:613), else labels[p / S].
+ * dns_feature_block: feat[p, 0:hidden] = fine[p, 1:1+hidden], feat[p, hidden:hidden+C] = code[p, :] * trunc(p) with
+ *   trunc = (1 - [z < 0.95 d]) (1 - [z > 1.05 d]) [d > 0], d = gt_depth[p / S] (slams/mapping.py:553-556; code NULL = zeros),
+ *   and raw[p, 3] = fine[p, 0] (raw [P,4], NULL = skip) -- the colour / logit networks' feature input (models/decoder.py:123)
+ *   and the occupancy column of the compositing input (slams/mapping.py:627).  hidden, C multiples of 4; feat, code 16-byte aligned.
+ * dns_rgb_sigmoid: raw[p, 0:3] = sigmoid(raw[p, 0:3]) in place (models/decoder.py:124), column 3 untouched.
+ * dns_raw_bwd: the backward of both: d_col[p, 0:3] = d_raw[p, 0:3] s (1 - s) with s = raw[p, 0:3], d_col[p, 3] = 0, and
+ *   d_occ[p * ld_occ] = (accumulate ? += : =) d_raw[p, 3].
+ * dns_lattice_points: normalised coordinates of the n^3 smoothness lattice (slams/mapping.py:133-143 as one float64 affine
+ *   map): pts[i,j,k] = float(mar + r6[0:3] * off + r6[3:6] * vox + (i,j,k) * vox); consts9 [host, 9 doubles] = vox, off, mar;
+ *   r6 [device, 6 floats] = the offset and jitter draws. */
+int dns_class_slots(const int64_t* labels, uint32_t N, uint32_t S, int tiled, const int64_t* lut, uint32_t n_lut,
+                    int64_t* slot_of_point, void* stream);
+int dns_feature_block(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C, const float* z,
+                      const float* gt_depth, uint32_t N, uint32_t S, float* feat, uint32_t ld_feat, float* raw, void* stream);
+int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream);
+int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, float* d_col, float* d_occ, uint32_t ld_occ, int accumulate,
+                void* stream);
+int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, float* pts, void* stream);
 
 /* ---- 2-D feature lookup (feature_matching / feature_searching, utils/common.py:632-673) --------
  * pts [P,3] world points, w2c [R,16] row-major world->camera of the R reference frames, K [host, 9 floats] intrinsics,

@@ -258,6 +258,62 @@ def test_rank_shards_equal_whole_batch_on_gpu(world, mode):
     assert max(errs) < 1e-4, errs          # fp32 sums in a different order; everything else is exact
 
 
+def _map_step_grads(ms):
+    return [g.detach().cpu().clone() for g in (ms.g_table, ms.g_coarse, ms.g_color, ms.g_logit, ms.g_pool, ms.g_quat[4:], ms.g_trans[3:])]
+
+
+def _map_step_worker(rank, world, port, q):
+    from dns_slam_amd.fused_step import MapStep
+    ctx = _init(rank, world, port)
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "per_ray")
+    mapper.dist = ctx
+    mapper.overlap_smooth = True
+    part = npf // world
+    mapper.rays_per_frame = (part, 0)                      # the buffers are sized for this rank's share
+    prep = mapper.prepare_frames(frames)
+    ms = MapStep(mapper, frames, ql, Tl, prep=prep)
+    shard = torch.cat([pix[f * npf + rank * part: f * npf + (rank + 1) * part] for f in range(4)])
+    r6 = torch.cat((u[0].reshape(-1), u[1].reshape(-1))).to("cuda:0")
+    ms.step(draws={"pix": shard, "jitter": jit, "r6": r6})
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put([g.numpy() for g in _map_step_grads(ms)] + [ms.out.cpu().numpy()])
+    ctx.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_map_step_rank_shards_equal_whole_batch_on_gpu():
+    """The fixed-launch-sequence iteration (fused_step.MapStep) under weak-mode data parallelism, 2 ranks over gloo on one GPU:
+    the all-reduced gradient buffer (early segment launched asynchronously after the MLP backward, late segment after the stream
+    join) and the loss terms (global numerators / denominators) equal the one-process step on the whole pixel list."""
+    from dns_slam_amd.fused_step import MapStep
+    world = 2
+    port = _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_map_step_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = [torch.from_numpy(a) for a in q.get(timeout=300)]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "per_ray")
+    part = npf // world
+    mapper.rays_per_frame = (world * part, 0)
+    prep = mapper.prepare_frames(frames)
+    ms = MapStep(mapper, frames, ql, Tl, prep=prep)
+    whole = torch.cat([pix[f * npf: f * npf + world * part] for f in range(4)])
+    r6 = torch.cat((u[0].reshape(-1), u[1].reshape(-1))).to("cuda:0")
+    ms.step(draws={"pix": whole, "jitter": jit, "r6": r6})
+    torch.cuda.synchronize()
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import rel_err
+    errs = [rel_err(a, b) for a, b in zip(got[:-1], _map_step_grads(ms))]
+    assert max(errs) < 1e-4, errs
+    assert rel_err(got[-1][:7], ms.out.cpu()[:7]) < 1e-5
+
+
 @pytest.mark.gpu
 def test_tv_slabs_sum_to_the_cube_on_gpu():
     """dns_tv_fwd / dns_tv_bwd with nx / halo: slab values and slab gradients (halo rows overlapping the next slab's first

@@ -104,3 +104,86 @@ def test_map_step_frozen_poses_and_single_frame():
     ms.write_back()
     assert ms.dydx is None and torch.equal(torch.stack([q.detach() for q in ql]), q0)
     assert float(ms.losses()[0]) < l0
+
+
+# ------------------------------------------------------------------------------------------------ the glue kernels (csrc/step.hip)
+def _lib():
+    from dns_slam_amd import ops
+    from dns_slam_amd._lib import check, ptr, stream_ptr
+    return ops.lib, check, ptr, stream_ptr
+
+
+@pytest.mark.parametrize("tiled", [1, 0])
+def test_class_slots_equals_the_reference_label_tiling(tiled):
+    lib, check, ptr, stream_ptr = _lib()
+    g = torch.Generator().manual_seed(3)
+    N, S = 97, 13
+    labels = torch.randint(-2, 12, (N,), generator=g)
+    lut = torch.full((10,), -1, dtype=torch.int64)
+    lut[[0, 2, 3, 7]] = torch.tensor([0, 1, 2, 3])
+    out = torch.empty(N * S, dtype=torch.int64, device=DEV)
+    lab_d, lut_d = labels.to(DEV), lut.to(DEV)
+    check(lib.dns_class_slots(ptr(lab_d), N, S, tiled, ptr(lut_d), 10, ptr(out), stream_ptr()), "dns_class_slots")
+    classes = labels.repeat(1, S).flatten(0, 1) if tiled else labels.repeat_interleave(S)      # slams/mapping.py:613 / per ray
+    want = torch.where((classes >= 0) & (classes < 10), lut[classes.clamp(0, 9)], torch.full_like(classes, -1))
+    assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("with_code", [True, False])
+def test_feature_block_rgb_sigmoid_and_their_backward(with_code):
+    lib, check, ptr, stream_ptr = _lib()
+    g = torch.Generator().manual_seed(4)
+    N, S, H, Cc = 50, 9, 32, 32
+    P = N * S
+    fine = torch.randn(P, H + 1, generator=g)
+    code = torch.rand(N, S, Cc, generator=g) * 2 - 1
+    d = torch.rand(N, generator=g) * 3
+    d[::7] = 0.0
+    z = d[:, None] * (0.8 + 0.4 * torch.rand(N, S, generator=g)) + 0.01
+    raw = torch.randn(P, 4, generator=g)
+    feat_d, raw_d = torch.empty(P, H + Cc, device=DEV), raw.to(DEV)
+    fine_d, code_d, z_d, d_d = fine.to(DEV), code.to(DEV), z.to(DEV), d.to(DEV)
+    check(lib.dns_feature_block(ptr(fine_d), H + 1, H, ptr(code_d) if with_code else None, Cc, ptr(z_d), ptr(d_d), N, S, ptr(feat_d),
+                                H + Cc, ptr(raw_d), stream_ptr()), "dns_feature_block")
+    check(lib.dns_rgb_sigmoid(ptr(raw_d), P, stream_ptr()), "dns_rgb_sigmoid")
+    dd = d[:, None]
+    trunc = (1.0 - (z < dd * 0.95).float()) * (1.0 - (z > dd * 1.05).float()) * (dd > 0.0).float()     # slams/mapping.py:553-556
+    assert 0.1 < float(trunc.mean()) < 0.9
+    want_code = (code * trunc[..., None]).reshape(P, Cc) if with_code else torch.zeros(P, Cc)
+    assert torch.equal(feat_d.cpu(), torch.cat((fine[:, 1:], want_code), -1))
+    want_raw = torch.cat((torch.sigmoid(raw[:, :3]), fine[:, 0:1]), -1)
+    assert_close(raw_d.cpu(), want_raw, rtol=1e-6, what="rgb sigmoid | occupancy")
+    # backward: d_col = d_raw * s (1 - s) on the colour columns, d occupancy added into a strided column
+    d_raw = torch.randn(P, 4, generator=g)
+    wide = torch.randn(P, 7, generator=g)
+    d_raw_d, wide_d, d_col = d_raw.to(DEV), wide.to(DEV), torch.empty(P, 4, device=DEV)
+    from ctypes import c_void_p
+    for acc in (1, 0):
+        w = wide_d.clone()
+        check(lib.dns_raw_bwd(ptr(d_raw_d), ptr(raw_d), P, ptr(d_col), c_void_p(w.data_ptr() + 4 * 3), 7, acc, stream_ptr()), "dns_raw_bwd")
+        s = want_raw[:, :3]
+        assert_close(d_col.cpu()[:, :3], d_raw[:, :3] * s * (1 - s), rtol=1e-6, what="sigmoid backward")
+        assert torch.equal(d_col.cpu()[:, 3], torch.zeros(P))
+        want_w = wide.clone()
+        want_w[:, 3] = wide[:, 3] + d_raw[:, 3] if acc else d_raw[:, 3]
+        assert torch.equal(w.cpu(), want_w)
+
+
+def test_lattice_points_equal_the_float64_affine_map():
+    lib, check, ptr, stream_ptr = _lib()
+    from ctypes import c_double
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    sp = cfg["training"]["smooth_pts"]
+    mapper._ensure_lattice(sp, 0.1, 0.05)
+    _, c_vox, c_off, c_mar = mapper._lattice_consts
+    r = torch.rand(6, device=DEV)
+    r64 = r.to(torch.float64)
+    b = torch.addcmul(torch.addcmul(c_mar, r64[:3], c_off), r64[3:], c_vox)                  # Mapper.smoothness, static_shapes
+    want = torch.addcmul(b, mapper._lattice, c_vox).reshape(-1, 3).float()
+    n = sp - 1
+    got = torch.empty(n ** 3, 3, device=DEV)
+    c9 = (c_double * 9)(*[float(v) for t in (c_vox, c_off, c_mar) for v in t.cpu().tolist()])
+    check(lib.dns_lattice_points(ptr(r), c9, n, ptr(got), stream_ptr()), "dns_lattice_points")
+    # float64 arithmetic rounded to float32 once: at most the last bit where torch contracts a multiply-add
+    assert float((got - want).abs().max()) <= 6e-8 * float(want.abs().max())
+    assert float((got != want).float().mean()) < 1e-3
