@@ -47,13 +47,33 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamBatch b, const float
   const float* __restrict__ g = b.g[t];
   float* __restrict__ m = b.m[t];
   float* __restrict__ v = b.v[t];
+  const float ob1 = 1.0f - beta1, ob2 = 1.0f - beta2;
+  if (i0 + 3u < n && (((uintptr_t)(p + i0) | (uintptr_t)(g + i0) | (uintptr_t)(m + i0) | (uintptr_t)(v + i0)) & 15u) == 0) {
+    // the common case: four 16-byte accesses instead of sixteen guarded dwords
+    const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
+    float4 m4 = *reinterpret_cast<const float4*>(m + i0), v4 = *reinterpret_cast<const float4*>(v + i0);
+    float4 p4 = *reinterpret_cast<const float4*>(p + i0);
+    const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
+    float me[4] = {m4.x, m4.y, m4.z, m4.w}, ve[4] = {v4.x, v4.y, v4.z, v4.w}, pe[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      me[e] = beta1 * me[e] + ob1 * ge[e];
+      ve[e] = beta2 * ve[e] + ob2 * ge[e] * ge[e];
+      const float denom = sqrtf(ve[e]) * inv_sqrt_bc2 + eps;
+      pe[e] -= step_size * (me[e] / denom);
+    }
+    *reinterpret_cast<float4*>(m + i0) = make_float4(me[0], me[1], me[2], me[3]);
+    *reinterpret_cast<float4*>(v + i0) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+    *reinterpret_cast<float4*>(p + i0) = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    return;
+  }
 #pragma unroll
   for (uint32_t e = 0; e < 4; ++e) {
     const uint32_t i = i0 + e;
     if (i < n) {
       const float gi = g[i];
-      const float mi = beta1 * m[i] + (1.0f - beta1) * gi;          // exp_avg.lerp_(grad, 1 - beta1)
-      const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float mi = beta1 * m[i] + ob1 * gi;                     // exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = beta2 * v[i] + ob2 * gi * gi;                // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
       m[i] = mi;
       v[i] = vi;
       const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;           // (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps)

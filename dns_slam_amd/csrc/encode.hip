@@ -438,25 +438,44 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
   const bool vec = ((ld & 3u) == 0) && ((((uintptr_t)d_grid) & 15u) == 0) && ((nf & 3u) == 0);
   float m = 0.f;
   bool bad = false;                                  // a NaN / Inf in the upstream gradient
-  for (uint32_t e = threadIdx.x; e < 256u * 8u; e += 256u) {
-    const uint32_t r = e >> 3, q = e & 7u;
-    const uint32_t p = p0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p < P && 4 * q < nf) {
-      const float* src = d_grid + (size_t)p * ld + 4 * q;
-      if (vec) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
+  if (vec) {
+    // all eight 16-byte loads of a thread are requested before the first is used (clamped addresses, no branch between
+    // them: a guarded load per trip made every trip wait its own memory round trip)
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t e = threadIdx.x + 256u * i;
+      const uint32_t r = e >> 3, q = e & 7u;
+      const uint32_t pc = min(p0 + r, P - 1u), qc = min(4u * q, nf - 4u);
+      v[i] = *reinterpret_cast<const float4*>(d_grid + (size_t)pc * ld + qc);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t e = threadIdx.x + 256u * i;
+      const uint32_t r = e >> 3, q = e & 7u;
+      if (!(p0 + r < P && 4u * q < nf)) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float* d = tile + r * LDT + 4 * q;
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+      bad = bad || !(fabsf(v[i].x) < INFINITY) || !(fabsf(v[i].y) < INFINITY) || !(fabsf(v[i].z) < INFINITY) || !(fabsf(v[i].w) < INFINITY);
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < 256u * 8u; e += 256u) {
+      const uint32_t r = e >> 3, q = e & 7u;
+      const uint32_t p = p0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < P && 4 * q < nf) {
+        const float* src = d_grid + (size_t)p * ld + 4 * q;
         v.x = src[0];
         if (4 * q + 1 < nf) v.y = src[1];
         if (4 * q + 2 < nf) v.z = src[2];
         if (4 * q + 3 < nf) v.w = src[3];
       }
+      float* d = tile + r * LDT + 4 * q;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      bad = bad || !(fabsf(v.x) < INFINITY) || !(fabsf(v.y) < INFINITY) || !(fabsf(v.z) < INFINITY) || !(fabsf(v.w) < INFINITY);
     }
-    float* d = tile + r * LDT + 4 * q;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    bad = bad || !(fabsf(v.x) < INFINITY) || !(fabsf(v.y) < INFINITY) || !(fabsf(v.z) < INFINITY) || !(fabsf(v.w) < INFINITY);
   }
   __syncthreads();
   const uint32_t p = p0 + threadIdx.x;

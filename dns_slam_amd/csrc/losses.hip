@@ -19,7 +19,8 @@ namespace dns {
 
 // sums[] layout
 enum { S_P = 0, S_D, S_L, S_LT, S_FS, S_OP, S_NV, S_ND, S_NFRONT, S_NOMASK, S_COUNT = 16,
-       S_TICKET = 16, S_PARTIALS = 32, S_MAX_BLOCKS = 1024 };   // workspace behind the 16 results: DNS_LOSS_SUMS_FLOATS
+       S_PARTIALS = 32, S_MAX_BLOCKS = 1024 };   // workspace behind the 16 results: DNS_LOSS_SUMS_FLOATS
+constexpr uint32_t LOSS_POINT_BLOCKS = 512;   // x 256 threads x 4 quads per trip; <= S_MAX_BLOCKS (5 partial sums each)
 // out[] layout: terms p,d,l,lt,fs,op, total ; coefficients
 enum { O_P = 0, O_D, O_L, O_LT, O_FS, O_OP, O_TOTAL, O_CP = 8, O_CD, O_CL, O_CLT, O_CFS, O_COP };
 
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void loss_ray_sums_kernel(LossCfg c, const flo
                                                             const float* __restrict__ gt_color,
                                                             const float* __restrict__ gt_depth,
                                                             const int64_t* __restrict__ gt_label,
-                                                            const uint8_t* __restrict__ valid, float* __restrict__ sums) {
+                                                            const uint8_t* __restrict__ valid, float* __restrict__ sums,
+                                                            uint32_t n_partials) {
   __shared__ float sh[4];
   const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
   float sp = 0.f, sd = 0.f, sl = 0.f, nv = 0.f, nd = 0.f;
@@ -88,6 +90,20 @@ __global__ __launch_bounds__(256) void loss_ray_sums_kernel(LossCfg c, const flo
   t = block_sum(sl, sh); if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + S_L, t);
   t = block_sum(nv, sh); if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + S_NV, t);
   t = block_sum(nd, sh); if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + S_ND, t);
+  // second stage of the point pass (loss_point_sums_kernel, launched BEFORE this kernel): workgroup 0 adds up the partial
+  // sums the point workgroups parked behind the results.  The kernel boundary orders the two -- no fence, no ticket counter
+  // (a device-scope release per workgroup, i.e. an L2 write-back on this multi-die part, was the point kernel's tail).
+  if (blockIdx.x == 0 && n_partials) {
+    const float* partial = sums + S_PARTIALS;
+    const int dst[5] = {S_LT, S_FS, S_OP, S_NFRONT, S_NOMASK};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float v = 0.f;
+      for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) v += partial[b * 5u + i];
+      const float tt = block_sum(v, sh);
+      if (threadIdx.x == 0) sums[dst[i]] = tt;               // only this workgroup writes these five words
+    }
+  }
 }
 
 __device__ __forceinline__ float sigmoid10f(float x) { return 1.0f / (1.0f + expf(-10.0f * x)); }
@@ -179,48 +195,33 @@ __global__ __launch_bounds__(256) void loss_point_sums_kernel(LossCfg c, const f
   const uint32_t Q = vec ? E / 4u : 0u;
   const float4* __restrict__ f4p = reinterpret_cast<const float4*>(fine);
   const float4* __restrict__ c4p = reinterpret_cast<const float4*>(coarse);
-  for (uint32_t q = gtid; q < Q; q += 2u * gstride) {
-    const uint32_t q2 = q + gstride;
-    const bool two = q2 < Q;
-    const float4 fa = f4p[q], ca = c4p[q];
-    float4 fb = make_float4(0.f, 0.f, 0.f, 0.f), cb = fb;
-    if (two) {
-      fb = f4p[q2];
-      cb = c4p[q2];
+  for (uint32_t q = gtid; q < Q; q += 4u * gstride) {
+    // four quads per trip, clamped indices: eight unconditional 16-byte loads requested together (128 B per lane in flight)
+    uint32_t qq[4];
+    float4 fv[4], cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      qq[u] = q + (uint32_t)u * gstride;
+      const uint32_t qc = qq[u] < Q ? qq[u] : q;
+      fv[u] = f4p[qc];
+      cv[u] = c4p[qc];
     }
-    loss_point_quad(c, 4u * q, fa, ca, z, gt_depth, valid, a);
-    if (two) loss_point_quad(c, 4u * q2, fb, cb, z, gt_depth, valid, a);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (qq[u] < Q) loss_point_quad(c, 4u * qq[u], fv[u], cv[u], z, gt_depth, valid, a);
   }
   for (uint32_t e = 4u * Q + gtid; e < E; e += gstride) {      // unaligned arrays / the last E % 4 elements
     const uint32_t p = e / c.L, k = e - p * c.L;
     loss_point_elem(c, fine[e], coarse[e], p, k, p / c.S, z, gt_depth, valid, a);
   }
-  // Two-stage reduction: every workgroup parks its 5 partial sums, the LAST one to finish (ticket counter) adds them
-  // up.  5 float atomics per workgroup on the same 5 words serialise at ~9 ns each: 33 us of this kernel's 67 at 768
-  // workgroups, 90 us at 2048 (measured).
+  // Two-stage reduction: every workgroup parks its 5 partial sums; loss_ray_sums_kernel (the next launch) adds them up.
+  // (5 float atomics per workgroup on the same 5 words serialise at ~9 ns each: 33 us of this kernel's 67 at 768 workgroups.)
   float* partial = sums + S_PARTIALS;
-  uint32_t* ticket = reinterpret_cast<uint32_t*>(sums + S_TICKET);
   const float vals[5] = {a.slt, a.sfs, a.sop, a.nfr, a.nom};
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const float t = block_sum(vals[i], sh);
     if (threadIdx.x == 0) partial[blockIdx.x * 5u + i] = t;
-  }
-  __shared__ uint32_t last;
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  const int dst[5] = {S_LT, S_FS, S_OP, S_NFRONT, S_NOMASK};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    float v = 0.f;
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) v += __builtin_nontemporal_load(partial + b * 5u + i);
-    const float t = block_sum(v, sh);
-    if (threadIdx.x == 0) sums[dst[i]] += t;
   }
 }
 
@@ -310,29 +311,72 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
   const uint32_t E = c.N * c.S * c.L;
   const float g = g_total[0];
   const float clt = g * out[O_CLT], cfs = g * out[O_CFS], cop = g * out[O_COP];
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+  // One aligned float4 of the flat [P * L] arrays per step, two steps per trip (four 16-byte loads requested together); the
+  // (point, channel, ray) of the quad's first element come from ONE pair of integer divisions and advance incrementally
+  // (a pair of divisions per ELEMENT was a third of this kernel's time).
+  auto elem = [&](uint32_t p, uint32_t k, uint32_t n, bool ok, float f, float co, float& df, float& dc) {
+    df = 0.f;
+    dc = 0.f;
+    if (!ok) return;
+    const float d0 = co - f;
+    dc = clt * d0;
+    df = -clt * d0;
+    if (k + 1 == c.L) {
+      const float d = gt_depth[n], zz = z[p];
+      const float occ = sigmoid10f(f);
+      const float front = zz < (d - c.truncation) ? 1.f : 0.f;
+      const float back = zz > (d + c.truncation) ? 1.f : 0.f;
+      const float dm = d > 0.f ? 1.f : 0.f;
+      const float om = (1.f - front) * (1.f - back) * dm;
+      const float r = (zz - d) / c.sigma;
+      const float pseudo = 0.5f * expf(-0.5f * r * r);
+      // d/docc of cfs/2*(occ*front*dm)^2 + cop/2*(occ*om - pseudo*om)^2, then occ' = 10 occ (1 - occ)
+      const float docc = cfs * (occ * front * dm) * (front * dm) + cop * (occ * om - pseudo * om) * om;
+      df += docc * 10.f * occ * (1.f - occ);
+    }
+  };
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const bool vec = ((((uintptr_t)fine) | ((uintptr_t)coarse) | ((uintptr_t)d_coarse)) & 15u) == 0;
+  const uint32_t Q = vec ? E / 4u : 0u;
+  const float4* __restrict__ f4p = reinterpret_cast<const float4*>(fine);
+  const float4* __restrict__ c4p = reinterpret_cast<const float4*>(coarse);
+  for (uint32_t q0 = gtid; q0 < Q; q0 += 2u * stride) {
+    const uint32_t q1 = q0 + stride;
+    const bool two = q1 < Q;
+    const uint32_t qq[2] = {q0, two ? q1 : q0};
+    const float4 fa[2] = {f4p[qq[0]], f4p[qq[1]]}, ca[2] = {c4p[qq[0]], c4p[qq[1]]};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      const uint32_t e0 = 4u * qq[u];
+      uint32_t p = e0 / c.L, k = e0 - p * c.L;
+      uint32_t n = p / c.S, sidx = p - n * c.S;
+      bool ok = ray_valid(valid, n);
+      const float fv[4] = {fa[u].x, fa[u].y, fa[u].z, fa[u].w}, cv[4] = {ca[u].x, ca[u].y, ca[u].z, ca[u].w};
+      float dcv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float df;
+        elem(p, k, n, ok, fv[j], cv[j], df, dcv[j]);
+        d_fine[(size_t)p * ldd_fine + k] = df;
+        if (++k == c.L) {                                  // next point (at most once per quad: L > 4 is not required, just likely)
+          k = 0;
+          ++p;
+          if (++sidx == c.S) {
+            sidx = 0;
+            ++n;
+            ok = n < c.N ? ray_valid(valid, n) : false;
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(d_coarse + e0) = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+    }
+  }
+  for (uint32_t e = 4u * Q + gtid; e < E; e += stride) {       // unaligned arrays / the last E % 4 elements
     const uint32_t p = e / c.L, k = e - p * c.L;
     const uint32_t n = p / c.S;
-    float df = 0.f, dc = 0.f;
-    if (ray_valid(valid, n)) {
-      const float f = fine[e];
-      const float d0 = coarse[e] - f;
-      dc = clt * d0;
-      df = -clt * d0;
-      if (k + 1 == c.L) {
-        const float d = gt_depth[n], zz = z[p];
-        const float occ = sigmoid10f(f);
-        const float front = zz < (d - c.truncation) ? 1.f : 0.f;
-        const float back = zz > (d + c.truncation) ? 1.f : 0.f;
-        const float dm = d > 0.f ? 1.f : 0.f;
-        const float om = (1.f - front) * (1.f - back) * dm;
-        const float r = (zz - d) / c.sigma;
-        const float pseudo = 0.5f * expf(-0.5f * r * r);
-        // d/docc of cfs/2*(occ*front*dm)^2 + cop/2*(occ*om - pseudo*om)^2, then occ' = 10 occ (1 - occ)
-        const float docc = cfs * (occ * front * dm) * (front * dm) + cop * (occ * om - pseudo * om) * om;
-        df += docc * 10.f * occ * (1.f - occ);
-      }
-    }
+    float df, dc;
+    elem(p, k, n, ray_valid(valid, n), fine[e], coarse[e], df, dc);
     d_fine[(size_t)p * ldd_fine + k] = df;
     d_coarse[e] = dc;
   }
@@ -359,7 +403,7 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
   DNS_REQUIRE(lambdas && sums, "dns_loss_sums: NULL argument");
   hipStream_t st = (hipStream_t)stream;
   {
-    const int rc = fill_words(sums, 0u, S_TICKET + 1, st, "dns_loss_sums");
+    const int rc = fill_words(sums, 0u, S_COUNT, st, "dns_loss_sums");
     if (rc != DNS_OK) return rc;
   }
   if (N == 0) return DNS_OK;
@@ -369,15 +413,16 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
   DNS_REQUIRE(tracker || (fine && coarse && z && L >= 1 && S >= 1), "dns_loss_sums: mapper mode needs fine, coarse, z");
   DNS_REQUIRE(tracker || (uint64_t)N * S * L < (1ull << 32) - (1ull << 22), "dns_loss_sums: N*S*L must stay below 2^32");
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
-  DNS_LAUNCH(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
-                     pred_logits, gt_color, gt_depth, gt_label, valid, sums);
+  uint32_t blocks = 0;
   if (!tracker) {
     const uint64_t E = (uint64_t)N * S * L;
-    // few, fat workgroups: every workgroup ends in 5 atomics on the same 5 words (same-address atomics serialise)
-    const uint32_t cap = S_MAX_BLOCKS;
-    const uint32_t blocks = (uint32_t)((E + 255) / 256 < cap ? (E + 255) / 256 : cap);
+    // few, fat workgroups: each parks 5 partial sums that workgroup 0 of the ray kernel (launched next) adds up
+    const uint32_t cap = LOSS_POINT_BLOCKS;
+    blocks = (uint32_t)((E + 255) / 256 < cap ? (E + 255) / 256 : cap);
     DNS_LAUNCH(loss_point_sums_kernel, dim3(blocks), dim3(256), 0, st, c, fine, coarse, z, gt_depth, valid, sums);
   }
+  DNS_LAUNCH(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
+                     pred_logits, gt_color, gt_depth, gt_label, valid, sums, blocks);
   return check_launch("dns_loss_sums");
 }
 

@@ -246,28 +246,36 @@ __global__ __launch_bounds__(256, 2) void mlp_dwin_kernel(DwinArgs a) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+          // unconditional loads on clamped slots, zeroed afterwards: a guarded load is a branch, and eight branches in a row
+          // keep the compiler from issuing the eight loads back to back (each then waits a memory round trip on its own)
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const uint32_t slot = slot0 + 16u * s + pt8 + j;
-            v[j] = slot < a.n_slots ? a.dh1[(size_t)slot * NN + 32 * t + ch] : 0.f;
+            v[j] = a.dh1[(size_t)min(slot, a.n_slots - 1u) * NN + 32 * t + ch];
           }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (slot0 + 16u * s + pt8 + j) < a.n_slots ? v[j] : 0.f;
           fa[t][s] = split8_bf3(v);
         }
 #pragma unroll
       for (int ct = 0; ct < IT; ++ct) {
-        const uint32_t col = 32u * ct + ch;
+        const uint32_t col_raw = 32u * ct + ch;
+        const bool col_ok = col_raw < n_in;
+        const uint32_t col = col_ok ? col_raw : n_in - 1u;                  // clamped: the load is unconditional (see above)
         const bool second = a.seg.x2 != nullptr && col >= a.seg.n_in1;
         const float* base = second ? a.seg.x2 + (col - a.seg.n_in1) : a.x + col;
         const uint32_t ld = second ? a.seg.ldx2 : a.ldx;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           float v[8];
+          int rowv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int row = rows_lds[16 * s + pt8 + j];
-            v[j] = (row >= 0 && col < n_in) ? base[(size_t)row * ld] : 0.f;
-          }
+          for (int j = 0; j < 8; ++j) rowv[j] = rows_lds[16 * s + pt8 + j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = base[(size_t)max(rowv[j], 0) * ld];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (rowv[j] >= 0 && col_ok) ? v[j] : 0.f;
           const Frag3 fb = split8_bf3(v);
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t][ct] = mma_pt<PREC>(fa[t][s], fb, acc[t][ct]);

@@ -281,8 +281,10 @@ __global__ __launch_bounds__(256) void sample_along_rays_kernel(const float* __r
 }
 
 // d_pts [n,S,3] (+ optional direct d_rays_o / d_rays_d) -> per-frame sums of dL/dR (9) and dL/dT (3).
-// grid = (ceil(npf/64), n_frames): a workgroup owns 64 rays of ONE frame (16 per wave, a wave reads a ray's
-// d_pts row coalesced), reduces in registers + LDS and issues 12 atomics.
+// grid = (ceil(npf / (4 RB_RAYS)), n_frames): a workgroup owns 4 * RB_RAYS rays of ONE frame (RB_RAYS per wave, a wave reads a
+// ray's d_pts row coalesced), reduces in registers + LDS and issues 12 atomics.  RB_RAYS = 2: 4096 rays give 512 workgroups
+// (16 rays per wave left three quarters of the CUs without work and each wave with 16 dependent reductions in a row: 26 us).
+constexpr int RB_RAYS = 2;
 __global__ __launch_bounds__(256) void raygen_bwd_reduce_kernel(const int64_t* __restrict__ pix_idx, Cam cam, int H0, int W0,
                                                                 int wwin, int n_frames, int npf, int S,
                                                                 const float* __restrict__ z, const float* __restrict__ d_pts,
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(256) void raygen_bwd_reduce_kernel(const int64_t* _
   float acc[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) acc[e] = 0.f;
-  for (int i = 0; i < 16; ++i) {
-    const int r = blockIdx.x * 64 + wave * 16 + i;
+  for (int i = 0; i < RB_RAYS; ++i) {
+    const int r = blockIdx.x * (4 * RB_RAYS) + wave * RB_RAYS + i;
     if (r >= npf) break;
     const int n = f * npf + r;
     float go[3] = {0.f, 0.f, 0.f}, gdv[3] = {0.f, 0.f, 0.f};
@@ -459,7 +461,7 @@ extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const d
     const int rc = fill_words(ws, 0u, (size_t)12 * n_frames, st, "dns_raygen_bwd");
     if (rc != DNS_OK) return rc;
   }
-  DNS_LAUNCH(raygen_bwd_reduce_kernel, dim3((n_per_frame + 63) / 64, n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
+  DNS_LAUNCH(raygen_bwd_reduce_kernel, dim3((n_per_frame + 4 * RB_RAYS - 1) / (4 * RB_RAYS), n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
                      n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);
   DNS_LAUNCH(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
   return check_launch("dns_raygen_bwd");

@@ -19,32 +19,32 @@ __global__ __launch_bounds__(256) void class_slots_kernel(const int64_t* __restr
 
 // feat[p] = (fine[p, 1 : 1 + hidden] | code[p] * trunc(p)),  raw[p, 3] = fine[p, 0]
 // trunc = (1 - [z < 0.95 d]) (1 - [z > 1.05 d]) [d > 0]   (slams/mapping.py:553-556; d = the ray's measured depth)
-// One thread per (point, 4-column group) of the output row.
+// One thread per (point, quad q): it moves latent quad q AND code quad q of the row (whichever exist), so that every lane of
+// a wave runs the same straight-line code and all its loads are requested before the first store.
 __global__ __launch_bounds__(256) void feature_block_kernel(const float* __restrict__ fine, uint32_t ld_fine, uint32_t hidden,
                                                             const float* __restrict__ code, uint32_t C,
                                                             const float* __restrict__ z, const float* __restrict__ gt_depth,
                                                             uint32_t P, uint32_t S, float* __restrict__ feat, uint32_t ld_feat,
                                                             float* __restrict__ raw) {
-  const uint32_t q_row = (hidden + C) / 4u;                // float4 groups per output row
-  const uint64_t total = (uint64_t)P * q_row;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t p = (uint32_t)(i / q_row), q = (uint32_t)(i - (uint64_t)p * q_row);
-    const uint32_t col = 4u * q;
-    float4 v;
-    if (col < hidden) {
-      const float* f = fine + (size_t)p * ld_fine + 1u + col;         // 4-byte aligned only: scalar loads
-      v = make_float4(f[0], f[1], f[2], f[3]);
-      if (q == 0 && raw) raw[(size_t)p * 4u + 3u] = f[-1];
-    } else if (code) {
+  const uint32_t qh = hidden / 4u, qc = C / 4u, qn = qh > qc ? qh : qc;       // quads per point handled by consecutive lanes
+  const uint32_t total = P * qn;                                             // < 2^32 (host check)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t p = i / qn, q = i - p * qn;
+    const bool lat = q < qh, cod = q < qc;
+    const float* f = fine + (size_t)p * ld_fine + 1u + 4u * (lat ? q : 0u);      // 4-byte aligned only: scalar loads
+    const float f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], occ = f[-1];
+    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float t = 0.f;
+    if (code) {
+      cv = *reinterpret_cast<const float4*>(code + (size_t)p * C + 4u * (cod ? q : 0u));
       const float d = gt_depth[p / S], zz = z[p];
       const float front = zz < d * 0.95f ? 1.f : 0.f, back = zz > d * 1.05f ? 1.f : 0.f, pos = d > 0.f ? 1.f : 0.f;
-      const float t = (1.f - front) * (1.f - back) * pos;
-      const float4 cv = *reinterpret_cast<const float4*>(code + (size_t)p * C + (col - hidden));
-      v = make_float4(cv.x * t, cv.y * t, cv.z * t, cv.w * t);
-    } else {
-      v = make_float4(0.f, 0.f, 0.f, 0.f);
+      t = (1.f - front) * (1.f - back) * pos;
     }
-    *reinterpret_cast<float4*>(feat + (size_t)p * ld_feat + col) = v;
+    float* o = feat + (size_t)p * ld_feat;
+    if (lat) *reinterpret_cast<float4*>(o + 4u * q) = make_float4(f0, f1, f2, f3);
+    if (cod) *reinterpret_cast<float4*>(o + hidden + 4u * q) = make_float4(cv.x * t, cv.y * t, cv.z * t, cv.w * t);
+    if (q == 0 && raw) raw[(size_t)p * 4u + 3u] = occ;
   }
 }
 
@@ -118,12 +118,14 @@ extern "C" int dns_feature_block(const float* fine, uint32_t ld_fine, uint32_t h
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(fine && feat, "dns_feature_block: NULL argument");
   DNS_REQUIRE(P < (1ull << 31), "dns_feature_block: too many points");
-  DNS_REQUIRE(hidden % 4 == 0 && C % 4 == 0 && hidden + C > 0 && ld_feat % 4 == 0 && ld_feat >= hidden + C &&
+  DNS_REQUIRE(hidden % 4 == 0 && C % 4 == 0 && hidden >= 4 && ld_feat % 4 == 0 && ld_feat >= hidden + C &&
               ld_fine >= hidden + 1, "dns_feature_block: hidden %u / C %u / ld_feat %u / ld_fine %u", hidden, C, ld_feat, ld_fine);
   DNS_REQUIRE(((uintptr_t)feat & 15) == 0 && (!code || ((uintptr_t)code & 15) == 0), "dns_feature_block: feat / code must be 16-byte aligned");
   DNS_REQUIRE(!code || (z && gt_depth), "dns_feature_block: a code needs z and gt_depth");
   hipStream_t st = (hipStream_t)stream;
-  DNS_LAUNCH(feature_block_kernel, dim3(grid_for(P * ((hidden + C) / 4), 16384)), dim3(256), 0, st, fine, ld_fine, hidden, code, C, z,
+  const uint32_t qn = (hidden > C ? hidden : C) / 4u;
+  DNS_REQUIRE(P * qn < (1ull << 32), "dns_feature_block: too many points");
+  DNS_LAUNCH(feature_block_kernel, dim3(grid_for(P * qn, 16384)), dim3(256), 0, st, fine, ld_fine, hidden, code, C, z,
              gt_depth, (uint32_t)P, S, feat, ld_feat, raw);
   return check_launch("dns_feature_block");
 }
