@@ -47,6 +47,7 @@ SIGNATURES = {
     "dns_rays_from_pixels": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dns_sample_along_rays": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "dns_raygen_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dns_raygen_bwd_ws_floats": (C.c_uint64, [_I, _I]),
     "dns_encode_fwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _P, _U, _P, _U, _P, _P]),
     "dns_encode_bwd": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _U, _P, _U, _P, _P, _P, _P, _U, _U, _P]),
     "dns_encode_bwd_ws_floats": (C.c_uint64, [_U, C.POINTER(DnsGridMeta), _U, _U]),

@@ -188,6 +188,8 @@ __global__ __launch_bounds__(256) void loss_point_sums_kernel(LossCfg c, const f
                                                               const uint8_t* __restrict__ valid,
                                                               float* __restrict__ sums) {
   __shared__ float sh[4];
+  // the 16 result words are cleared HERE (mapper mode): the ray kernel that adds into them is the next launch
+  if (blockIdx.x == 0 && threadIdx.x < S_COUNT) sums[threadIdx.x] = 0.f;
   const uint32_t E = c.N * c.S * c.L;               // < 2^32 (checked on the host): 32-bit divides, not 64-bit
   PointAcc a = {0.f, 0.f, 0.f, 0.f, 0.f};
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
@@ -402,7 +404,7 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
                              const float* z, float* sums, void* stream) {
   DNS_REQUIRE(lambdas && sums, "dns_loss_sums: NULL argument");
   hipStream_t st = (hipStream_t)stream;
-  {
+  if (tracker || N == 0) {                           // mapper mode: cleared by the point kernel
     const int rc = fill_words(sums, 0u, S_COUNT, st, "dns_loss_sums");
     if (rc != DNS_OK) return rc;
   }

@@ -338,16 +338,28 @@ __global__ __launch_bounds__(256) void raygen_bwd_reduce_kernel(const int64_t* _
     for (int e = 0; e < 12; ++e) part[wave][e] = acc[e];
   __syncthreads();
   if (threadIdx.x < 12) {
+    // the workgroup's 12 partial sums, parked: raygen_bwd_pose_kernel (the next launch) adds a frame's workgroups up -- no
+    // atomics on 12 shared words, and no zero fill of the workspace ahead of this kernel
     const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    atomicAdd(ws + 12 * f + threadIdx.x, v);
+    ws[((size_t)f * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = v;
   }
 }
 
-__global__ void raygen_bwd_pose_kernel(const float* __restrict__ quat, const float* __restrict__ ws, int n_frames,
-                                       float* __restrict__ d_quat, float* __restrict__ d_trans) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_frames) return;
-  const float* G = ws + 12 * f;
+// one wave per frame: sums the frame's n_part partial [12] vectors, then the quaternion chain rule on lane 0
+__global__ __launch_bounds__(64) void raygen_bwd_pose_kernel(const float* __restrict__ quat, const float* __restrict__ ws,
+                                                             int n_frames, int n_part, float* __restrict__ d_quat,
+                                                             float* __restrict__ d_trans) {
+  const int f = blockIdx.x;
+  float G[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    float v = 0.f;
+    for (int g = threadIdx.x; g < n_part; g += 64) v += ws[((size_t)f * n_part + g) * 12 + e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    G[e] = v;
+  }
+  if (threadIdx.x != 0) return;
   const float r = quat[4 * f], i = quat[4 * f + 1], j = quat[4 * f + 2], k = quat[4 * f + 3];
   const float nrm = r * r + i * i + j * j + k * k;
   const float two_s = 2.0f / nrm;
@@ -457,14 +469,16 @@ extern "C" int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const d
   const int n = n_frames * n_per_frame;
   if (n <= 0) return DNS_OK;
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int rc = fill_words(ws, 0u, (size_t)12 * n_frames, st, "dns_raygen_bwd");
-    if (rc != DNS_OK) return rc;
-  }
-  DNS_LAUNCH(raygen_bwd_reduce_kernel, dim3((n_per_frame + 4 * RB_RAYS - 1) / (4 * RB_RAYS), n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
+  const int n_part = (n_per_frame + 4 * RB_RAYS - 1) / (4 * RB_RAYS);          // == dns_raygen_bwd_ws_floats / (12 n_frames)
+  DNS_LAUNCH(raygen_bwd_reduce_kernel, dim3(n_part, n_frames), dim3(256), 0, st, pix_idx, make_cam(cam), H0, W0, W1 - W0,
                      n_frames, n_per_frame, S, z, d_pts, d_rays_o, d_rays_d, ws);
-  DNS_LAUNCH(raygen_bwd_pose_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, quat, ws, n_frames, d_quat, d_trans);
+  DNS_LAUNCH(raygen_bwd_pose_kernel, dim3(n_frames), dim3(64), 0, st, quat, ws, n_frames, n_part, d_quat, d_trans);
   return check_launch("dns_raygen_bwd");
+}
+
+extern "C" uint64_t dns_raygen_bwd_ws_floats(int n_frames, int n_per_frame) {
+  if (n_frames <= 0 || n_per_frame <= 0) return 0;
+  return (uint64_t)12 * (uint64_t)n_frames * (uint64_t)((n_per_frame + 4 * RB_RAYS - 1) / (4 * RB_RAYS));
 }
 
 extern "C" int dns_rays_from_pixels(const int64_t* pix_idx, const float* image, int C, const float* R, const float* T,

@@ -8,7 +8,12 @@ list of C-ABI calls (include/dns_hip.h) over buffers allocated ONCE, every gradi
 fill clears, the lattice (smoothness) branch -- forward AND backward, it meets the ray branch only in the parameter
 gradients -- runs on the side stream, and Adam (csrc/adam.hip) steps all parameters from a prebuilt tensor list.
 
-Same kernels, same arithmetic, same random draws (``Mapper._take_draws``) as the autograd path: tests/test_gpu_fused_step.py
+Everything that depends only on the random draws -- the draws themselves, the per-frame maximum of the sampled depths, the
+class -> decoder routing of every sample (``dns_class_slots`` + ``dns_group_slots``) and the zero fills of the buffers the step
+accumulates into -- is prepared ONE STEP AHEAD on the side stream into one of two alternating sets of buffers (``_Set``), so
+none of it sits on the main stream's chain of dependent kernels.
+
+Same kernels, same arithmetic, same random draws (``Mapper._draw_all``, same generator order) as the autograd path: tests/test_gpu_fused_step.py
 holds the two against each other (losses, every parameter after several iterations).  No CPU path: the constructor raises
 off-GPU like every op here.
 
@@ -28,6 +33,12 @@ from ._lib import DnsAdamTensor, check, ptr
 from .common import get_quad_from_c2w, get_rotation_from_quad
 
 _V = C.c_void_p
+
+
+class _Set:
+    """What one step's preparation writes: the gradient buffer (zeroed), the fine network's output (zeroed), the draws and what
+    derives from them alone (per-frame depth maximum, slot -> row table of the per-class routing)."""
+    pass
 
 
 class MapStep:
@@ -86,12 +97,9 @@ class MapStep:
             if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
                 raise ValueError("MapStep: parameters must be contiguous fp32 CUDA tensors")
         sizes = [(p.numel() + 3) // 4 * 4 for p in plist]                  # 16-byte aligned segments
-        self.G = torch.zeros(sum(sizes), device=dev)
         offs = [sum(sizes[:i]) for i in range(len(sizes))]
-        seg = lambda i: self.G[offs[i]:offs[i] + plist[i].numel()]
-        self.g_color, self.g_logit, self.g_pool, self.g_table, self.g_coarse, self.g_quat, self.g_trans = (seg(i) for i in range(7))
-        self.G_early, self.G_late = self.G[:offs[3]], self.G[offs[3]:]
-        self.M, self.V = torch.zeros_like(self.G), torch.zeros_like(self.G)
+        n_G = sum(sizes)
+        self.M, self.V = torch.zeros(n_G, device=dev), torch.zeros(n_G, device=dev)
         self.adam_state = torch.zeros(3, device=dev)
         lr_pose = float(m.BA_cam_lr) * float(self.is_BA)
         items = [(plist[i], offs[i], plist[i].numel(), float(m.lr)) for i in range(5)]
@@ -100,13 +108,16 @@ class MapStep:
             items.append((self.Q.view(-1)[a4:], offs[5] + a4, self.Q.numel() - a4, lr_pose))
             items.append((self.T.view(-1)[a3:], offs[6] + a3, self.T.numel() - a3, lr_pose))
         items = [it for it in items if it[2] > 0]
-        self.adam_items = (DnsAdamTensor * len(items))()
-        for k, (p, o, n, lr) in enumerate(items):
-            it = self.adam_items[k]
-            it.p, it.g = p.data_ptr(), self.G.data_ptr() + 4 * o
-            it.m, it.v = self.M.data_ptr() + 4 * o, self.V.data_ptr() + 4 * o
-            it.n, it.lr = n, lr
         self.n_adam = len(items)
+
+        def adam_items(G):
+            arr = (DnsAdamTensor * len(items))()
+            for k, (p, o, n, lr) in enumerate(items):
+                it = arr[k]
+                it.p, it.g = p.data_ptr(), G.data_ptr() + 4 * o
+                it.m, it.v = self.M.data_ptr() + 4 * o, self.V.data_ptr() + 4 * o
+                it.n, it.lr = n, lr
+            return arr
 
         # ---- ray-branch buffers
         npf = self.npf = self.prep["n1"] + self.prep["n2"]
@@ -120,19 +131,31 @@ class MapStep:
         self.gt_label = torch.empty(N, device=dev, dtype=torch.int64)
         self.inside = torch.empty(N, device=dev, dtype=torch.uint8)
         self.z, self.pts = f(N, S), f(N, S, 3)
-        self.dmax_ws = torch.empty(K, device=dev, dtype=torch.int32)
         ld = self.ld = self.pe_dim + self.grid_dim
         self.x3, self.buf = f(P, 3), f(P, ld)
         self.dydx = f(self.meta.n_levels * 3 * P * 2) if self.is_BA else None
         nf = self.hid + 1
-        self.coarse, self.fine = f(P, nf), f(P, nf)
+        self.coarse = f(P, nf)
         n_groups = self.n_groups = max(len(pool), 1)
         self.n_slots = (P + 127) // 128 * 128 + 128 * n_groups
-        self.row_index = torch.empty(self.n_slots, device=dev, dtype=torch.int32)
-        self.tile_group = torch.empty(self.n_slots // 128, device=dev, dtype=torch.int32)
         self.group_ws = torch.empty(512, device=dev, dtype=torch.int32)
         self.feat = f(P, self.n_feat)
         self.slot = torch.empty(P, device=dev, dtype=torch.int64)
+        # two alternating sets of everything a step's preparation writes (see _prepare)
+        self.sets = []
+        for _ in range(2):
+            st_ = _Set()
+            st_.G = torch.zeros(n_G, device=dev)
+            seg = lambda i: st_.G[offs[i]:offs[i] + plist[i].numel()]
+            st_.g_color, st_.g_logit, st_.g_pool, st_.g_table, st_.g_coarse, st_.g_quat, st_.g_trans = (seg(i) for i in range(7))
+            st_.G_early, st_.G_late = st_.G[:offs[3]], st_.G[offs[3]:]
+            st_.adam_items = adam_items(st_.G)
+            st_.fine = f(P, nf)
+            st_.row_index = torch.empty(self.n_slots, device=dev, dtype=torch.int32)
+            st_.tile_group = torch.empty(self.n_slots // 128, device=dev, dtype=torch.int32)
+            st_.ev, st_.draws, st_.dmax = None, None, None
+            self.sets.append(st_)
+        self.cur = self.sets[0]
         self.raw, self.logit = f(P, 4), f(P, self.n_class)
         self.depth, self.var, self.rgb, self.weights, self.sem = f(N), f(N), f(N, 3), f(N, S), f(N, self.n_class)
         self.sums_ws, self.out = f(ops.LOSS_SUMS_FLOATS), f(16)
@@ -143,8 +166,8 @@ class MapStep:
         self.d_buf = f(P, ld)
         self.d_featx = torch.zeros(P, 4 + self.n_feat, device=dev)        # zeroed once: the code columns only accumulate
         self.d_x3 = f(P, 3)
-        self.ray_ws = f(12 * K)
         raw_lib = ops.lib._raw
+        self.ray_ws = f(max(int(raw_lib.dns_raygen_bwd_ws_floats(K, npf)), 1))
         mlp_ws = lambda n_slots, s: f(max(int(raw_lib.dns_mlp_bwd_ws_floats(n_slots, s[2], s[3])), 4))
         self.ws_mlp = max((mlp_ws(self.n_slots, s) for s in (self.shp_f, self.shp_c, self.shp_col, self.shp_log)),
                           key=lambda t: t.numel())
@@ -177,13 +200,13 @@ class MapStep:
         self.steps = 0
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _lattice_branch(self, r6, st):
+    def _lattice_branch(self, cur, st):
         """Forward and backward of the smoothness term on the side stream: its loss weight is a constant, so its backward
         needs nothing from the ray branch."""
         lib = ops.lib
         Pl, ld, pe = self.Pl, self.ld, self.pe_dim
         pts = self.pts_l
-        check(lib.dns_lattice_points(ptr(r6), self.lat_consts, self.n_lat, ptr(pts), st), "dns_lattice_points")
+        check(lib.dns_lattice_points(ptr(cur.draws["r6"]), self.lat_consts, self.n_lat, ptr(pts), st), "dns_lattice_points")
         meta = C.byref(self.meta.c)
         grid_l = _V(self.bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
@@ -195,12 +218,35 @@ class MapStep:
         check(lib.dns_tv_bwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ), st),
               "dns_tv_bwd")
         check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
-                              ptr(self.d_bufl), ld, None, 0, ptr(self.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, None,
+                              ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, None,
                               self.fp16, st), "dns_mlp_bwd")
         d_grid_l = _V(self.d_bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
-                                 ptr(self.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),
+                                 ptr(cur.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),
               "dns_encode_bwd")
+
+    def _prepare(self, st_, stream, draws):
+        """Everything of a step that depends on the random draws alone, on the CURRENT stream (``stream`` = its handle): the
+        draws (utils/common.py:274,313-328,571-582; slams/mapping.py:137-143 -- ``Mapper._draw_all``, the generator order of the
+        autograd path), the per-frame maximum of the sampled depths (:581,591; all-reduced MAX over the ranks), the routing of
+        every sample to its class's decoder (slams/mapping.py:590-601,613) and the zero fills of what the step adds into."""
+        m, lib = self.m, ops.lib
+        K, npf, N, S, P = self.K, self.npf, self.N, self.S, self.P
+        d = draws if draws is not None else m._draw_all(self.prep)
+        st_.draws = d
+        pix = d["pix"].reshape(K, npf)
+        dmax = torch.gather(self.prep["depth"].reshape(K, -1), 1, pix).amax(dim=1).clamp_min(0.0)
+        if self.world > 1:
+            m.dist.allreduce_max(dmax)
+        st_.dmax = dmax.float().contiguous().view(torch.int32)             # bit patterns, as dns_raygen_sample takes them
+        labels = torch.gather(self.prep["label"].reshape(K, -1), 1, pix).reshape(-1).long()      # = the gt_label raygen writes
+        lut = m.fine_decoders.lut(0)                                       # class id -> pool row; :613 tiles the labels (SURVEY D1)
+        check(lib.dns_class_slots(ptr(labels), N, S, 1 if m.label_layout == "reference_tiled" else 0, ptr(lut), lut.numel(),
+                                  ptr(self.slot), stream), "dns_class_slots")
+        check(lib.dns_group_slots(ptr(self.slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(st_.row_index),
+                                  ptr(st_.tile_group), stream), "dns_group_slots")
+        st_.fine.zero_()                                                   # points without a network keep zeros (:592)
+        st_.G.zero_()
 
     @torch.no_grad()
     def step(self, draws=None):
@@ -210,40 +256,43 @@ class MapStep:
         main = torch.cuda.current_stream()
         st = _V(main.cuda_stream)
         K, npf, N, S, P, ld, pe = self.K, self.npf, self.N, self.S, self.P, self.ld, self.pe_dim
-        self.G.zero_()
-        # mapper.prefetch_draws: this step's draws were made on the side stream a step ago, the next ones are enqueued there
+        # mapper.prefetch_draws: this step's set was prepared on the side stream a step ago and the next one is prepared there
         # now; mapper.overlap_smooth: the lattice branch runs on the side stream (both off inside a one-stream graph capture)
-        prefetch = getattr(m, "prefetch_draws", False)
-        if draws is not None:
-            prefetch, d = False, draws
+        prefetch = getattr(m, "prefetch_draws", False) and draws is None
+        cur = self.sets[self.steps % 2]
+        if not prefetch or cur.ev is None:
+            self._prepare(cur, st, draws)              # first step / no prefetch / given draws: in line, on the main stream
         else:
-            d = m._take_draws(self.prep) if prefetch else m._draw_all(self.prep)
-        pix, (t_surf, t_zero), r6 = d["pix"], d["jitter"], d["r6"]
-        m._lattice_r6 = None
+            main.wait_event(cur.ev)
+        cur.ev = None
+        self.cur = cur
+        pix, (t_surf, t_zero) = cur.draws["pix"], cur.draws["jitter"]
         on_side = self.smooth and getattr(m, "overlap_smooth", False)
+        if on_side or prefetch:
+            self.side.wait_stream(main)                # behind the last Adam step and the last reads of the other set's buffers
         if on_side:
-            if not prefetch:
-                self.side.wait_stream(main)    # (_take_draws has done it): after the gradient fill and the last Adam step
             with torch.cuda.stream(self.side):
-                self._lattice_branch(r6, _V(self.side.cuda_stream))
+                self._lattice_branch(cur, _V(self.side.cuda_stream))
         elif self.smooth:
-            self._lattice_branch(r6, st)
+            self._lattice_branch(cur, st)
+        if prefetch:
+            nxt = self.sets[(self.steps + 1) % 2]
+            with torch.cuda.stream(self.side):
+                self._prepare(nxt, _V(self.side.cuda_stream), None)
+                nxt.ev = torch.cuda.Event()
+                nxt.ev.record(self.side)
+            for t in (nxt.draws["pix"], nxt.draws["jitter"][0], nxt.draws["jitter"][1], nxt.dmax):
+                t.record_stream(main)                  # allocated on the side stream, read by the main stream next step
 
         # ---- rays, samples (utils/common.py:248-264, 561-599)
-        dmax = None
-        if self.world > 1:
-            dmax = torch.gather(self.prep["depth"].reshape(K, -1), 1, pix.reshape(K, npf)).amax(dim=1).clamp_min(0.0)
-            m.dist.allreduce_max(dmax)
-            dmax = dmax.float().contiguous().view(torch.int32)
         jstride = self.ns if t_surf.dim() == 2 else 0
         prep = self.prep
         H, W = m.H, m.W
         check(lib.dns_raygen_sample(ptr(pix), ptr(prep["color"]), ptr(prep["depth"]), ptr(prep["label"]), ptr(self.Q),
                                     ptr(self.T), self.camv, self.b6, H, W, 0, H, 0, W, K, npf, ptr(m.t_uniform), ptr(t_surf),
-                                    ptr(t_zero), self.nu, self.ns, jstride, ptr(self.dmax_ws if dmax is None else dmax),
-                                    0 if dmax is None else 1, ptr(self.rays_o), ptr(self.rays_d), ptr(self.gt_color),
-                                    ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(self.z), ptr(self.pts), st),
-              "dns_raygen_sample")
+                                    ptr(t_zero), self.nu, self.ns, jstride, ptr(cur.dmax), 1, ptr(self.rays_o), ptr(self.rays_d),
+                                    ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(self.z),
+                                    ptr(self.pts), st), "dns_raygen_sample")
         # ---- encoding (slams/mapping.py:608 + models/decoder.py:45-48)
         meta = C.byref(self.meta.c)
         grid = _V(self.buf.data_ptr() + 4 * pe)
@@ -258,15 +307,10 @@ class MapStep:
                                   nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, None, fp16, st), "dns_mlp_fwd")
 
         fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0)
-        lut = m.fine_decoders.lut(0)                                       # class id -> pool row; :613 tiles the labels
-        check(lib.dns_class_slots(ptr(self.gt_label), N, S, 1 if m.label_layout == "reference_tiled" else 0, ptr(lut), lut.numel(),
-                                  ptr(self.slot), st), "dns_class_slots")
-        check(lib.dns_group_slots(ptr(self.slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(self.row_index),
-                                  ptr(self.tile_group), st), "dns_group_slots")
-        self.fine.zero_()                                                  # points without a network keep zeros (:592)
-        fwd(None, 0, self.p_pool, self.shp_f, self.fine, self.row_index, self.tile_group, self.n_slots, self.p_pool.shape[-1])
+        fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
+        fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1])
         # (latents | truncated 2-D code) for the colour / logit networks, occupancy into the compositing input (:553-556, :622-627)
-        check(lib.dns_feature_block(ptr(self.fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
+        check(lib.dns_feature_block(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
                                     ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
         fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0)
         fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0)
@@ -277,7 +321,7 @@ class MapStep:
                                     ptr(self.rgb), ptr(self.weights), ptr(self.sem), st), "dns_composite_fwd")
         lam = self.lam
         check(lib.dns_loss_sums(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
-                                ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(self.fine), ptr(self.coarse),
+                                ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(fine), ptr(self.coarse),
                                 ptr(self.z), ptr(self.sums_ws), st), "dns_loss_sums")
         if self.world > 1:
             m.dist.allreduce_sums(self.sums_ws[:16])
@@ -291,7 +335,7 @@ class MapStep:
         d_fine_dst = _V(self.d_featx.data_ptr() + 4 * 3)
         check(lib.dns_loss_bwd(lam, N, S, Cn, L, 0, ptr(self.out), ptr(self.one), ptr(self.rgb), ptr(self.depth), None,
                                ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside),
-                               ptr(self.fine), ptr(self.coarse), ptr(self.z), ptr(self.d_color), ptr(self.d_depth), None,
+                               ptr(fine), ptr(self.coarse), ptr(self.z), ptr(self.d_color), ptr(self.d_depth), None,
                                ptr(self.d_sem), d_fine_dst, ptr(self.d_coarse), ldf, st), "dns_loss_bwd")
         check(lib.dns_composite_bwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), None,
                                     ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), st),
@@ -305,35 +349,44 @@ class MapStep:
                                   stride, None, acc | fp16, st), "dns_mlp_bwd")
 
         d_feat = self.d_featx[:, 4:]
-        bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, self.g_coarse, None, None, P, 0, 0)
+        bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, cur.g_coarse, None, None, P, 0, 0)
         check(lib.dns_raw_bwd(ptr(self.d_raw), ptr(self.raw), P, ptr(self.d_col), d_fine_dst, ldf, 1, st), "dns_raw_bwd")
-        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, self.g_color, None, None, P, 0, 3)
-        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, self.g_logit, None, None, P, 0, 3)
-        bwd(None, 0, self.d_featx[:, 3:3 + L], self.p_pool, self.shp_f, None, self.g_pool, self.row_index, self.tile_group,
+        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, cur.g_color, None, None, P, 0, 3)
+        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, cur.g_logit, None, None, P, 0, 3)
+        bwd(None, 0, self.d_featx[:, 3:3 + L], self.p_pool, self.shp_f, None, cur.g_pool, row_index, tile_group,
             self.n_slots, self.p_pool.shape[-1], 1)
         work = None
         if self.world > 1:
             import torch.distributed as dist
-            work = dist.all_reduce(self.G_early, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
+            work = dist.all_reduce(cur.G_early, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
         d_grid = _V(self.d_buf.data_ptr() + 4 * pe)
         check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld, d_grid, ld,
-                                 ptr(self.g_table), ptr(self.d_x3) if self.is_BA else None, ptr(self.dydx), ptr(self.ws_enc),
+                                 ptr(cur.g_table), ptr(self.d_x3) if self.is_BA else None, ptr(self.dydx), ptr(self.ws_enc),
                                  self.scatter_form, self.scatter_cap, st), "dns_encode_bwd")
         if self.is_BA:
             check(lib.dns_raygen_bwd(ptr(pix), ptr(self.Q), self.camv, 0, H, 0, W, K, npf, S, ptr(self.z), ptr(self.d_x3), None,
-                                     None, ptr(self.ray_ws), ptr(self.g_quat), ptr(self.g_trans), st), "dns_raygen_bwd")
+                                     None, ptr(self.ray_ws), ptr(cur.g_quat), ptr(cur.g_trans), st), "dns_raygen_bwd")
         if on_side:
             main.wait_stream(self.side)
         if self.world > 1:
             import torch.distributed as dist
-            work2 = dist.all_reduce(self.G_late, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
+            work2 = dist.all_reduce(cur.G_late, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
             work.wait()
             work2.wait()
-        check(lib.dns_adam_step(self.adam_items, self.n_adam, self.betas[0], self.betas[1], self.eps, ptr(self.adam_state), st),
+        check(lib.dns_adam_step(cur.adam_items, self.n_adam, self.betas[0], self.betas[1], self.eps, ptr(self.adam_state), st),
               "dns_adam_step")
         self.steps += 1
 
     # ------------------------------------------------------------------------------------------------------------------
+    # the last step's gradient segments (tests, inspection)
+    g_table = property(lambda self: self.cur.g_table)
+    g_coarse = property(lambda self: self.cur.g_coarse)
+    g_color = property(lambda self: self.cur.g_color)
+    g_logit = property(lambda self: self.cur.g_logit)
+    g_pool = property(lambda self: self.cur.g_pool)
+    g_quat = property(lambda self: self.cur.g_quat)
+    g_trans = property(lambda self: self.cur.g_trans)
+
     def losses(self):
         """(total, terms) of the last step, as ``Mapper.iteration_loss`` returns them (device tensors, no sync)."""
         t = self.out

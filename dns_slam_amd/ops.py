@@ -25,7 +25,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._raw, name)
-        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_last_error",
+        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_raygen_bwd_ws_floats", "dns_last_error",
                                             "dns_abi_version", "dns_init") or name.startswith("dns_kernel_timing"):
             return fn
 
@@ -586,7 +586,7 @@ class _RaygenFn(torch.autograd.Function):
         dev = quat.device
         d_quat = torch.zeros(K, 4, device=dev)
         d_trans = torch.zeros(K, 3, device=dev)
-        ws = torch.empty(12 * K, device=dev)
+        ws = torch.empty(max(int(lib.dns_raygen_bwd_ws_floats(K, npf)), 1), device=dev)
         c = lambda t: None if t is None else t.contiguous()
         check(lib.dns_raygen_bwd(ptr(pix_idx), ptr(quat), camv, H0, H1, W0, W1, K, npf, S, ptr(z), ptr(c(d_pts)),
                                  ptr(c(d_ro)), ptr(c(d_rd)), ptr(ws), ptr(d_quat), ptr(d_trans), stream_ptr()),

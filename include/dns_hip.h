@@ -119,11 +119,13 @@ int dns_sample_along_rays(const float* gt_depth, const double* far_bb, int n_ray
 
 /* Backward of the ray generation w.r.t. the pose (autograd of pts = o + d*z, get_rays_from_uv and
  * quad2rotation, utils/common.py:248-264,406-429): d_quat [K,4] (+=), d_trans [K,3] (+=) from d_pts [n,S,3]
- * and/or direct d_rays_o / d_rays_d [n,3] (each may be NULL).  ws: 12*K floats of scratch. */
+ * and/or direct d_rays_o / d_rays_d [n,3] (each may be NULL).  ws: dns_raygen_bwd_ws_floats(K, n_per_frame) floats of scratch
+ * (one [12] partial sum per workgroup: no atomics, nothing to clear). */
 int dns_raygen_bwd(const int64_t* pix_idx, const float* quat, const double* cam,
                    int H0, int H1, int W0, int W1, int n_frames, int n_per_frame, int S,
                    const float* z, const float* d_pts, const float* d_rays_o, const float* d_rays_d,
                    float* ws, float* d_quat, float* d_trans, void* stream);
+uint64_t dns_raygen_bwd_ws_floats(int n_frames, int n_per_frame);
 
 /* ---- point encoding: OneBlob + hash grid ---------------------------------------------------
  * Replaces Pos_Encoding.forward (models/decoder.py:45-48) = tcnn OneBlob (pos_encoding.py:61-71)
