@@ -270,12 +270,15 @@ class MapStep:
         on_side = self.smooth and getattr(m, "overlap_smooth", False)
         if on_side or prefetch:
             self.side.wait_stream(main)                # behind the last Adam step and the last reads of the other set's buffers
+        # (host order: the side stream's launches go out first.  Measured against "main stream's first launches first" and
+        # "next set's preparation after the forward": 2.06 / 2.08 / 2.09 ms per step at cfg2 -- the lattice branch and the ~20
+        # tiny preparation kernels overlap best with the ray branch's long FORWARD kernels, not with its backward.)
         if on_side:
             with torch.cuda.stream(self.side):
                 self._lattice_branch(cur, _V(self.side.cuda_stream))
         elif self.smooth:
             self._lattice_branch(cur, st)
-        if prefetch:
+        if prefetch:                                   # the next step's set, behind the lattice branch on the side stream
             nxt = self.sets[(self.steps + 1) % 2]
             with torch.cuda.stream(self.side):
                 self._prepare(nxt, _V(self.side.cuda_stream), None)
@@ -378,6 +381,11 @@ class MapStep:
         self.steps += 1
 
     # ------------------------------------------------------------------------------------------------------------------
+    def set_lambda_lt(self, value):
+        """Weight of the latent loss for the following steps (slams/mapping.py:893-896: 0 in the first half of an optimize()
+        that added decoders)."""
+        self.lam[3] = float(value)
+
     # the last step's gradient segments (tests, inspection)
     g_table = property(lambda self: self.cur.g_table)
     g_coarse = property(lambda self: self.cur.g_coarse)

@@ -126,6 +126,7 @@ class Mapper:
         self.dist = None                                 # dns_slam_amd.dist.DistCtx for ray-batch data parallelism
         self.static_shapes = False                       # True: sync-free iteration (hipGraph-capturable)
         self.fused_losses = True                         # one HIP loss pass instead of ~60 torch launches
+        self.use_map_step = False                        # True (+ static_shapes): optimize_frames runs fused_step.MapStep
         net_cfg = decoder.coarse_fn.decoder.network_config
         self.fine_decoders = FineDecoderPool(self.pe_dim + self.grid_dim, self.hidden_dim + 1, net_cfg, device=device)
         self.exist_decoders: Dict[int, int] = {}
@@ -909,15 +910,25 @@ class Mapper:
         optimizer.param_groups[2]["lr"] = self.BA_cam_lr * self.is_BA
         prep = self.prepare_frames(target_frames)
         terms = {}
+        lt_of = lambda it: (10 if it > n_iters // 2 else 0) if len(new_decoder_idx) > 0 else 10
+        if getattr(self, "use_map_step", False) and self.static_shapes and self.fused_losses and \
+                (features is None or features.dim() == 3) and not (self.dist is not None and self.dist.union):
+            # the same iterations as the loop below as a fixed launch sequence over preallocated buffers (fused_step.MapStep:
+            # no autograd graph, draws and routing prepared a step ahead on the side stream); Adam state lives in the MapStep
+            from .fused_step import MapStep
+            ms = MapStep(self, target_frames, quad_list, T_list, prep=prep, features=features, smooth=smooth)
+            for iter_ in range(n_iters):
+                ms.set_lambda_lt(lt_of(iter_))
+                ms.step()
+            ms.write_back()
+            if n_iters > 0:
+                _, terms = ms.losses()
+            n_iters = 0
         for iter_ in range(n_iters):
             optimizer.zero_grad()
             samples = self.get_target_samples(target_frames, quad_list, T_list, refer_frames=refer_frames, features=features,
                                               prep=prep)
-            if len(new_decoder_idx) > 0:
-                lambda_lt = 10 if iter_ > n_iters // 2 else 0
-            else:
-                lambda_lt = 10
-            loss, terms = self.iteration_loss(samples, lambda_lt=lambda_lt, smooth=smooth)
+            loss, terms = self.iteration_loss(samples, lambda_lt=lt_of(iter_), smooth=smooth)
             loss.backward()
             optimizer.step()
         bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self.device)

@@ -106,6 +106,29 @@ def test_map_step_frozen_poses_and_single_frame():
     assert float(ms.losses()[0]) < l0
 
 
+def test_optimize_frames_through_map_step():
+    """``Mapper.optimize_frames`` with ``use_map_step``: the reference's driver (set_decoder, the lambda_lt schedule of
+    slams/mapping.py:893-896, pose write-back :914-926) around the fixed launch sequence -- same result as the autograd loop."""
+    out = []
+    for use in (False, True):
+        cfg, bound, cam, frames, dec, mapper = _setup()
+        mapper.fine_decoders.slot.pop(max(mapper.fine_decoders.slot))            # one class gets its decoder in this call:
+        mapper.exist_decoders.pop(max(mapper.exist_decoders))                    # lambda_lt = 0 for the first half
+        mapper.fine_decoders._lut = None
+        mapper.static_shapes, mapper.overlap_smooth, mapper.prefetch_draws, mapper.use_map_step = True, True, True, use
+        frames = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in frames.items()}
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        c2w, terms = mapper.optimize_frames(8, 20, frames)
+        torch.cuda.synchronize()
+        out.append((c2w.cpu(), {k: float(v) for k, v in terms.items()}, dec.coarse_fn.decoder.params.detach().cpu().clone()))
+    (ca, ta, pa), (cb, tb, pb) = out
+    assert_close(cb, ca, rtol=2e-4, what="optimize_frames pose: MapStep vs autograd")
+    for k in ta:
+        assert abs(ta[k] - tb[k]) <= 2e-4 * max(abs(ta[k]), 1e-6), (k, ta[k], tb[k])
+    assert float((pa - pb).abs().max()) <= 1e-4 * float(pa.abs().max()) + 0.05 * 8 * 0.005
+
+
 # ------------------------------------------------------------------------------------------------ the glue kernels (csrc/step.hip)
 def _lib():
     from dns_slam_amd import ops
