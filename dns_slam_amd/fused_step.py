@@ -232,7 +232,12 @@ class MapStep:
         every sample to its class's decoder (slams/mapping.py:590-601,613) and the zero fills of what the step adds into."""
         m, lib = self.m, ops.lib
         K, npf, N, S, P = self.K, self.npf, self.N, self.S, self.P
-        d = draws if draws is not None else m._draw_all(self.prep)
+        if draws is not None:
+            d = draws
+        elif self.smooth:
+            d = m._draw_all(self.prep)
+        else:                                          # no lattice: no lattice draw (the autograd path makes none either)
+            d = {"pix": m.draw_pixels(self.prep), "jitter": m.draw_jitter(), "r6": None}
         st_.draws = d
         pix = d["pix"].reshape(K, npf)
         dmax = torch.gather(self.prep["depth"].reshape(K, -1), 1, pix).amax(dim=1).clamp_min(0.0)

@@ -106,6 +106,38 @@ def test_map_step_frozen_poses_and_single_frame():
     assert float(ms.losses()[0]) < l0
 
 
+def test_map_step_without_smoothness_and_single_stream():
+    """smooth=False (decoder_init-style iterations) and the one-stream mode (no side stream, no prefetch: what a hipGraph capture
+    of the step uses) against the autograd iteration."""
+    from dns_slam_amd.fused_step import MapStep
+    out = []
+    for fused in (False, True):
+        cfg, bound, cam, frames, dec, mapper = _setup()
+        mapper.static_shapes, mapper.is_BA, mapper.overlap_smooth, mapper.prefetch_draws = True, True, False, False
+        opt, ql, Tl = mapper.set_optimizer(frames, fused=True)
+        for grp, lr in zip(opt.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):
+            grp["lr"] = lr
+        prep = mapper.prepare_frames(frames)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        hist = []
+        ms = MapStep(mapper, frames, ql, Tl, prep=prep, smooth=False) if fused else None
+        for _ in range(4):
+            if fused:
+                ms.step()
+                hist.append(float(ms.losses()[0]))
+            else:
+                opt.zero_grad(set_to_none=True)
+                s = mapper.get_target_samples(frames, ql, Tl, prep=prep)
+                loss, _ = mapper.iteration_loss(s, lambda_lt=10.0, smooth=False)
+                loss.backward()
+                opt.step()
+                hist.append(float(loss.detach()))
+        out.append(hist)
+    for a, b in zip(*out):
+        assert abs(a - b) <= 1e-4 * abs(a), out
+
+
 def test_optimize_frames_through_map_step():
     """``Mapper.optimize_frames`` with ``use_map_step``: the reference's driver (set_decoder, the lambda_lt schedule of
     slams/mapping.py:893-896, pose write-back :914-926) around the fixed launch sequence -- same result as the autograd loop."""
