@@ -337,11 +337,13 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     wl = WORKLOADS[args.workload]
-    # Launch mode.  Eager launches on two streams overlap the smoothness branch with the ray branch but need ~2 ms of host
-    # enqueue per step; a hipGraph replay needs none but runs the branches one after the other.  Which wins depends on the
-    # workload and on the box's host (cfg2: eager 2.31 vs graph 2.44 ms; cfg3 / ref on a slow host: eager is HOST-bound at
-    # 2.96 / 1.91 ms while their kernels need 2.4 / 1.5).  Default (neither --graph nor --eager, one GPU): both are built,
-    # timed for a few untimed steps, and the faster one runs the timed region -- reported as launch_mode / launch_trial_ms.
+    # Launch mode.  Eager launches on two streams overlap the smoothness branch with the ray branch; a hipGraph replay needs no
+    # host work but runs the branches one after the other (graph branches do not run concurrently on this ROCm: 2.46 with the
+    # lattice captured as a branch, 2.45 without).  With the fixed launch sequence (fused_step.MapStep: 0.44 ms of host enqueue
+    # per step) eager wins on every workload measured (cfg2 2.09 vs 2.28-2.34 ms, ref 1.00 vs 1.23); with the autograd driver
+    # (--autograd-step: 2.0 ms of enqueue) small workloads on a slow host were HOST-bound and the graph won.  Default (neither
+    # --graph nor --eager, one GPU): both are built, timed for a few untimed steps, and the faster one runs the timed region
+    # -- reported as launch_mode / launch_trial_ms.
     auto_mode = not args.graph and not args.eager and not args.no_overlap and ctx.world_size == 1
     use_graph = args.graph and not args.eager and ctx.world_size == 1
     # the smoothness branch on a second stream (eager), or -- with --graph-branches -- as a parallel branch of the captured graph
