@@ -555,7 +555,18 @@ def main():
             tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, fused=True, graph=(mode == "graph"))
             torch.cuda.synchronize()
             res[mode] = (time.perf_counter() - t1) * 1e3 / n_it
+        # the same loop as a fixed launch sequence (fused_step.TrackStep), eager and as one captured iteration replayed n_it times
+        tracker.use_track_step = True
+        for mode in ("eager", "graph"):
+            tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, graph=(mode == "graph"))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, graph=(mode == "graph"))
+            torch.cuda.synchronize()
+            res["step_" + mode] = (time.perf_counter() - t1) * 1e3 / n_it
         out["tracking"] = {"ms_per_iter_eager": res["eager"], "ms_per_iter_graph_incl_capture": res["graph"],
+                           "ms_per_iter_track_step_eager": res["step_eager"],
+                           "ms_per_iter_track_step_graph_incl_capture": res["step_graph"],
                            "rays": tcfg["tracking"]["n_pixels"], "samples_per_ray": S, "iters_per_frame": n_it}
     except Exception as e:
         out["tracking"] = {"error": f"{type(e).__name__}: {e}"}

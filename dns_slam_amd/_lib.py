@@ -64,6 +64,9 @@ SIGNATURES = {
     "dns_rgb_sigmoid": (C.c_int, [_P, _U, _P]),
     "dns_raw_bwd": (C.c_int, [_P, _P, _U, _P, _P, _U, _I, _P]),
     "dns_lattice_points": (C.c_int, [_P, _P, _U, _P, _P]),
+    "dns_track_mask": (C.c_int, [_P, _P, _U, C.c_float, _P, _P]),
+    "dns_keep_best": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "dns_force_half": (C.c_int, [_P, _U, _U, _P]),
     "dns_feature_gather": (C.c_int, [_P, _P, _P, _P, _U, _U, _U, _I, _I, _I, _I, _P, _P, _P]),
     "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P]),
     "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P, _P]),

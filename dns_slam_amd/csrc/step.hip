@@ -91,6 +91,34 @@ __global__ __launch_bounds__(256) void lattice_points_kernel(const float* __rest
   }
 }
 
+// ---- tracker glue (slams/tracking.py:171-172, 326-335; utils/common.py:571-574) --------------------------------------------
+// valid[n] = gt_depth[n] > min_depth && inside[n]
+__global__ __launch_bounds__(256) void track_mask_kernel(const float* __restrict__ gt_depth, const uint8_t* __restrict__ inside,
+                                                         uint32_t N, float min_depth, uint8_t* __restrict__ valid) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) valid[n] = (gt_depth[n] > min_depth && inside[n] != 0) ? 1 : 0;
+}
+
+// keep-best of the tracking loop: if (loss < best_loss) { best_loss = loss; best_cam = (quat | trans) } -- the camera that
+// PRODUCED the loss, i.e. before this iteration's Adam step (a NaN loss compares false and keeps the old best)
+__global__ void keep_best_kernel(const float* __restrict__ loss, const float* __restrict__ quat, const float* __restrict__ trans,
+                                 float* __restrict__ best_loss, float* __restrict__ best_cam) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float l = loss[0];
+  if (l < best_loss[0]) {
+    best_loss[0] = l;
+    for (int i = 0; i < 4; ++i) best_cam[i] = quat[i];
+    for (int i = 0; i < 3; ++i) best_cam[4 + i] = trans[i];
+  }
+}
+
+// sample_along_rays' forced mid-sample: t[idx] = 0.5 unless some t already equals 0.5 (utils/common.py:572-574); one wave
+__global__ __launch_bounds__(64) void force_half_kernel(float* __restrict__ t, uint32_t n, uint32_t idx) {
+  bool any = false;
+  for (uint32_t i = threadIdx.x; i < n; i += 64u) any = any || t[i] == 0.5f;
+  if (!__any(any) && threadIdx.x == 0 && idx < n) t[idx] = 0.5f;
+}
+
 }  // namespace dns
 
 using namespace dns;
@@ -158,4 +186,27 @@ extern "C" int dns_lattice_points(const float* r6, const double* consts9, uint32
   hipStream_t st = (hipStream_t)stream;
   DNS_LAUNCH(lattice_points_kernel, dim3(grid_for((uint64_t)n * n * n)), dim3(256), 0, st, r6, c, n, pts);
   return check_launch("dns_lattice_points");
+}
+
+extern "C" int dns_track_mask(const float* gt_depth, const uint8_t* inside, uint32_t N, float min_depth, uint8_t* valid, void* stream) {
+  if (N == 0) return DNS_OK;
+  DNS_REQUIRE(gt_depth && inside && valid, "dns_track_mask: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(track_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, st, gt_depth, inside, N, min_depth, valid);
+  return check_launch("dns_track_mask");
+}
+
+extern "C" int dns_keep_best(const float* loss, const float* quat, const float* trans, float* best_loss, float* best_cam, void* stream) {
+  DNS_REQUIRE(loss && quat && trans && best_loss && best_cam, "dns_keep_best: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(keep_best_kernel, dim3(1), dim3(64), 0, st, loss, quat, trans, best_loss, best_cam);
+  return check_launch("dns_keep_best");
+}
+
+extern "C" int dns_force_half(float* t, uint32_t n, uint32_t idx, void* stream) {
+  if (n == 0) return DNS_OK;
+  DNS_REQUIRE(t, "dns_force_half: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(force_half_kernel, dim3(1), dim3(64), 0, st, t, n, idx);
+  return check_launch("dns_force_half");
 }

@@ -420,3 +420,177 @@ class MapStep:
     def pose(self, k):
         bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self.dev)
         return torch.cat([torch.cat((get_rotation_from_quad(self.Q[k]), self.T[k][:, None]), -1), bottom], dim=0)
+
+
+class TrackStep:
+    """The tracker's iteration (slams/tracking.py:313-340: sample -> coarse-only render -> three masked losses -> pose gradient ->
+    Adam on (quat, T) -> keep the best pose) as a fixed launch sequence, like ``MapStep``: ~33 launches on one stream over
+    buffers allocated once, no host read anywhere (the keep-best comparison runs on the device, ``dns_keep_best``), so ONE
+    captured iteration replays n_iters times from a hipGraph.  The scene is frozen (:120-124): no weight-gradient work, no
+    table scatter.  Same kernels, arithmetic and generator calls as ``Tracker.track_frame`` (tests/test_gpu_fused_step.py).
+    ``features``: None or the per-sample 2-D code [n_pixels, S, C] (stem feature maps run through ``Tracker.track_frame``)."""
+
+    def __init__(self, tracker, cur_frames, est_c2w, features=None, betas=(0.9, 0.999), eps=1e-8):
+        t = self.t = tracker
+        dev = self.dev = torch.device(t.device)
+        if dev.type != "cuda":
+            raise ValueError("dns_slam_amd ops run on the GPU only; there is no CPU fallback")
+        if features is not None and features.dim() != 3:
+            raise ValueError("TrackStep takes the per-sample code [N, S, C] (stem feature maps run through Tracker.track_frame)")
+        dec = t.decoder
+        self.prep = t.prepare_frame(cur_frames)
+        self.features = None if features is None else features.to(dev).float().contiguous()
+        self.betas, self.eps = betas, eps
+        self.pe_dim, self.grid_dim, self.hid = dec.pe_dim, dec.grid_dim, dec.hidden_dim
+        nets = (dec.coarse_fn.decoder, dec.out_fn.color_decoder, dec.out_fn.logit_decoder)
+        self.fp16 = ops.MLP_FP16_FLAG if getattr(nets[0], "fp16", False) else 0
+        shp = lambda n: (n.n_input_dims, n.n_output_dims, n.n_neurons, n.n_hidden_layers)
+        self.shp_c, self.shp_col, self.shp_log = (shp(n) for n in nets)
+        self.p_coarse, self.p_color, self.p_logit = (n.params for n in nets)
+        self.p_table, self.meta, self.n_bins = dec.pe_fn.grid_fn.params, dec.pe_fn.grid_fn.meta, dec.pe_fn.pe_fn.n_bins
+        self.n_feat = self.hid + (self.hid if features is None else self.features.shape[-1])
+        if not (self.pe_dim % 4 == 0 and self.pe_dim <= 64 and self.n_feat <= 64 and self.n_feat % 4 == 0
+                and self.shp_col[0] == self.pe_dim + self.n_feat and self.shp_c[1] == self.hid + 1):
+            raise ValueError("TrackStep: network shapes outside the two-segment input form")
+        self.n_class = self.shp_log[1]
+        N = self.N = int(t.n_pixels)
+        nu = self.nu = 0 if t.t_uniform is None else t.t_uniform.numel()
+        ns = self.ns = t.n_surface_ray
+        S = self.S = nu + ns
+        P = self.P = N * S
+        ld = self.ld = self.pe_dim + self.grid_dim
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        # pose = the parameter; [d_buf | g_quat(4) g_trans(3) pad] share one buffer: one fill clears both per iteration
+        self.Q = get_quad_from_c2w(est_c2w).detach().to(dev).float().reshape(1, 4).contiguous()
+        self.T = est_c2w[:3, 3].detach().clone().to(dev).float().reshape(1, 3).contiguous()
+        self.zbuf = torch.zeros(P * ld + 8, device=dev)
+        self.d_buf = self.zbuf[:P * ld].view(P, ld)
+        self.g_quat, self.g_trans = self.zbuf[P * ld:P * ld + 4], self.zbuf[P * ld + 4:P * ld + 7]
+        self.M, self.V, self.adam_state = torch.zeros(8, device=dev), torch.zeros(8, device=dev), torch.zeros(3, device=dev)
+        lr = float(t.cam_lr)
+        lrT = lr * 0.2 if t.seperate_LR else lr
+        self.adam_items = (DnsAdamTensor * 2)()
+        for k, (p, g, o, n, l) in enumerate(((self.T, self.g_trans, 4, 3, lrT), (self.Q, self.g_quat, 0, 4, lr))):
+            it = self.adam_items[k]
+            it.p, it.g, it.m, it.v, it.n, it.lr = p.data_ptr(), g.data_ptr(), self.M.data_ptr() + 4 * o, self.V.data_ptr() + 4 * o, n, l
+        self.best_loss = torch.full((1,), float("inf"), device=dev)
+        self.best_cam = torch.cat((self.Q.reshape(-1), self.T.reshape(-1))).clone()
+        self.rays_o, self.rays_d, self.gt_color, self.gt_depth = f(N, 3), f(N, 3), f(N, 3), f(N)
+        self.gt_label = torch.empty(N, device=dev, dtype=torch.int64)
+        self.inside, self.valid = torch.empty(N, device=dev, dtype=torch.uint8), torch.empty(N, device=dev, dtype=torch.uint8)
+        self.z, self.pts = f(N, S), f(N, S, 3)
+        self.dmax_ws = torch.empty(1, device=dev, dtype=torch.int32)
+        self.x3, self.buf = f(P, 3), f(P, ld)
+        self.dydx = f(self.meta.n_levels * 3 * P * 2)
+        nf = self.hid + 1
+        self.lat, self.feat = f(P, nf), f(P, self.n_feat)
+        self.raw, self.logit = f(P, 4), f(P, self.n_class)
+        self.depth, self.var, self.rgb, self.weights, self.sem = f(N), f(N), f(N, 3), f(N, S), f(N, self.n_class)
+        self.sums_ws, self.out, self.one = f(ops.LOSS_SUMS_FLOATS), f(16), torch.ones(1, device=dev)
+        self.d_color, self.d_depth, self.d_var, self.d_sem = f(N, 3), f(N), f(N), f(N, self.n_class)
+        self.d_raw, self.d_logit, self.d_col = f(P, 4), f(P, self.n_class), f(P, 4)
+        self.d_featx = f(P, 4 + self.n_feat)
+        self.d_x3 = f(P, 3)
+        raw_lib = ops.lib._raw
+        self.ray_ws = f(max(int(raw_lib.dns_raygen_bwd_ws_floats(1, N)), 1))
+        self.lam = (C.c_float * 8)(t.lambda_p, t.lambda_d, t.lambda_l, 0.0, 0.0, 0.0, 0.0, 1.0)
+        self.camv = (C.c_double * 4)(float(t.fx), float(t.fy), float(t.cx), float(t.cy))
+        self.b6 = ops._bound6(t.bound)
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, draws=None):
+        """One tracking iteration on the current stream (capturable).  ``draws`` = (pix [N] int64, t_surf [ns], t_zero [ns])."""
+        t, lib = self.t, ops.lib
+        st = _V(torch.cuda.current_stream().cuda_stream)
+        N, S, P, ld, pe, b = self.N, self.S, self.P, self.ld, self.pe_dim, t.border
+        H, W = t.H, t.W
+        if draws is None:                                  # Tracker.draw_pixels / draw_jitter, device generator, same call order
+            pix = torch.randint((H - 2 * b) * (W - 2 * b), (N,), device=self.dev)
+            t_surf = torch.rand(self.ns, device=self.dev)
+            check(lib.dns_force_half(ptr(t_surf), self.ns, self.ns // 2 + 1, st), "dns_force_half")
+            t_zero = torch.rand(self.ns, device=self.dev)
+        else:
+            pix, t_surf, t_zero = draws
+        self._keep = (pix, t_surf, t_zero)
+        self.zbuf.zero_()
+        prep = self.prep
+        check(lib.dns_raygen_sample(ptr(pix), ptr(prep["color"]), ptr(prep["depth"]), ptr(prep["label"]), ptr(self.Q), ptr(self.T),
+                                    self.camv, self.b6, H, W, b, H - b, b, W - b, 1, N, ptr(t.t_uniform), ptr(t_surf), ptr(t_zero),
+                                    self.nu, self.ns, 0, ptr(self.dmax_ws), 0, ptr(self.rays_o), ptr(self.rays_d),
+                                    ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(self.z),
+                                    ptr(self.pts), st), "dns_raygen_sample")
+        check(lib.dns_track_mask(ptr(self.gt_depth), ptr(self.inside), N, 0.01, ptr(self.valid), st), "dns_track_mask")   # :171-172
+        meta = C.byref(self.meta.c)
+        check(lib.dns_encode_fwd(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf), ld,
+                                 _V(self.buf.data_ptr() + 4 * pe), ld, ptr(self.dydx), st), "dns_encode_fwd")
+        fp16 = self.fp16
+
+        def fwd(x2, n_in1, params, shape, y):
+            n_in, n_out, nn, nl = shape
+            check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
+                                  nn, nl, ptr(y), y.stride(0), P, None, None, 0, None, fp16, st), "dns_mlp_fwd")
+
+        fwd(None, 0, self.p_coarse, self.shp_c, self.lat)                  # coarse-only render (slams/tracking.py:196-200)
+        check(lib.dns_feature_block(ptr(self.lat), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
+                                    ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
+        fwd(self.feat, pe, self.p_color, self.shp_col, self.raw)
+        fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit)
+        check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
+        Cn = self.n_class
+        check(lib.dns_composite_fwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
+                                    ptr(self.rgb), ptr(self.weights), ptr(self.sem), st), "dns_composite_fwd")
+        lam = self.lam
+        check(lib.dns_loss_sums(lam, N, 1, Cn, 1, 1, ptr(self.rgb), ptr(self.depth), ptr(self.var), ptr(self.sem), ptr(self.gt_color),
+                                ptr(self.gt_depth), ptr(self.gt_label), ptr(self.valid), None, None, None, ptr(self.sums_ws), st),
+              "dns_loss_sums")
+        check(lib.dns_loss_finalize(lam, N, 1, Cn, 1, 1, ptr(self.sums_ws), ptr(self.out), st), "dns_loss_finalize")
+        check(lib.dns_keep_best(_V(self.out.data_ptr() + 4 * 6), ptr(self.Q), ptr(self.T), ptr(self.best_loss), ptr(self.best_cam),
+                                st), "dns_keep_best")                       # :326-335, before the optimiser moves the pose
+        # ---- backward to the pose
+        check(lib.dns_loss_bwd(lam, N, 1, Cn, 1, 1, ptr(self.out), ptr(self.one), ptr(self.rgb), ptr(self.depth), ptr(self.var),
+                               ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.valid), None,
+                               None, None, ptr(self.d_color), ptr(self.d_depth), ptr(self.d_var), ptr(self.d_sem), None, None, 0,
+                               st), "dns_loss_bwd")
+        check(lib.dns_composite_bwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), ptr(self.d_var),
+                                    ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), st),
+              "dns_composite_bwd")
+        ldf = 4 + self.n_feat
+        check(lib.dns_raw_bwd(ptr(self.d_raw), ptr(self.raw), P, ptr(self.d_col), _V(self.d_featx.data_ptr() + 12), ldf, 0, st),
+              "dns_raw_bwd")
+
+        def bwd(x2, n_in1, dy, params, shape, d_x2, acc):
+            n_in, n_out, nn, nl = shape
+            check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
+                                  ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
+                                  0 if d_x2 is None else d_x2.stride(0), None, None, P, None, None, 0, None, acc | fp16, st),
+                  "dns_mlp_bwd")
+
+        d_feat = self.d_featx[:, 4:]
+        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, 1)        # d_buf (zeroed) += ; feature block =
+        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, 3)
+        bwd(None, 0, self.d_featx[:, 3:3 + self.hid + 1], self.p_coarse, self.shp_c, None, 1)
+        check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld,
+                                 _V(self.d_buf.data_ptr() + 4 * pe), ld, None, ptr(self.d_x3), ptr(self.dydx), None, 0, 0, st),
+              "dns_encode_bwd")
+        check(lib.dns_raygen_bwd(ptr(pix), ptr(self.Q), self.camv, b, H - b, b, W - b, 1, N, S, ptr(self.z), ptr(self.d_x3), None,
+                                 None, ptr(self.ray_ws), ptr(self.g_quat), ptr(self.g_trans), st), "dns_raygen_bwd")
+        check(lib.dns_adam_step(self.adam_items, 2, self.betas[0], self.betas[1], self.eps, ptr(self.adam_state), st),
+              "dns_adam_step")
+        self.steps += 1
+
+    def run(self, n_iters, graph=True):
+        """n_iters iterations -> (best camera tensor [7] = (quat | T), best loss).  ``graph``: capture one iteration into a
+        hipGraph and replay it (tracking is 30-50 latency-bound iterations per frame)."""
+        if not graph:
+            for _ in range(n_iters):
+                self.step()
+            return self.best_cam, self.best_loss[0]
+        from ._lib import ensure_init
+        ensure_init()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):                          # records one iteration; nothing executes during capture
+            self.step()
+        for _ in range(n_iters):
+            g.replay()
+        return self.best_cam, self.best_loss[0]

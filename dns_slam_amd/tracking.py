@@ -36,6 +36,7 @@ class Tracker:
         self.pe_dim = decoder.pe_dim
         self.border = 20
         self.static_shapes = False        # True: device-side jitter draws, no host work per iteration (hipGraph-capturable)
+        self.use_track_step = False       # True: track_frame runs fused_step.TrackStep (fixed launch sequence, device-side draws)
         self.t_uniform = torch.linspace(0.0, 1.0, steps=self.n_samples_ray, device=device) if self.n_samples_ray > 0 else None
         if str(device) != "cpu":
             from ._lib import ensure_init
@@ -160,6 +161,14 @@ class Tracker:
         ``graph=True`` captures ONE iteration (sampling, render, losses, backward, fused Adam, keep-best) into a hipGraph
         and replays it n_iters times: tracking is 30-50 tiny latency-bound iterations per frame."""
         n_iters = self.n_iters if n_iters is None else n_iters
+        if getattr(self, "use_track_step", False) and (features is None or features.dim() == 3):
+            # the same loop as a fixed launch sequence over preallocated buffers (no autograd graph; draws on the device
+            # generator like static_shapes); graph=True replays one captured iteration
+            from .fused_step import TrackStep
+            ts = TrackStep(self, cur_frames, est_c2w, features=features)
+            cam, best = ts.run(n_iters, graph=graph)
+            self.last_track_step = ts
+            return cam, best
         with self.frozen_scene():
             if graph:
                 return self._track_frame_graphed(cur_frames, est_c2w, n_iters, features, graph_warmup)

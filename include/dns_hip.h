@@ -316,6 +316,14 @@ int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream);
 int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, float* d_col, float* d_occ, uint32_t ld_occ, int accumulate,
                 void* stream);
 int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, float* pts, void* stream);
+/* Tracker glue (slams/tracking.py:171-172, 326-335; utils/common.py:572-574), used by fused_step.TrackStep:
+ * dns_track_mask: valid[n] = gt_depth[n] > min_depth && inside[n] (uint8).
+ * dns_keep_best: if (loss[0] < best_loss[0]) { best_loss[0] = loss[0]; best_cam[0:7] = (quat[0:4] | trans[0:3]) } -- device-side
+ *   keep-best-pose of the tracking loop, no host read of the loss (a NaN loss keeps the old best).
+ * dns_force_half: t[idx] = 0.5 unless some t[i] == 0.5 already (the forced mid-sample of sample_along_rays' surface draws). */
+int dns_track_mask(const float* gt_depth, const uint8_t* inside, uint32_t N, float min_depth, uint8_t* valid, void* stream);
+int dns_keep_best(const float* loss, const float* quat, const float* trans, float* best_loss, float* best_cam, void* stream);
+int dns_force_half(float* t, uint32_t n, uint32_t idx, void* stream);
 
 /* ---- 2-D feature lookup (feature_matching / feature_searching, utils/common.py:632-673) --------
  * pts [P,3] world points, w2c [R,16] row-major world->camera of the R reference frames, K [host, 9 floats] intrinsics,

@@ -161,6 +161,71 @@ def test_optimize_frames_through_map_step():
     assert float((pa - pb).abs().max()) <= 1e-4 * float(pa.abs().max()) + 0.05 * 8 * 0.005
 
 
+@pytest.mark.parametrize("code", [False, True])
+def test_track_step_equals_the_tracker_loop(code):
+    """``TrackStep`` (the tracker's iteration as a fixed launch sequence, eager and replayed from a hipGraph) against
+    ``Tracker.track_frame`` (autograd driver, itself held to the oracle by test_gpu_slam.py) from the same seed: the same
+    keep-best loss (1e-5) and camera (2e-5; float atomics in the pose gradient are the only run-to-run difference)."""
+    from dns_slam_amd.fused_step import TrackStep
+    from dns_slam_amd.tracking import Tracker
+    cfg, bound, cam, frames, dec, mapper = _setup(64, 2, n_pixels=400)
+    cfg["tracking"]["n_pixels"] = 256
+    cur = {"gt_color": frames["gt_color"][2], "gt_depth": frames["gt_depth"][2], "gt_label": frames["gt_label"][2]}
+    c2w = frames["est_c2w"][2].clone()
+    c2w[:3, 3] += torch.tensor([0.02, -0.01, 0.015], dtype=c2w.dtype)
+    feats = None
+    if code:
+        feats = (torch.rand(256, 32 + 15, 32, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(DEV)
+    out = {}
+    for mode in ("autograd", "eager", "graph"):
+        tracker = Tracker(cfg, dec, bound, cam, device=DEV)
+        tracker.border = 5
+        tracker.static_shapes = True
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(3)
+        if mode == "autograd":
+            cam7, best = tracker.track_frame(cur, c2w, n_iters=25, features=feats, fused=True, graph=False)
+        else:
+            with tracker.frozen_scene():
+                ts = TrackStep(tracker, cur, c2w, features=feats)
+                cam7, best = ts.run(25, graph=(mode == "graph"))
+        torch.cuda.synchronize()
+        out[mode] = (cam7.detach().cpu().clone(), float(best))
+    for mode in ("eager", "graph"):
+        assert abs(out[mode][1] - out["autograd"][1]) <= 1e-5 * abs(out["autograd"][1]), (mode, out[mode][1], out["autograd"][1])
+        assert float((out[mode][0] - out["autograd"][0]).abs().max()) <= 2e-5, (mode, out[mode][0], out["autograd"][0])
+    assert float((out["autograd"][0][4:] - c2w[:3, 3]).abs().max()) > 0        # the pose did move
+
+
+def test_tracker_glue_kernels():
+    lib, check, ptr, stream_ptr = _lib()
+    g = torch.Generator().manual_seed(8)
+    N = 300
+    d = torch.rand(N, generator=g) * 0.03
+    ins = (torch.rand(N, generator=g) < 0.7).to(torch.uint8)
+    valid = torch.empty(N, dtype=torch.uint8, device=DEV)
+    d_d, ins_d = d.to(DEV), ins.to(DEV)
+    check(lib.dns_track_mask(ptr(d_d), ptr(ins_d), N, 0.01, ptr(valid), stream_ptr()), "dns_track_mask")
+    assert torch.equal(valid.cpu().bool(), (d > 0.01) & ins.bool())              # slams/tracking.py:171-172
+    q, t = torch.tensor([[0.9, 0.1, 0.2, 0.3]], device=DEV), torch.tensor([[1.0, 2.0, 3.0]], device=DEV)
+    best_loss, best_cam = torch.tensor([5.0], device=DEV), torch.zeros(7, device=DEV)
+    for loss, want_l, want_q0 in ((7.0, 5.0, 0.0), (3.0, 3.0, 0.9), (float("nan"), 3.0, 0.9)):
+        l = torch.tensor([loss], device=DEV)
+        check(lib.dns_keep_best(ptr(l), ptr(q), ptr(t), ptr(best_loss), ptr(best_cam), stream_ptr()), "dns_keep_best")
+        assert float(best_loss) == want_l and abs(float(best_cam[0]) - want_q0) < 1e-7
+    assert torch.equal(best_cam.cpu(), torch.tensor([0.9, 0.1, 0.2, 0.3, 1.0, 2.0, 3.0]))
+    tt = torch.rand(15, generator=g).to(DEV)
+    keep = tt.clone()
+    check(lib.dns_force_half(ptr(tt), 15, 8, stream_ptr()), "dns_force_half")        # utils/common.py:572-574
+    keep[8] = 0.5
+    assert torch.equal(tt, keep)
+    tt[3] = 0.5
+    tt[8] = 0.25
+    keep = tt.clone()
+    check(lib.dns_force_half(ptr(tt), 15, 8, stream_ptr()), "dns_force_half")        # a draw already equals 0.5: untouched
+    assert torch.equal(tt, keep)
+
+
 # ------------------------------------------------------------------------------------------------ the glue kernels (csrc/step.hip)
 def _lib():
     from dns_slam_amd import ops
