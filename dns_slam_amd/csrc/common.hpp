@@ -66,6 +66,7 @@ struct KernelSpan {
 // their destination (found in round 2 with tools/graph_sync_min.py: the sampling step is stable with the per-frame depth
 // maximum supplied, i.e. without its memset, and goes wrong with it).
 int fill_words(void* dst, uint32_t value, size_t n_words, hipStream_t st, const char* who);
+int fill_words2(void* a, uint32_t va, size_t na, void* b, uint32_t vb, size_t nb, hipStream_t st, const char* who);
 constexpr int MAX_DYN_LDS = 160 * 1024;      // gfx950: 160 KiB of LDS per CU, all of it available to one workgroup
 
 // Device-side copy of the level table, passed by value as a kernel argument.

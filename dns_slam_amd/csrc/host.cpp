@@ -102,6 +102,22 @@ int fill_words(void* dst, uint32_t value, size_t n_words, hipStream_t st, const 
   return check_launch(who);
 }
 
+// two ranges in one launch (dns_group_slots: the class counters and the slot -> row table)
+__global__ __launch_bounds__(256) void fill_words2_kernel(uint32_t* __restrict__ a, uint32_t va, size_t na, uint32_t* __restrict__ b,
+                                                          uint32_t vb, size_t nb) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < na) a[i] = va;
+    else b[i - na] = vb;
+  }
+}
+int fill_words2(void* a, uint32_t va, size_t na, void* b, uint32_t vb, size_t nb, hipStream_t st, const char* who) {
+  if (na + nb == 0) return DNS_OK;
+  const size_t want = (na + nb + 255) / 256;
+  const uint32_t blocks = (uint32_t)(want < 2048 ? want : 2048);
+  DNS_LAUNCH(fill_words2_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(a), va, na, reinterpret_cast<uint32_t*>(b), vb, nb);
+  return check_launch(who);
+}
+
 // ---- per-kernel event timing (measurement aid; see KernelSpan in common.hpp) ----
 struct SpanRec {
   const char* name;

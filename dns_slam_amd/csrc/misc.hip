@@ -186,8 +186,7 @@ extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_
   uint32_t* cursor = ws + GROUP_MAX;
   {
     int rc = ensure_ready(st, "dns_group_slots");
-    if (rc == DNS_OK) rc = fill_words(counts, 0u, GROUP_MAX, st, "dns_group_slots");
-    if (rc == DNS_OK) rc = fill_words(row_index, 0xFFFFFFFFu, n_slots, st, "dns_group_slots");   // -1 = padding slot
+    if (rc == DNS_OK) rc = fill_words2(counts, 0u, GROUP_MAX, row_index, 0xFFFFFFFFu, n_slots, st, "dns_group_slots");   // -1 = padding slot
     if (rc != DNS_OK) return rc;
   }
   if (P) {

@@ -91,6 +91,41 @@ __global__ __launch_bounds__(256) void lattice_points_kernel(const float* __rest
   }
 }
 
+// The index arithmetic behind the pixel draws of one iteration (select_uv + select_by_class, utils/common.py:274,313-328, all K
+// frames at once) and what follows from the drawn pixels alone: per frame f, pix[f, 0:n1] = i1[f, :] (uniform picks),
+// pix[f, n1 + s] = sorted[start[f, s] + min(int64(u[f, s] * count[f, s]), count[f, s] - 1)] (class-balanced picks from the
+// frame's pixels sorted by class), labels[f, r] = int64(label[f, pix]) and dmax[f] = max(0, max_r depth[f, pix]) as float bits
+// (what sample_along_rays takes the maximum of, :581,591).  One workgroup per frame: the maximum needs no atomics.
+__global__ __launch_bounds__(256) void draw_finish_kernel(const int64_t* __restrict__ i1, const double* __restrict__ u,
+                                                          const double* __restrict__ count_f64, const int64_t* __restrict__ count_m1,
+                                                          const int64_t* __restrict__ start_flat, const int64_t* __restrict__ sorted_flat,
+                                                          const float* __restrict__ depth, const float* __restrict__ label,
+                                                          uint32_t n1, uint32_t n2, uint32_t HW, int64_t* __restrict__ pix,
+                                                          int64_t* __restrict__ labels, uint32_t* __restrict__ dmax) {
+  __shared__ float red[4];
+  const uint32_t f = blockIdx.x, npf = n1 + n2;
+  float m = 0.f;
+  for (uint32_t r = threadIdx.x; r < npf; r += blockDim.x) {
+    int64_t p;
+    if (r < n1) {
+      p = i1[(size_t)f * n1 + r];
+    } else {
+      const size_t s = (size_t)f * n2 + (r - n1);
+      int64_t j = (int64_t)(u[s] * count_f64[s]);
+      j = j < count_m1[s] ? j : count_m1[s];
+      p = sorted_flat[start_flat[s] + j];
+    }
+    pix[(size_t)f * npf + r] = p;
+    labels[(size_t)f * npf + r] = (int64_t)label[(size_t)f * HW + p];
+    m = fmaxf(m, depth[(size_t)f * HW + p]);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) dmax[f] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 // ---- tracker glue (slams/tracking.py:171-172, 326-335; utils/common.py:571-574) --------------------------------------------
 // valid[n] = gt_depth[n] > min_depth && inside[n]
 __global__ __launch_bounds__(256) void track_mask_kernel(const float* __restrict__ gt_depth, const uint8_t* __restrict__ inside,
@@ -209,4 +244,18 @@ extern "C" int dns_force_half(float* t, uint32_t n, uint32_t idx, void* stream) 
   hipStream_t st = (hipStream_t)stream;
   DNS_LAUNCH(force_half_kernel, dim3(1), dim3(64), 0, st, t, n, idx);
   return check_launch("dns_force_half");
+}
+
+extern "C" int dns_draw_finish(const int64_t* i1, const double* u, const double* count_f64, const int64_t* count_m1,
+                               const int64_t* start_flat, const int64_t* sorted_flat, const float* depth, const float* label,
+                               uint32_t n_frames, uint32_t n1, uint32_t n2, uint32_t HW, int64_t* pix, int64_t* labels,
+                               uint32_t* dmax, void* stream) {
+  if (n_frames == 0 || n1 + n2 == 0) return DNS_OK;
+  DNS_REQUIRE(depth && label && pix && labels && dmax, "dns_draw_finish: NULL argument");
+  DNS_REQUIRE(n1 == 0 || i1, "dns_draw_finish: n1 > 0 needs i1");
+  DNS_REQUIRE(n2 == 0 || (u && count_f64 && count_m1 && start_flat && sorted_flat), "dns_draw_finish: n2 > 0 needs the class tables");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(draw_finish_kernel, dim3(n_frames), dim3(256), 0, st, i1, u, count_f64, count_m1, start_flat, sorted_flat, depth, label,
+             n1, n2, HW, pix, labels, dmax);
+  return check_launch("dns_draw_finish");
 }

@@ -145,12 +145,13 @@ class MapStep:
         self.sets = []
         for _ in range(2):
             st_ = _Set()
-            st_.G = torch.zeros(n_G, device=dev)
+            o_G = (P * nf + 3) // 4 * 4                                   # G starts 16-byte aligned
+            st_.zb = torch.zeros(o_G + n_G, device=dev)                   # [fine | G]: one fill per step clears both
+            st_.fine, st_.G = st_.zb[:P * nf].view(P, nf), st_.zb[o_G:]
             seg = lambda i: st_.G[offs[i]:offs[i] + plist[i].numel()]
             st_.g_color, st_.g_logit, st_.g_pool, st_.g_table, st_.g_coarse, st_.g_quat, st_.g_trans = (seg(i) for i in range(7))
             st_.G_early, st_.G_late = st_.G[:offs[3]], st_.G[offs[3]:]
             st_.adam_items = adam_items(st_.G)
-            st_.fine = f(P, nf)
             st_.row_index = torch.empty(self.n_slots, device=dev, dtype=torch.int32)
             st_.tile_group = torch.empty(self.n_slots // 128, device=dev, dtype=torch.int32)
             st_.ev, st_.draws, st_.dmax = None, None, None
@@ -232,26 +233,36 @@ class MapStep:
         every sample to its class's decoder (slams/mapping.py:590-601,613) and the zero fills of what the step adds into."""
         m, lib = self.m, ops.lib
         K, npf, N, S, P = self.K, self.npf, self.N, self.S, self.P
-        if draws is not None:
+        prep = self.prep
+        if draws is None:
+            # Mapper._draw_all's generator calls in its order (pixels: randint then float64 rand; jitter; lattice), the index
+            # arithmetic, the labels of the drawn pixels and the per-frame depth maxima in ONE kernel (dns_draw_finish)
+            n1, n2 = prep["n1"], prep["n2"]
+            i1 = torch.randint(prep["HW"], (K, n1), device=self.dev)
+            u = torch.rand(K, n2, device=self.dev, dtype=torch.float64)
+            pix = torch.empty(K * npf, device=self.dev, dtype=torch.int64)
+            labels = torch.empty(K * npf, device=self.dev, dtype=torch.int64)
+            dmax = torch.empty(K, device=self.dev, dtype=torch.int32)
+            check(lib.dns_draw_finish(ptr(i1), ptr(u), ptr(prep["counts_f64"]), ptr(prep["counts_m1"]), ptr(prep["starts_flat"]),
+                                      ptr(prep["sorted_flat"]), ptr(prep["depth"]), ptr(prep["label"]), K, n1, n2, prep["HW"],
+                                      ptr(pix), ptr(labels), ptr(dmax), stream), "dns_draw_finish")
+            d = {"pix": pix, "jitter": m.draw_jitter(), "r6": torch.rand(6, device=self.dev) if self.smooth else None}
+        else:                                          # given draws (tests): the same quantities with torch ops
             d = draws
-        elif self.smooth:
-            d = m._draw_all(self.prep)
-        else:                                          # no lattice: no lattice draw (the autograd path makes none either)
-            d = {"pix": m.draw_pixels(self.prep), "jitter": m.draw_jitter(), "r6": None}
+            pix2 = d["pix"].reshape(K, npf)
+            dmax = torch.gather(prep["depth"].reshape(K, -1), 1, pix2).amax(dim=1).clamp_min(0.0).float().contiguous().view(torch.int32)
+            labels = torch.gather(prep["label"].reshape(K, -1), 1, pix2).reshape(-1).long()      # = the gt_label raygen writes
         st_.draws = d
-        pix = d["pix"].reshape(K, npf)
-        dmax = torch.gather(self.prep["depth"].reshape(K, -1), 1, pix).amax(dim=1).clamp_min(0.0)
         if self.world > 1:
-            m.dist.allreduce_max(dmax)
-        st_.dmax = dmax.float().contiguous().view(torch.int32)             # bit patterns, as dns_raygen_sample takes them
-        labels = torch.gather(self.prep["label"].reshape(K, -1), 1, pix).reshape(-1).long()      # = the gt_label raygen writes
+            fmax = dmax.view(torch.float32)
+            m.dist.allreduce_max(fmax)                  # in place on the same storage
+        st_.dmax = dmax                                 # bit patterns, as dns_raygen_sample takes them
         lut = m.fine_decoders.lut(0)                                       # class id -> pool row; :613 tiles the labels (SURVEY D1)
         check(lib.dns_class_slots(ptr(labels), N, S, 1 if m.label_layout == "reference_tiled" else 0, ptr(lut), lut.numel(),
                                   ptr(self.slot), stream), "dns_class_slots")
         check(lib.dns_group_slots(ptr(self.slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(st_.row_index),
                                   ptr(st_.tile_group), stream), "dns_group_slots")
-        st_.fine.zero_()                                                   # points without a network keep zeros (:592)
-        st_.G.zero_()
+        st_.zb.zero_()            # the fine network's output (points without a network keep zeros, :592) | the gradient buffer
 
     @torch.no_grad()
     def step(self, draws=None):

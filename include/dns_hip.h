@@ -316,6 +316,17 @@ int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream);
 int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, float* d_col, float* d_occ, uint32_t ld_occ, int accumulate,
                 void* stream);
 int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, float* pts, void* stream);
+/* dns_draw_finish: the index arithmetic behind one iteration's pixel draws for all K frames (select_uv + select_by_class,
+ * utils/common.py:274,313-328) plus what follows from the drawn pixels alone.  The RANDOM NUMBERS come from the caller's
+ * generator: i1 [K, n1] int64 uniform picks in [0, HW), u [K, n2] float64 in [0, 1).  Per frame f: pix[f, 0:n1] = i1[f],
+ * pix[f, n1 + s] = sorted_flat[start_flat[f, s] + min(int64(u[f, s] * count_f64[f, s]), count_m1[f, s])] (sorted_flat [K * HW]:
+ * every frame's pixel indices ordered by class; start_flat already holds the frame's offset f * HW), labels[f, r] =
+ * int64(label[f, pix[f, r]]), dmax[f] = bit pattern of max(0, max_r depth[f, pix[f, r]]) -- the form dns_raygen_sample takes
+ * with depth_max_given = 1.  pix, labels [K * (n1 + n2)] int64; depth, label [K, HW] fp32. */
+int dns_draw_finish(const int64_t* i1, const double* u, const double* count_f64, const int64_t* count_m1,
+                    const int64_t* start_flat, const int64_t* sorted_flat, const float* depth, const float* label,
+                    uint32_t n_frames, uint32_t n1, uint32_t n2, uint32_t HW, int64_t* pix, int64_t* labels, uint32_t* dmax,
+                    void* stream);
 /* Tracker glue (slams/tracking.py:171-172, 326-335; utils/common.py:572-574), used by fused_step.TrackStep:
  * dns_track_mask: valid[n] = gt_depth[n] > min_depth && inside[n] (uint8).
  * dns_keep_best: if (loss[0] < best_loss[0]) { best_loss[0] = loss[0]; best_cam[0:7] = (quat[0:4] | trans[0:3]) } -- device-side

@@ -307,3 +307,28 @@ def test_lattice_points_equal_the_float64_affine_map():
     # float64 arithmetic rounded to float32 once: at most the last bit where torch contracts a multiply-add
     assert float((got - want).abs().max()) <= 6e-8 * float(want.abs().max())
     assert float((got != want).float().mean()) < 1e-3
+
+
+def test_draw_finish_equals_the_mapper_draw_arithmetic():
+    """dns_draw_finish on given random numbers == Mapper.draw_pixels' index arithmetic (select_uv + select_by_class,
+    utils/common.py:274,313-328), the labels raygen would read and the per-frame depth maxima."""
+    lib, check, ptr, stream_ptr = _lib()
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    prep = mapper.prepare_frames(frames)
+    K, n1, n2, HW = 4, prep["n1"], prep["n2"], prep["HW"]
+    npf = n1 + n2
+    torch.manual_seed(21)
+    i1 = torch.randint(HW, (K, n1), device=DEV)
+    u = torch.rand(K, n2, device=DEV, dtype=torch.float64)
+    j = torch.minimum((u * prep["counts_f64"]).to(torch.int64), prep["counts_m1"])
+    want_pix = torch.cat((i1, prep["sorted_flat"][prep["starts_flat"] + j]), 1).reshape(-1)
+    pix = torch.empty(K * npf, device=DEV, dtype=torch.int64)
+    labels = torch.empty(K * npf, device=DEV, dtype=torch.int64)
+    dmax = torch.empty(K, device=DEV, dtype=torch.int32)
+    check(lib.dns_draw_finish(ptr(i1), ptr(u), ptr(prep["counts_f64"]), ptr(prep["counts_m1"]), ptr(prep["starts_flat"]),
+                              ptr(prep["sorted_flat"]), ptr(prep["depth"]), ptr(prep["label"]), K, n1, n2, HW, ptr(pix), ptr(labels),
+                              ptr(dmax), stream_ptr()), "dns_draw_finish")
+    assert torch.equal(pix, want_pix)
+    p2 = want_pix.reshape(K, npf)
+    assert torch.equal(labels, torch.gather(prep["label"].reshape(K, -1), 1, p2).reshape(-1).long())
+    assert torch.equal(dmax.view(torch.float32), torch.gather(prep["depth"].reshape(K, -1), 1, p2).amax(dim=1).clamp_min(0.0))
