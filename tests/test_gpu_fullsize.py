@@ -320,7 +320,7 @@ def test_cfg2_fullsize_matches_oracle():
     assert ql[0].grad is None
 
 
-def test_cfg2_prefetched_draws_same_trajectory_without_host_syncs(monkeypatch):
+def test_cfg2_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(monkeypatch):
     """Mapper.prefetch_draws (the benchmark's default with two streams: iteration k+1's pixel / jitter / lattice draws are
     enqueued on the side stream during iteration k): same generator order, so the losses of 16 full-size iterations
     launched WITHOUT any host synchronisation equal the unprefetched run's up to the run-to-run noise of the float
@@ -330,13 +330,19 @@ def test_cfg2_prefetched_draws_same_trajectory_without_host_syncs(monkeypatch):
     from dns_slam_amd import dist as dd
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
     runs = []
-    for prefetch in (False, True, True):
+    for fused, prefetch in ((False, False), (False, True), (False, True), (True, False), (True, True), (True, True)):
+        # the autograd-driven step and the fixed launch sequence (fused_step.MapStep: its next step's draws, depth maxima and
+        # decoder routing are prepared on the side stream too) make the same generator calls in the same order
         cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS["cfg2"], DEV, seed=100, dist_ctx=dd.DistCtx(),
-                                                            overlap=True, prefetch=prefetch)
-        assert mapper.prefetch_draws == prefetch
-        losses = [step().detach() for _ in range(16)]
+                                                            overlap=True, prefetch=prefetch, fused_step=fused)
+        assert mapper.prefetch_draws == prefetch and (getattr(mapper, "map_step", None) is not None) == fused
+        losses = []
+        for _ in range(16):
+            out = step()
+            losses.append(mapper.map_step.losses()[0].clone() if fused else out.detach())
         torch.cuda.synchronize()
         runs.append(torch.stack(losses).cpu())
+    assert len(set(runs[0].tolist())) == 16                       # sixteen different batches, not one buffer read sixteen times
     for r in runs[1:]:
         err = float(((r - runs[0]).abs() / runs[0].abs()).max())
-        assert err <= 5e-4, f"prefetched draws changed the loss trajectory: max relative difference {err:.2e}"
+        assert err <= 5e-4, f"prefetched draws / the fixed launch sequence changed the loss trajectory: max relative difference {err:.2e}"
