@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class DnsGridMeta(C.Structure):
@@ -55,6 +55,8 @@ SIGNATURES = {
     "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P, _U, _P]),
     "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P, _I, _P]),
     "dns_mlp_bwd_ws_floats": (C.c_uint64, [_U, _U, _U]),
+    "dns_mlp_prepared_floats": (C.c_uint64, [_U, _U, _U, _U]),
+    "dns_mlp_prepare": (C.c_int, [_P, _U, _U, _U, _U, _U, _U, _P, _P]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,

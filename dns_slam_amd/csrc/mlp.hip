@@ -35,7 +35,9 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
                            const int32_t* tile_group, uint32_t param_stride, float* h_save, uint32_t flags, void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
-  DNS_REQUIRE((flags & ~DNS_MLP_FP16) == 0, "dns_mlp_fwd: unknown flags 0x%x", flags);
+  DNS_REQUIRE((flags & ~(DNS_MLP_FP16 | DNS_MLP_PREPARED)) == 0, "dns_mlp_fwd: unknown flags 0x%x", flags);
+  const bool prepared = (flags & DNS_MLP_PREPARED) != 0;
+  DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_fwd: prepared images must be 16-byte aligned");
   DNS_REQUIRE(!h_save || (((uintptr_t)h_save) % 16) == 0, "dns_mlp_fwd: h_save must be 16-byte aligned");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
@@ -47,8 +49,11 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   }
   const int rc = ensure_ready((hipStream_t)stream, "dns_mlp_fwd");
   if (rc != DNS_OK) return rc;
+  // DNS_MLP_PREPARED: `params` is what dns_mlp_prepare wrote (the forward images come first in every weight set's block)
+  const unsigned char* prep = prepared ? reinterpret_cast<const unsigned char*>(params) : nullptr;
   return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
-                              row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, (hipStream_t)stream);
+                              row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, prep,
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (hipStream_t)stream);
 }
 
 extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
@@ -60,7 +65,9 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   (void)h_saved;                              // accepted for ABI stability: the backward recomputes the hidden activations
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params, "dns_mlp_bwd: NULL argument");
-  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16)) == 0, "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED)) == 0, "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  const bool prepared = (accumulate_dx & (int)DNS_MLP_PREPARED) != 0;
+  DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_bwd: prepared images must be 16-byte aligned");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_bwd: x must be 16-byte aligned with ldx %% 4 == 0");
@@ -78,5 +85,27 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   if (rc != DNS_OK) return rc;
   return launch_mlp_bwd_split(x, ldx, x2, ldx2, n_in1, dy, lddy, params, n_in, n_out, n_neurons, n_hidden_layers, d_x, lddx,
                               d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride, accumulate_dx & 1,
-                              (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0, st);
+                              (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
+                              prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
+                                       : nullptr,
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), st);
+}
+
+extern "C" uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers) {
+  if (!shape_ok(n_in, n_out, n_neurons, n_hidden_layers)) return 0;
+  return mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers) / 4u;
+}
+
+extern "C" int dns_mlp_prepare(const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
+                               uint32_t n_sets, uint32_t param_stride, float* prepared, void* stream) {
+  if (n_sets == 0) return DNS_OK;
+  DNS_REQUIRE(params && prepared, "dns_mlp_prepare: NULL argument");
+  DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_prepare: unsupported shape in=%u out=%u neurons=%u layers=%u",
+              n_in, n_out, n_neurons, n_hidden_layers);
+  DNS_REQUIRE((((uintptr_t)prepared) % 16) == 0, "dns_mlp_prepare: prepared must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = ensure_ready(st, "dns_mlp_prepare");
+  if (rc != DNS_OK) return rc;
+  return launch_mlp_prepare(params, param_stride, n_in, n_out, n_neurons, n_hidden_layers, n_sets,
+                            reinterpret_cast<unsigned char*>(prepared), st);
 }

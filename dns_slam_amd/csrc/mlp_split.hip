@@ -8,21 +8,6 @@ namespace sp {
 unsigned long long* g_bwd_trace = nullptr;
 #endif
 
-// ---- LDS layout of the forward kernel (bytes) ----
-template <int NN, int NL>
-struct FwdLds {
-  static __host__ __device__ uint32_t ns0(uint32_t n_in) { return (n_in + 15u) / 16u; }
-  static __host__ __device__ uint32_t mt(uint32_t n_out) { return (n_out + 31u) / 32u; }
-  static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
-  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return (NN / 32) * ns0(n_in) * 2048u; }
-  static __host__ __device__ uint32_t img_out(uint32_t n_in) { return img_h(n_in) + (NL - 1) * (NN / 32) * (NN / 16) * 2048u; }
-  static __host__ __device__ uint32_t misc(uint32_t n_in, uint32_t n_out) { return img_out(n_in) + mt(n_out) * (NN / 16) * 2048u; }
-  static __host__ __device__ uint32_t stage(uint32_t n_in, uint32_t n_out) { return misc(n_in, n_out) + 256u; }   // exps + reduction
-  static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, uint32_t nwaves) {
-    return stage(n_in, n_out) + nwaves * STG_WAVE_FLOATS * 4u;
-  }
-};
-
 struct FwdArgs {
   const float* x;
   uint32_t ldx;
@@ -35,6 +20,8 @@ struct FwdArgs {
   const int32_t* tile_group;
   uint32_t param_stride, tiles_per_block;
   float* h_save;
+  const unsigned char* prep;                 // prepared images (NULL: build them from params)
+  uint32_t prep_stride;                      // bytes per weight set
 };
 
 template <int NN, int NL, int PREC>
@@ -53,7 +40,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
   const _Float16* img_h = reinterpret_cast<const _Float16*>(lds + L::img_h(n_in));
   const _Float16* img_out = reinterpret_cast<const _Float16*>(lds + L::img_out(n_in));
   int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
-  float* red = reinterpret_cast<float*>(lds + L::misc(n_in, n_out) + 64);
   float* stg = reinterpret_cast<float*>(lds + L::stage(n_in, n_out)) + wave * STG_WAVE_FLOATS;
   int* rows_all = reinterpret_cast<int*>(stg + STG_FLOATS);
   XChunk xc[4];                                  // n_in <= 128: at most 4 chunks of 32 columns
@@ -65,19 +51,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
     if (grp != cur_group) {
       __syncthreads();
       if (grp >= 0) {
-        const float* pw = a.params + (size_t)grp * a.param_stride;
-        const float* wh = pw + NN * n_in;
-        const float* wout = wh + (NL - 1) * NN * NN;
-        ImgQuads<8> q_in;                                              // 64 x 128 / 4 / 256 threads
-        ImgQuads<4> q_h, q_out;
-        const float m_in = image_load(q_in, pw, NN, n_in);
-        const float m_h = (NL == 2) ? image_load(q_h, wh, NN, NN) : 0.f;
-        const float m_out = image_load(q_out, wout, n_out, NN);
-        lds_zero16(lds, L::misc(n_in, n_out));
-        block_scale_exps(m_in, m_h, m_out, red, wexp);                 // two barriers: the zero fill is complete
-        image_scatter(q_in, const_cast<_Float16*>(img_in), NN, n_in, false, NT, ns0, K_NAT, pow2f(wexp[0]));
-        if (NL == 2) image_scatter(q_h, const_cast<_Float16*>(img_h), NN, NN, false, NT, NN / 16, K_CHAIN, pow2f(wexp[1]));
-        image_scatter(q_out, const_cast<_Float16*>(img_out), n_out, NN, false, mt, NN / 16, K_CHAIN, pow2f(wexp[2]));
+        if (a.prep) {
+          const unsigned char* src = a.prep + (size_t)grp * a.prep_stride;
+          images_copy_in(lds, src, L::misc(n_in, n_out), src + L::misc(n_in, n_out), wexp);
+        }
+        if (!a.prep) build_fwd_images<NN, NL>(lds, a.params + (size_t)grp * a.param_stride, n_in, n_out);
       }
       cur_group = grp;
       __syncthreads();
@@ -317,9 +295,10 @@ static AttrRegistrar split_attr_registrar(split_init_attrs);
 int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* params,
                          uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
                          uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
-                         float* h_save, bool fp16_single, hipStream_t st) {
+                         float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, hipStream_t st) {
   using namespace sp;
   FwdArgs a;
+  a.prep = prep; a.prep_stride = prep_stride;
   a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.params = params; a.n_in = n_in; a.n_out = n_out;
   a.y = y; a.ldy = ldy; a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
   a.h_save = h_save;
@@ -346,9 +325,11 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t lddy, const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
-                         uint32_t param_stride, int acc1, int acc2, bool fp16_single, hipStream_t st) {
+                         uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
+                         hipStream_t st) {
   using namespace sp;
   BwdArgs a;
+  a.prep = prep; a.prep_stride = prep_stride;
 #ifdef DNS_BWD_TRACE
   a.trace = g_bwd_trace;
 #endif
@@ -395,6 +376,38 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
 #undef LAUNCH_DWIN
 #undef LAUNCH_DWIN2
   return check_launch("dns_mlp_bwd(dW_in)");
+}
+
+// ---- prepared weight images (dns_mlp_prepare): per weight set [forward image area | 16 B exponents | backward image area
+// (with the dX image) | 16 B exponents]
+static uint32_t prepared_fwd_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
+  using namespace sp;
+  uint32_t b;
+  if (nn == 32 && nl == 1) b = FwdLds<32, 1>::misc(n_in, n_out);
+  else if (nn == 32) b = FwdLds<32, 2>::misc(n_in, n_out);
+  else if (nl == 1) b = FwdLds<64, 1>::misc(n_in, n_out);
+  else b = FwdLds<64, 2>::misc(n_in, n_out);
+  return b + 16u;
+}
+static uint32_t prepared_bwd_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
+  using namespace sp;
+  if (nn == 32 && nl == 1) return prepared_bwd_bytes_32_1(n_in, n_out);
+  if (nn == 32) return prepared_bwd_bytes_32_2(n_in, n_out);
+  if (nl == 1) return prepared_bwd_bytes_64_1(n_in, n_out);
+  return prepared_bwd_bytes_64_2(n_in, n_out);
+}
+uint32_t mlp_prepared_fwd_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) { return prepared_fwd_bytes(n_in, n_out, nn, nl); }
+uint32_t mlp_prepared_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
+  return prepared_fwd_bytes(n_in, n_out, nn, nl) + prepared_bwd_bytes(n_in, n_out, nn, nl);
+}
+int launch_mlp_prepare(const float* params, uint32_t param_stride, uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl,
+                       uint32_t n_sets, unsigned char* blob, hipStream_t st) {
+  using namespace sp;
+  const uint32_t stride = mlp_prepared_bytes(n_in, n_out, nn, nl), fb = prepared_fwd_bytes(n_in, n_out, nn, nl);
+  if (nn == 32 && nl == 1) return prepare_32_1(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
+  if (nn == 32) return prepare_32_2(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
+  if (nl == 1) return prepare_64_1(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
+  return prepare_64_2(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
 }
 
 }  // namespace dns

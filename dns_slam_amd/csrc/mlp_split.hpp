@@ -227,6 +227,24 @@ __device__ __forceinline__ void lds_zero16(void* p, uint32_t bytes) {   // bytes
   for (uint32_t e = threadIdx.x; e < bytes / 16u; e += blockDim.x) q[e] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Prepared weight images (dns_mlp_prepare): the image area of a kernel's LDS exactly as its prologue builds it, followed by the
+// three scale exponents -- a workgroup then COPIES the area in (13-25 16-byte loads per thread, L2 hits) instead of loading the
+// fp32 matrices, reducing their maxima across the workgroup (two barriers), splitting and scattering them: the weights change
+// once per optimiser step, the prologue ran once per workgroup per launch.
+__device__ __forceinline__ void images_copy_in(unsigned char* lds, const unsigned char* __restrict__ src, uint32_t bytes,
+                                               const unsigned char* __restrict__ exps, int* wexp) {
+  const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+  uint4* d4 = reinterpret_cast<uint4*>(lds);
+  for (uint32_t e = threadIdx.x; e < bytes / 16u; e += blockDim.x) d4[e] = s4[e];
+  if (threadIdx.x < 3) wexp[threadIdx.x] = reinterpret_cast<const int*>(exps)[threadIdx.x];
+}
+__device__ __forceinline__ void images_copy_out(const unsigned char* lds, unsigned char* __restrict__ dst, uint32_t bytes, const int* wexp) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(lds);
+  uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
+  for (uint32_t e = threadIdx.x; e < bytes / 16u; e += blockDim.x) d4[e] = s4[e];
+  if (threadIdx.x < 4) reinterpret_cast<int*>(dst + bytes)[threadIdx.x] = threadIdx.x < 3 ? wexp[threadIdx.x] : 0;
+}
+
 // workgroup-wide maxima of up to 3 values -> power-of-two exponents in wexp[0..2] (LDS); red: 3 * nwaves floats of LDS
 __device__ __forceinline__ void block_scale_exps(float m0, float m1, float m2, float* red, int* wexp) {
   float m[3] = {m0, m1, m2};
@@ -582,6 +600,48 @@ __device__ __forceinline__ void transpose_frags(const f32x16& a, int k_lane, Fra
   wave_lds_fence();
 }
 
+// ---- LDS layout of the forward kernel (bytes) ----
+template <int NN, int NL>
+struct FwdLds {
+  static __host__ __device__ uint32_t ns0(uint32_t n_in) { return (n_in + 15u) / 16u; }
+  static __host__ __device__ uint32_t mt(uint32_t n_out) { return (n_out + 31u) / 32u; }
+  static __host__ __device__ uint32_t img_in(uint32_t) { return 0; }
+  static __host__ __device__ uint32_t img_h(uint32_t n_in) { return (NN / 32) * ns0(n_in) * 2048u; }
+  static __host__ __device__ uint32_t img_out(uint32_t n_in) { return img_h(n_in) + (NL - 1) * (NN / 32) * (NN / 16) * 2048u; }
+  static __host__ __device__ uint32_t misc(uint32_t n_in, uint32_t n_out) { return img_out(n_in) + mt(n_out) * (NN / 16) * 2048u; }
+  static __host__ __device__ uint32_t stage(uint32_t n_in, uint32_t n_out) { return misc(n_in, n_out) + 256u; }   // exps + reduction
+  static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, uint32_t nwaves) {
+    return stage(n_in, n_out) + nwaves * STG_WAVE_FLOATS * 4u;
+  }
+};
+
+
+// the forward kernel's prologue: the three weight matrices of one weight set -> scaled f16 hi/lo operand images in LDS
+template <int NN, int NL>
+__device__ __forceinline__ void build_fwd_images(unsigned char* lds, const float* __restrict__ pw, uint32_t n_in, uint32_t n_out) {
+  using L = FwdLds<NN, NL>;
+  constexpr int NT = NN / 32;
+  const uint32_t ns0 = L::ns0(n_in), mt = L::mt(n_out);
+  _Float16* img_in = reinterpret_cast<_Float16*>(lds + L::img_in(n_in));
+  _Float16* img_h = reinterpret_cast<_Float16*>(lds + L::img_h(n_in));
+  _Float16* img_out = reinterpret_cast<_Float16*>(lds + L::img_out(n_in));
+  int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
+  float* red = reinterpret_cast<float*>(lds + L::misc(n_in, n_out) + 64);
+  const float* wh = pw + NN * n_in;
+  const float* wout = wh + (NL - 1) * NN * NN;
+  ImgQuads<8> q_in;                                              // 64 x 128 / 4 / 256 threads
+  ImgQuads<4> q_h, q_out;
+  const float m_in = image_load(q_in, pw, NN, n_in);
+  const float m_h = (NL == 2) ? image_load(q_h, wh, NN, NN) : 0.f;
+  const float m_out = image_load(q_out, wout, n_out, NN);
+  lds_zero16(lds, L::misc(n_in, n_out));
+  block_scale_exps(m_in, m_h, m_out, red, wexp);                 // two barriers: the zero fill is complete
+  image_scatter(q_in, img_in, NN, n_in, false, NT, ns0, K_NAT, pow2f(wexp[0]));
+  if (NL == 2) image_scatter(q_h, img_h, NN, NN, false, NT, NN / 16, K_CHAIN, pow2f(wexp[1]));
+  image_scatter(q_out, img_out, n_out, NN, false, mt, NN / 16, K_CHAIN, pow2f(wexp[2]));
+}
+
+
 struct BwdArgs {
   const float* x;
   uint32_t ldx;
@@ -599,6 +659,8 @@ struct BwdArgs {
   const int32_t* row_index;
   const int32_t* tile_group;
   uint32_t param_stride, tiles_per_block;
+  const unsigned char* prep;                 // prepared images of the backward kernel (NULL: build them from params)
+  uint32_t prep_stride;                      // bytes per weight set
 #ifdef DNS_BWD_TRACE
   unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
 #endif
@@ -626,6 +688,15 @@ int launch_bwd_32_1(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStre
 int launch_bwd_32_2(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
 int launch_bwd_64_1(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
 int launch_bwd_64_2(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStream_t st);
+#define DNS_DECL_PREP(nn, nl)                                                                                                  \
+  uint32_t prepared_bwd_bytes_##nn##_##nl(uint32_t n_in, uint32_t n_out);                                                     \
+  int prepare_##nn##_##nl(const float* params, uint32_t param_stride, uint32_t n_in, uint32_t n_out, uint32_t n_sets,         \
+                          unsigned char* blob, uint32_t fwd_bytes, uint32_t blob_stride, hipStream_t st);
+DNS_DECL_PREP(32, 1)
+DNS_DECL_PREP(32, 2)
+DNS_DECL_PREP(64, 1)
+DNS_DECL_PREP(64, 2)
+#undef DNS_DECL_PREP
 
 // adds the workgroup's four copies of one 32 x 32 accumulator tile (rows = dW rows, lanes = dW columns) and issues the
 // float atomics: one 128-byte row segment per lane half per instruction

@@ -504,6 +504,19 @@ class TrackStep:
         self.d_x3 = f(P, 3)
         raw_lib = ops.lib._raw
         self.ray_ws = f(max(int(raw_lib.dns_raygen_bwd_ws_floats(1, N)), 1))
+        # The scene is frozen for the whole loop: its networks' operand images are built ONCE (DNS_MLP_PREPARED) and every
+        # launch copies them in instead of rebuilding them per workgroup (0.253 -> 0.245 ms per iteration).  MapStep does not
+        # use this: its weights change every step, and in the two-stream step the five extra launches plus the copy-in traffic
+        # cost more than the per-workgroup rebuild (measured on one box: 2.105 without, 2.111 with the images but no
+        # re-preparation, 2.133 with both; stand-alone the prepared launches are 1-3 us (forward) and 4-7 us (backward) faster).
+        self.PREP = ops.MLP_PREPARED_FLAG
+        self.w = []
+        for p_, shp_ in ((self.p_coarse, self.shp_c), (self.p_color, self.shp_col), (self.p_logit, self.shp_log)):
+            w = f(int(raw_lib.dns_mlp_prepared_floats(*shp_)))
+            check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w),
+                                          _V(torch.cuda.current_stream().cuda_stream)), "dns_mlp_prepare")
+            self.w.append(w)
+        self.w_coarse, self.w_color, self.w_logit = self.w
         self.lam = (C.c_float * 8)(t.lambda_p, t.lambda_d, t.lambda_l, 0.0, 0.0, 0.0, 0.0, 1.0)
         self.camv = (C.c_double * 4)(float(t.fx), float(t.fy), float(t.cx), float(t.cy))
         self.b6 = ops._bound6(t.bound)
@@ -535,18 +548,18 @@ class TrackStep:
         meta = C.byref(self.meta.c)
         check(lib.dns_encode_fwd(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf), ld,
                                  _V(self.buf.data_ptr() + 4 * pe), ld, ptr(self.dydx), st), "dns_encode_fwd")
-        fp16 = self.fp16
+        fp16 = self.fp16 | self.PREP
 
         def fwd(x2, n_in1, params, shape, y):
             n_in, n_out, nn, nl = shape
             check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
                                   nn, nl, ptr(y), y.stride(0), P, None, None, 0, None, fp16, st), "dns_mlp_fwd")
 
-        fwd(None, 0, self.p_coarse, self.shp_c, self.lat)                  # coarse-only render (slams/tracking.py:196-200)
+        fwd(None, 0, self.w_coarse, self.shp_c, self.lat)                  # coarse-only render (slams/tracking.py:196-200)
         check(lib.dns_feature_block(ptr(self.lat), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
                                     ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
-        fwd(self.feat, pe, self.p_color, self.shp_col, self.raw)
-        fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit)
+        fwd(self.feat, pe, self.w_color, self.shp_col, self.raw)
+        fwd(self.feat, pe, self.w_logit, self.shp_log, self.logit)
         check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
         Cn = self.n_class
         check(lib.dns_composite_fwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
@@ -578,9 +591,9 @@ class TrackStep:
                   "dns_mlp_bwd")
 
         d_feat = self.d_featx[:, 4:]
-        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, 1)        # d_buf (zeroed) += ; feature block =
-        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, 3)
-        bwd(None, 0, self.d_featx[:, 3:3 + self.hid + 1], self.p_coarse, self.shp_c, None, 1)
+        bwd(self.feat, pe, self.d_col, self.w_color, self.shp_col, d_feat, 1)        # d_buf (zeroed) += ; feature block =
+        bwd(self.feat, pe, self.d_logit, self.w_logit, self.shp_log, d_feat, 3)
+        bwd(None, 0, self.d_featx[:, 3:3 + self.hid + 1], self.w_coarse, self.shp_c, None, 1)
         check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld,
                                  _V(self.d_buf.data_ptr() + 4 * pe), ld, None, ptr(self.d_x3), ptr(self.dydx), None, 0, 0, st),
               "dns_encode_bwd")

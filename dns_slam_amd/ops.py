@@ -25,7 +25,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._raw, name)
-        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_encode_bwd_ws_floats", "dns_raygen_bwd_ws_floats", "dns_last_error",
+        if self.records is None or name in ("dns_grid_meta_init", "dns_mlp_bwd_ws_floats", "dns_mlp_prepared_floats", "dns_encode_bwd_ws_floats", "dns_raygen_bwd_ws_floats", "dns_last_error",
                                             "dns_abi_version", "dns_init") or name.startswith("dns_kernel_timing"):
             return fn
 
@@ -232,6 +232,7 @@ def _row_major_2d(x: torch.Tensor) -> torch.Tensor:
 LOSS_SUMS_FLOATS = 32 + 5 * 1024          # include/dns_hip.h DNS_LOSS_SUMS_FLOATS
 MLP_SAVE_HIDDEN = False
 MLP_FP16_FLAG = 0x100                      # include/dns_hip.h DNS_MLP_FP16
+MLP_PREPARED_FLAG = 0x200                  # include/dns_hip.h DNS_MLP_PREPARED
 
 
 class _MlpFn(torch.autograd.Function):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 6
+#define DNS_ABI_VERSION 7
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -184,6 +184,17 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class
  * fine decoders of slams/mapping.py:590-601 without gathering activations. */
 #define DNS_MLP_FP16 0x100u   /* flags of dns_mlp_fwd; bit 8 of accumulate_dx of dns_mlp_bwd */
+/* DNS_MLP_PREPARED (flags of dns_mlp_fwd, bit 9 of accumulate_dx of dns_mlp_bwd): `params` points to what dns_mlp_prepare wrote
+ * for the same (n_in, n_out, n_neurons, n_hidden_layers) -- the scaled, split operand images of the kernels' LDS prologue --
+ * instead of to the fp32 matrices: every workgroup then copies its weight set's images in (L2 hits) instead of loading,
+ * reducing, splitting and scattering the matrices itself.  Results are bit-identical.  The weights change once per optimiser
+ * step and are used by ~10 launches of hundreds of workgroups each; param_stride keeps its meaning (fp32 floats per weight
+ * set: it still addresses d_params), the prepared sets are dns_mlp_prepared_floats(...) floats apart.
+ * dns_mlp_prepare: params [n_sets, param_stride] -> prepared [n_sets, dns_mlp_prepared_floats] (16-byte aligned). */
+#define DNS_MLP_PREPARED 0x200u
+uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers);
+int dns_mlp_prepare(const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
+                    uint32_t n_sets, uint32_t param_stride, float* prepared, void* stream);
 int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,

@@ -706,3 +706,52 @@ def test_kernel_timing_spans():
     # disarmed: nothing is recorded
     ops.encode(x, table.detach(), pm, None, 16, True, True)
     assert ops.timer.records is None
+
+
+@pytest.mark.parametrize("n_in,n_out,nn,nl,grouped", [(80, 33, 64, 2, False), (112, 8, 64, 2, False), (80, 33, 32, 1, False),
+                                                       (80, 1, 64, 2, False), (80, 33, 64, 2, True), (32, 32, 32, 2, False)])
+def test_mlp_prepared_images_are_bit_identical(n_in, n_out, nn, nl, grouped):
+    """DNS_MLP_PREPARED: dns_mlp_prepare writes the operand images the kernels' prologue would build (once per weight set); the
+    forward and the backward (dX, dW, with and without dX) then COPY them in -- every output bit-identical."""
+    import ctypes as C
+    ops = _ops()
+    from dns_slam_amd._lib import check, ptr, stream_ptr
+    lib = ops.lib
+    g = torch.Generator().manual_seed(17)
+    P, G = 3000, (3 if grouped else 1)
+    count = ops.mlp_param_count(n_in, n_out, nn, nl)
+    params = (torch.randn(G, count, generator=g) * 0.2).to(DEV)
+    x = torch.randn(P, n_in, generator=g).to(DEV)
+    dy = torch.randn(P, n_out, generator=g).to(DEV)
+    ri = tg = None
+    n_slots = P
+    if grouped:
+        slot = torch.randint(0, G, (P,), generator=g).to(DEV)
+        ri, tg, n_slots = ops.group_slots(slot, G, 2)
+    nf = int(lib.dns_mlp_prepared_floats(n_in, n_out, nn, nl))
+    assert nf > 0 and nf % 4 == 0
+    prep = torch.empty(G, nf, device=DEV)
+    check(lib.dns_mlp_prepare(ptr(params), n_in, n_out, nn, nl, G, count, ptr(prep), stream_ptr()), "dns_mlp_prepare")
+    stride = count if grouped else 0
+    ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(n_slots, nn, nl)), device=DEV)
+    outs = []
+    for prepared in (False, True):
+        w, flag = (prep, ops.MLP_PREPARED_FLAG) if prepared else (params, 0)
+        y = torch.zeros(P, n_out, device=DEV)
+        check(lib.dns_mlp_fwd(ptr(x), n_in, None, 0, 0, ptr(w), n_in, n_out, nn, nl, ptr(y), n_out, n_slots, ptr(ri), ptr(tg), stride,
+                              None, flag, stream_ptr()), "dns_mlp_fwd")
+        res = [y]
+        for need_dx in (True, False):
+            dx = torch.zeros(P, n_in, device=DEV) if need_dx else None
+            dp = torch.zeros_like(params)
+            check(lib.dns_mlp_bwd(ptr(x), n_in, None, 0, 0, ptr(dy), n_out, ptr(w), n_in, n_out, nn, nl, ptr(dx), n_in, None, 0, ptr(dp),
+                                  ptr(ws), n_slots, ptr(ri), ptr(tg), stride, None, flag, stream_ptr()), "dns_mlp_bwd")
+            res += [dx, dp] if need_dx else [dp]
+        outs.append(res)
+    torch.cuda.synchronize()
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
+    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dW (with dx)", "dW (without dx)")):
+        if name.startswith("dW"):                 # float atomics across workgroups: order-dependent sums, not bit-stable run to run
+            assert_close(b.cpu(), a.cpu(), rtol=1e-5, elementwise=False, what=f"prepared images: {name}")
+        else:
+            assert torch.equal(a, b), name
