@@ -320,7 +320,11 @@ def test_cfg2_fullsize_matches_oracle():
     assert ql[0].grad is None
 
 
-def test_cfg2_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(monkeypatch):
+@pytest.mark.parametrize("workload,combos", [
+    ("cfg2", ((False, False), (False, True), (False, True), (True, False), (True, True), (True, True))),
+    ("cfg3", ((False, True), (True, False), (True, True))),             # the 2-D code through the truncation mask (feature block)
+    ("cfg5_fp16", ((False, True), (True, True)))])                      # 8192 x 128, T = 2^20, fp16-operand networks
+def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(workload, combos):
     """Mapper.prefetch_draws (the benchmark's default with two streams: iteration k+1's pixel / jitter / lattice draws are
     enqueued on the side stream during iteration k): same generator order, so the losses of 16 full-size iterations
     launched WITHOUT any host synchronisation equal the unprefetched run's up to the run-to-run noise of the float
@@ -330,10 +334,10 @@ def test_cfg2_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(m
     from dns_slam_amd import dist as dd
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
     runs = []
-    for fused, prefetch in ((False, False), (False, True), (False, True), (True, False), (True, True), (True, True)):
+    for fused, prefetch in combos:
         # the autograd-driven step and the fixed launch sequence (fused_step.MapStep: its next step's draws, depth maxima and
         # decoder routing are prepared on the side stream too) make the same generator calls in the same order
-        cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS["cfg2"], DEV, seed=100, dist_ctx=dd.DistCtx(),
+        cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS[workload], DEV, seed=100, dist_ctx=dd.DistCtx(),
                                                             overlap=True, prefetch=prefetch, fused_step=fused)
         assert mapper.prefetch_draws == prefetch and (getattr(mapper, "map_step", None) is not None) == fused
         losses = []
