@@ -12,6 +12,7 @@
 // (__fmul_rn/__fadd_rn, never contracted), the cell is (uint32)(int)floorf(pos); hash primes
 // {1, 2654435761, 805459861}; index % level size.  Those make the table rows bit-exact.
 #include <type_traits>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace dns {
@@ -1028,11 +1029,14 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       total_chunks += chunk_of[l];
     }
     if (total_chunks == 0) total_chunks = 1;
-    // ~512 workgroups in all: a dense level's jobs are sliced 4x (one chunk) / 2x finer, see below
+    // ~1280 workgroups in all (five per CU; one fits a CU at a time): a dense level's jobs are sliced 4x (one chunk) / 2x finer,
+    // see below.  Round 2 aimed at 512 (two rounds): stand-alone the kernel does not care (221-224 us at 5, 10 slices per hashed
+    // level), but inside the two-stream step finer jobs leave fewer CUs idle behind the last round and interleave better with
+    // the other stream's kernels: 2.08-2.10 -> 2.05-2.07 ms per step at 10-12 slices, worse again at 16-20
     uint32_t weight = 0;
     for (uint32_t l = 0; l < lv.n_levels; ++l) weight += chunk_of[l] * (lv.hashed[l] ? 1u : (chunk_of[l] == 1 ? 4u : 2u));
     if (weight == 0) weight = 1;
-    uint32_t ns = (512u + weight - 1) / weight;
+    uint32_t ns = (1280u + weight - 1) / weight;
     if (ns < 1) ns = 1;
     const uint32_t max_ns = (P + 1023) / 1024;                 // at least ~one point per thread
     if (ns > max_ns) ns = max_ns ? max_ns : 1;
