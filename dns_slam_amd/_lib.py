@@ -55,6 +55,7 @@ SIGNATURES = {
     "dns_mlp_fwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _P, _U, _P]),
     "dns_mlp_bwd": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U, _P, _P, _U, _P, _P, _U, _P, _I, _P]),
     "dns_mlp_bwd_ws_floats": (C.c_uint64, [_U, _U, _U]),
+    "dns_mlp_dwin": (C.c_int, [_P, _U, _P, _U, _U, _U, _U, _U, _P, _P, _U, _P, _P, _U, _U, _P]),
     "dns_mlp_prepared_floats": (C.c_uint64, [_U, _U, _U, _U]),
     "dns_mlp_prepare": (C.c_int, [_P, _U, _U, _U, _U, _U, _U, _P, _P]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

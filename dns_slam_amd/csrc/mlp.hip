@@ -65,7 +65,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   (void)h_saved;                              // accepted for ABI stability: the backward recomputes the hidden activations
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params, "dns_mlp_bwd: NULL argument");
-  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED)) == 0, "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN)) == 0,
+              "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
   const bool prepared = (accumulate_dx & (int)DNS_MLP_PREPARED) != 0;
   DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_bwd: prepared images must be 16-byte aligned");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
@@ -88,7 +89,28 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                               (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
                               prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
                                        : nullptr,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), st);
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, st);
+}
+
+extern "C" int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in,
+                            uint32_t n_neurons, uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots,
+                            const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream) {
+  if (n_slots == 0) return DNS_OK;
+  DNS_REQUIRE(x && d_params && ws, "dns_mlp_dwin: NULL argument");
+  DNS_REQUIRE((flags & ~DNS_MLP_FP16) == 0, "dns_mlp_dwin: unknown flags 0x%x", flags);
+  DNS_REQUIRE(shape_ok(n_in, 1, n_neurons, n_hidden_layers), "dns_mlp_dwin: unsupported shape in=%u neurons=%u layers=%u", n_in,
+              n_neurons, n_hidden_layers);
+  DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)ws) % 16) == 0, "dns_mlp_dwin: x / ws must be 16-byte aligned with ldx %% 4 == 0");
+  {
+    const int rc = check_segments("dns_mlp_dwin", x2, ldx2, n_in1, n_in);
+    if (rc != DNS_OK) return rc;
+  }
+  if (!x2) n_in1 = n_in;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = ensure_ready(st, "dns_mlp_dwin");
+  if (rc != DNS_OK) return rc;
+  return launch_mlp_dwin(x, ldx, x2, ldx2, n_in1, n_in, n_neurons, n_hidden_layers, d_params, ws, n_slots, row_index, tile_group,
+                         param_stride, (flags & DNS_MLP_FP16) != 0, st);
 }
 
 extern "C" uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers) {

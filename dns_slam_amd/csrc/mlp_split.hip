@@ -326,7 +326,7 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
-                         hipStream_t st) {
+                         bool with_dwin, hipStream_t st) {
   using namespace sp;
   BwdArgs a;
   a.prep = prep; a.prep_stride = prep_stride;
@@ -348,10 +348,21 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
   else if (n_neurons == 32 && n_hidden_layers == 2) rc = launch_bwd_32_2(a, blocks, fp16_single, st);
   else if (n_neurons == 64 && n_hidden_layers == 1) rc = launch_bwd_64_1(a, blocks, fp16_single, st);
   else rc = launch_bwd_64_2(a, blocks, fp16_single, st);
-  if (rc != DNS_OK || !d_params) return rc;
+  if (rc != DNS_OK || !d_params || !with_dwin) return rc;
   // dW_in = dH_1^T X from the workspace the first kernel wrote
+  return launch_mlp_dwin(x, ldx, x2, ldx2, n_in1, n_in, n_neurons, n_hidden_layers, d_params, ws, n_slots, row_index, tile_group,
+                         param_stride, fp16_single, st);
+}
+
+// the streaming weight-gradient kernel of the first layer on its own (dns_mlp_dwin; the second half of dns_mlp_bwd)
+int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
+                    uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
+                    const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st) {
+  using namespace sp;
+  (void)n_hidden_layers;
+  const uint32_t n_btiles = (n_slots + 127u) / 128u;
   DwinArgs d;
-  d.dh1 = ws; d.x = x; d.ldx = ldx; d.seg = a.seg; d.n_in = n_in; d.d_params = d_params; d.n_slots = n_slots;
+  d.dh1 = ws; d.x = x; d.ldx = ldx; d.seg = {x2, ldx2, x2 ? n_in1 : n_in}; d.n_in = n_in; d.d_params = d_params; d.n_slots = n_slots;
   d.row_index = row_index; d.tile_group = tile_group; d.param_stride = param_stride;
   uint32_t tpb2 = (n_btiles + 511u) / 512u;      // two workgroups per CU
   if (tpb2 < 1) tpb2 = 1;

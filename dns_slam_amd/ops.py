@@ -233,6 +233,7 @@ LOSS_SUMS_FLOATS = 32 + 5 * 1024          # include/dns_hip.h DNS_LOSS_SUMS_FLOA
 MLP_SAVE_HIDDEN = False
 MLP_FP16_FLAG = 0x100                      # include/dns_hip.h DNS_MLP_FP16
 MLP_PREPARED_FLAG = 0x200                  # include/dns_hip.h DNS_MLP_PREPARED
+MLP_NO_DWIN_FLAG = 0x400                   # include/dns_hip.h DNS_MLP_NO_DWIN
 
 
 class _MlpFn(torch.autograd.Function):

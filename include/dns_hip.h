@@ -192,6 +192,14 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * set: it still addresses d_params), the prepared sets are dns_mlp_prepared_floats(...) floats apart.
  * dns_mlp_prepare: params [n_sets, param_stride] -> prepared [n_sets, dns_mlp_prepared_floats] (16-byte aligned). */
 #define DNS_MLP_PREPARED 0x200u
+/* DNS_MLP_NO_DWIN (bit 10 of accumulate_dx of dns_mlp_bwd): the backward kernel leaves dH_1 in ws as always, but the second,
+ * streaming kernel (dW_in = dH_1^T x) is NOT launched: the caller launches it with dns_mlp_dwin -- same x / ws / d_params /
+ * slot arguments -- possibly on ANOTHER stream: it is memory-bound and independent of everything that follows in the
+ * backward pass except d_params, so it runs beside the next network's (vector-bound) backward kernel (fused_step.MapStep). */
+#define DNS_MLP_NO_DWIN 0x400u
+int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
+                 uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
+                 const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);
 uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers);
 int dns_mlp_prepare(const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
                     uint32_t n_sets, uint32_t param_stride, float* prepared, void* stream);
