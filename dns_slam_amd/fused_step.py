@@ -395,8 +395,14 @@ class MapStep:
             self.n_slots, self.p_pool.shape[-1], 1)
         work = None
         if self.world > 1:
+            # colour | logit | pool gradients are complete once the LAST forked dW_in has run: with the fork the all-reduce is
+            # issued from the side stream (behind that kernel, which itself waited for the fine network's backward kernel)
             import torch.distributed as dist
-            work = dist.all_reduce(cur.G_early, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
+            if fork_dwin:
+                with torch.cuda.stream(self.side):
+                    work = dist.all_reduce(cur.G_early, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
+            else:
+                work = dist.all_reduce(cur.G_early, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
         d_grid = _V(self.d_buf.data_ptr() + 4 * pe)
         fork_pose = self.is_BA and on_side
         if fork_pose:

@@ -755,3 +755,35 @@ def test_mlp_prepared_images_are_bit_identical(n_in, n_out, nn, nl, grouped):
             assert_close(b.cpu(), a.cpu(), rtol=1e-5, elementwise=False, what=f"prepared images: {name}")
         else:
             assert torch.equal(a, b), name
+
+
+def test_mlp_dwin_alone_equals_the_backward_with_it():
+    """DNS_MLP_NO_DWIN + dns_mlp_dwin (the streaming dW_in = dH_1^T x kernel launched by the caller, e.g. on another stream)
+    against dns_mlp_bwd launching both: same dX, same weight gradients (two-segment input, accumulate flags)."""
+    ops = _ops()
+    from dns_slam_amd._lib import check, ptr, stream_ptr
+    lib = ops.lib
+    g = torch.Generator().manual_seed(23)
+    P, n1, n2, n_out, nn, nl = 5000, 48, 64, 8, 64, 2
+    n_in = n1 + n2
+    count = ops.mlp_param_count(n_in, n_out, nn, nl)
+    params = (torch.randn(count, generator=g) * 0.2).to(DEV)
+    x1, x2 = torch.randn(P, 80, generator=g).to(DEV), torch.randn(P, n2, generator=g).to(DEV)
+    dy = torch.randn(P, n_out, generator=g).to(DEV)
+    ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(P, nn, nl)), device=DEV)
+    res = []
+    for split in (False, True):
+        d1, d2, dp = torch.zeros(P, 80, device=DEV), torch.zeros(P, n2, device=DEV), torch.zeros(count, device=DEV)
+        flag = ops.MLP_NO_DWIN_FLAG if split else 0
+        check(lib.dns_mlp_bwd(ptr(x1), 80, ptr(x2), n2, n1, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(d1), 80, ptr(d2), n2,
+                              ptr(dp), ptr(ws), P, None, None, 0, None, 3 | flag, stream_ptr()), "dns_mlp_bwd")
+        if split:
+            w_in = dp[:nn * n_in].clone()
+            assert float(w_in.abs().max()) == 0.0                      # the first layer's block is untouched until ...
+            check(lib.dns_mlp_dwin(ptr(x1), 80, ptr(x2), n2, n1, n_in, nn, nl, ptr(dp), ptr(ws), P, None, None, 0, 0, stream_ptr()),
+                  "dns_mlp_dwin")
+        res.append((d1, d2, dp))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[1][2][:nn * n_in].abs().max()) > 0
+    assert_close(res[1][2].cpu(), res[0][2].cpu(), rtol=1e-5, elementwise=False, what="dW with dns_mlp_dwin launched separately")
