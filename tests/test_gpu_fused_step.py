@@ -138,6 +138,48 @@ def test_map_step_without_smoothness_and_single_stream():
         assert abs(a - b) <= 1e-4 * abs(a), out
 
 
+def test_map_step_single_frame_optimises_its_pose():
+    """One target frame (the first mapping call, slams/mapping.py:447-455: with n_target_frame == 1 the only frame's pose IS
+    optimised): MapStep against the autograd iteration."""
+    from dns_slam_amd.fused_step import MapStep
+    out = []
+    for fused in (False, True):
+        cfg, bound, cam, frames, dec, mapper = _setup()
+        one = {k: (v[:1] if (torch.is_tensor(v) or isinstance(v, list)) else v) for k, v in frames.items()}
+        mapper.n_target_frame = 1
+        mapper.static_shapes, mapper.is_BA, mapper.overlap_smooth, mapper.prefetch_draws = True, True, True, True
+        opt, ql, Tl = mapper.set_optimizer(one, fused=True)
+        assert ql[0].requires_grad
+        for grp, lr in zip(opt.param_groups, (mapper.lr, mapper.BA_cam_lr, mapper.BA_cam_lr)):
+            grp["lr"] = lr
+        prep = mapper.prepare_frames(one)
+        torch.manual_seed(4)
+        torch.cuda.manual_seed(4)
+        hist = []
+        ms = MapStep(mapper, one, ql, Tl, prep=prep) if fused else None
+        for _ in range(4):
+            if fused:
+                ms.step()
+                hist.append(float(ms.losses()[0]))
+            else:
+                opt.zero_grad(set_to_none=True)
+                s = mapper.get_target_samples(one, ql, Tl, prep=prep)
+                loss, _ = mapper.iteration_loss(s, lambda_lt=10.0, smooth=True)
+                loss.backward()
+                opt.step()
+                hist.append(float(loss.detach()))
+        if fused:
+            ms.write_back()
+        torch.cuda.synchronize()
+        out.append((hist, ql[0].detach().cpu().clone(), Tl[0].detach().cpu().clone()))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert abs(a - b) <= 1e-4 * abs(a), (out[0][0], out[1][0])
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-5 and float((out[0][2] - out[1][2]).abs().max()) <= 2e-5
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    from dns_slam_amd.common import get_quad_from_c2w
+    assert float((out[1][1] - get_quad_from_c2w(frames["est_c2w"][0])).abs().max()) > 0          # and the pose did move
+
+
 def test_optimize_frames_through_map_step():
     """``Mapper.optimize_frames`` with ``use_map_step``: the reference's driver (set_decoder, the lambda_lt schedule of
     slams/mapping.py:893-896, pose write-back :914-926) around the fixed launch sequence -- same result as the autograd loop."""
