@@ -212,8 +212,8 @@ def capture(step, n_warm=3):
     """Capture one full iteration (sampling -> ... -> Adam) into a hipGraph; replays draw fresh rays (graph-safe Philox
     offsets).  Returns a zero-argument callable returning the (static) loss tensor.  Valid since the library stopped issuing
     hipMemsetAsync (memset nodes of a captured graph stop clearing their destination after a host synchronisation on ROCm
-    7.0.51831 -- DESIGN.md section 5), but not the default: replayed on one stream the iteration takes 2.51 ms, with the
-    smoothness branch captured as a parallel branch 2.56, launched eagerly on two streams 2.35."""
+    7.0.51831 -- DESIGN.md section 5), but not the default: a graph's branches do not run concurrently on this ROCm (round 3: 2.28 ms
+    replayed against 1.90 launched eagerly on two streams)."""
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):

@@ -11,7 +11,10 @@ gradients -- runs on the side stream, and Adam (csrc/adam.hip) steps all paramet
 Everything that depends only on the random draws -- the draws themselves, the per-frame maximum of the sampled depths, the
 class -> decoder routing of every sample (``dns_class_slots`` + ``dns_group_slots``) and the zero fills of the buffers the step
 accumulates into -- is prepared ONE STEP AHEAD on the side stream into one of two alternating sets of buffers (``_Set``), so
-none of it sits on the main stream's chain of dependent kernels.
+none of it sits on the main stream's chain of dependent kernels.  The memory-bound kernels of the backward that nothing
+downstream waits for -- ``dW_in`` of every network (``dns_mlp_dwin``), the pose gradient -- run on the side stream as well,
+beside the vector-bound backward kernels / table scatter on the main stream (2.31 -> 1.90 ms per iteration
+at 4096 rays x 64 samples).
 
 Same kernels, same arithmetic, same random draws (``Mapper._draw_all``, same generator order) as the autograd path: tests/test_gpu_fused_step.py
 holds the two against each other (losses, every parameter after several iterations).  No CPU path: the constructor raises
