@@ -102,7 +102,7 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
-                         bool with_dwin, hipStream_t st);
+                         bool with_dwin, const float* h_saved, hipStream_t st);
 int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                     uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
                     const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st);

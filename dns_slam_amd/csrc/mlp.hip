@@ -62,7 +62,6 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                            float* d_params, float* ws, uint32_t n_slots, const int32_t* row_index,
                            const int32_t* tile_group, uint32_t param_stride, const float* h_saved, int accumulate_dx,
                            void* stream) {
-  (void)h_saved;                              // accepted for ABI stability: the backward recomputes the hidden activations
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params, "dns_mlp_bwd: NULL argument");
   DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN)) == 0,
@@ -73,6 +72,7 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_bwd: x must be 16-byte aligned with ldx %% 4 == 0");
   DNS_REQUIRE(!d_params || (ws && (((uintptr_t)ws) % 16) == 0), "dns_mlp_bwd: d_params needs a 16-byte aligned workspace ws");
+  DNS_REQUIRE(!h_saved || (((uintptr_t)h_saved) % 16) == 0, "dns_mlp_bwd: h_saved must be 16-byte aligned");
   {
     const int rc = check_segments("dns_mlp_bwd", x2, ldx2, n_in1, n_in);
     if (rc != DNS_OK) return rc;
@@ -89,7 +89,7 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                               (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
                               prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
                                        : nullptr,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, st);
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, st);
 }
 
 extern "C" int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in,

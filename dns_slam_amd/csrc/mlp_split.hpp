@@ -323,6 +323,33 @@ __device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restric
   for (int i = 0; i < 4; ++i) xc.v[i] = *reinterpret_cast<const float4*>(base + (size_t)(uint32_t)rows[i] * ld);
 }
 
+// Saved hidden activations (dns_mlp_fwd's h_save, slot-major rows of n_neurons floats): 32 columns of the tile's 32 slots in
+// the XChunk load layout, and the read that turns the staged chunk into an ACCUMULATOR-layout tile (lane = point column,
+// register r = hidden row (r & 3) + 8 (r >> 2) + 4 h) -- the inverse of store_tile_rows_scalar's staging write.
+__device__ __forceinline__ void h_chunk_issue(XChunk& hc, const float* __restrict__ hs, uint32_t nn, uint32_t slot0, uint32_t n_slots,
+                                              uint32_t t, uint32_t lane) {
+  const float* base = hs + 32u * t + 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t slot = min(slot0 + (lane >> 3) + 8u * i, n_slots - 1u);
+    // component-wise: a plain struct copy here and in x_chunk_commit is two memcpys (global -> private -> LDS) that the
+    // compiler leaves in scratch memory -- the chunk is never read as a value on this path
+    const float4 t = *reinterpret_cast<const float4*>(base + (size_t)slot * nn);
+    hc.v[i] = make_float4(t.x, t.y, t.z, t.w);
+  }
+}
+__device__ __forceinline__ f32x16 acc_tile_read(const float* __restrict__ stg, uint32_t lane) {
+  const float* src = stg + (lane & 31u) * STG_LD + 4u * (lane >> 5);
+  f32x16 a;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(src + 8 * g);
+    a[4 * g] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+  }
+  wave_lds_fence();
+  return a;
+}
+
 // max |x| of every row of the tile over all its chunks (still in the load layout: 8 lanes share a row) -> rmax[32] in LDS.
 // The point's scale must be known before its first operand is converted, and this costs 12 cross-lane steps per tile
 // where keeping the whole half row in registers until its maximum is known cost 48 registers.
@@ -659,6 +686,7 @@ struct BwdArgs {
   const int32_t* row_index;
   const int32_t* tile_group;
   uint32_t param_stride, tiles_per_block;
+  const float* h_saved;                      // [n_hidden_layers][n_slots][n_neurons] hidden activations the forward kept (NULL: recompute)
   const unsigned char* prep;                 // prepared images of the backward kernel (NULL: build them from params)
   uint32_t prep_stride;                      // bytes per weight set
 #ifdef DNS_BWD_TRACE

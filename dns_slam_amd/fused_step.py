@@ -46,7 +46,7 @@ class _Set:
 
 class MapStep:
     def __init__(self, mapper, target_frames, quad_list=None, T_list=None, prep=None, features=None, lambda_lt=10.0,
-                 smooth=True, betas=(0.9, 0.999), eps=1e-8):
+                 smooth=True, betas=(0.9, 0.999), eps=1e-8, keep_hidden=False):
         m = self.m = mapper
         dev = self.dev = torch.device(m.device)
         if dev.type != "cuda":
@@ -176,6 +176,13 @@ class MapStep:
         self.ws_mlp = max((mlp_ws(self.n_slots, s) for s in (self.shp_f, self.shp_c, self.shp_col, self.shp_log)),
                           key=lambda t: t.numel())
         self.ws_mlp4 = [self.ws_mlp] + [torch.empty_like(self.ws_mlp) for _ in range(3)]   # one per network when dW_in is forked
+        # Hidden activations kept by the forward for the backward (dns_mlp_fwd h_save -> dns_mlp_bwd h_saved) instead of being
+        # recomputed: stand-alone the backward kernel is 17 % faster (122 -> 101 us) and the forward 18 % slower (46 -> 54 us),
+        # but in this two-stream step the extra 0.76 GB of traffic per iteration costs more than the vector work it saves
+        # (1.917 -> 1.944 ms with every network keeping them, 1.915 with the lattice branch alone): off by default
+        self.keep_h = self.keep_h_lat = bool(keep_hidden)
+        hbuf = lambda n_slots, s: f(s[3] * n_slots * s[2]) if self.keep_h else None
+        self.h_c, self.h_f, self.h_col, self.h_log = hbuf(P, self.shp_c), hbuf(self.n_slots, self.shp_f), hbuf(P, self.shp_col), hbuf(P, self.shp_log)
         self.scatter_form, self.scatter_cap = ops.SCATTER_FORM
         enc_ws = lambda n: f(max(int(raw_lib.dns_encode_bwd_ws_floats(n, C.byref(self.meta.c), self.scatter_form, self.scatter_cap)), 4))
         self.ws_enc = enc_ws(P)
@@ -198,6 +205,7 @@ class MapStep:
             self.tv = f(1)
             self.w_sm = torch.full((1,), m.lambda_sm / self.world, device=dev)
             self.ws_mlp_l = mlp_ws(Pl, self.shp_c)
+            self.h_l = f(self.shp_c[3] * Pl * self.shp_c[2]) if self.keep_h_lat else None
             self.ws_enc_l = enc_ws(Pl)
         if getattr(m, "_side_stream", None) is None:
             m._side_stream = torch.cuda.Stream(device=dev)
@@ -218,12 +226,12 @@ class MapStep:
                                  grid_l, ld, None, st), "dns_encode_fwd")
         n_in, _, nn, nl = self.shp_c
         check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
-                              None, None, 0, None, self.fp16, st), "dns_mlp_fwd")
+                              None, None, 0, ptr(self.h_l), self.fp16, st), "dns_mlp_fwd")
         check(lib.dns_tv_fwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.tv), st), "dns_tv_fwd")
         check(lib.dns_tv_bwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ), st),
               "dns_tv_bwd")
         check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
-                              ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, None,
+                              ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, ptr(self.h_l),
                               self.fp16, st), "dns_mlp_bwd")
         d_grid_l = _V(self.d_bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
@@ -324,19 +332,19 @@ class MapStep:
         # ---- the four networks (slams/mapping.py:616-626)
         fp16 = self.fp16
 
-        def fwd(x2, n_in1, params, shape, y, ri, tg, n_slots, stride):
+        def fwd(x2, n_in1, params, shape, y, ri, tg, n_slots, stride, hs):
             n_in, n_out, nn, nl = shape
             check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
-                                  nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, None, fp16, st), "dns_mlp_fwd")
+                                  nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(hs), fp16, st), "dns_mlp_fwd")
 
-        fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0)
+        fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0, self.h_c)
         fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
-        fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1])
+        fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1], self.h_f)
         # (latents | truncated 2-D code) for the colour / logit networks, occupancy into the compositing input (:553-556, :622-627)
         check(lib.dns_feature_block(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
                                     ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
-        fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0)
-        fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0)
+        fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0, self.h_col)
+        fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0, self.h_log)
         check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
         # ---- compositing + losses (utils/common.py:506-537, slams/mapping.py:887-907)
         Cn, L = self.n_class, self.hid + 1
@@ -371,14 +379,14 @@ class MapStep:
         side_st = _V(self.side.cuda_stream)
         nws = [0]
 
-        def bwd(x2, n_in1, dy, params, shape, d_x2, d_p, ri, tg, n_slots, stride, acc):
+        def bwd(x2, n_in1, dy, params, shape, d_x2, d_p, ri, tg, n_slots, stride, acc, hs):
             n_in, n_out, nn, nl = shape
             ws = self.ws_mlp4[nws[0]] if fork_dwin else self.ws_mlp
             nws[0] += 1
             check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
                                   ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
                                   0 if d_x2 is None else d_x2.stride(0), ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg),
-                                  stride, None, acc | fp16 | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
+                                  stride, ptr(hs), acc | fp16 | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
             if fork_dwin:
                 # dW_in = dH_1^T x (memory-bound, needs only what this launch left in ws) on the side stream, beside the next
                 # network's vector-bound backward kernel
@@ -390,12 +398,12 @@ class MapStep:
                                            ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16, side_st), "dns_mlp_dwin")
 
         d_feat = self.d_featx[:, 4:]
-        bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, cur.g_coarse, None, None, P, 0, 0)
+        bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, cur.g_coarse, None, None, P, 0, 0, self.h_c)
         check(lib.dns_raw_bwd(ptr(self.d_raw), ptr(self.raw), P, ptr(self.d_col), d_fine_dst, ldf, 1, st), "dns_raw_bwd")
-        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, cur.g_color, None, None, P, 0, 3)
-        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, cur.g_logit, None, None, P, 0, 3)
+        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, cur.g_color, None, None, P, 0, 3, self.h_col)
+        bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, cur.g_logit, None, None, P, 0, 3, self.h_log)
         bwd(None, 0, self.d_featx[:, 3:3 + L], self.p_pool, self.shp_f, None, cur.g_pool, row_index, tile_group,
-            self.n_slots, self.p_pool.shape[-1], 1)
+            self.n_slots, self.p_pool.shape[-1], 1, self.h_f)
         work = None
         if self.world > 1:
             # colour | logit | pool gradients are complete once the LAST forked dW_in has run: with the fork the all-reduce is

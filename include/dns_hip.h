@@ -207,11 +207,13 @@ int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, ui
                 const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
-                float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: also write the hidden activations (inspection;
-                                 the backward does not need them) */,
+                float* h_save /* NULL, or [n_hidden_layers, n_slots, n_neurons]: also write the hidden activations (inspection, or
+                                 to hand them to dns_mlp_bwd as h_saved; the backward does not NEED them) */,
                 uint32_t flags /* 0 or DNS_MLP_FP16 */, void* stream);
 
-/* Backward.  Hidden activations are RECOMPUTED from x (h_saved is accepted and ignored).  One kernel produces d_x, dW_hidden
+/* Backward.  Hidden activations are RECOMPUTED from x, or -- with h_saved = what dns_mlp_fwd wrote to h_save for the same slots,
+ * fp32-grade mode with d_params only -- read back (bit-identical results; trades the recompute's vector work for 512 B of traffic
+ * per point each way).  One kernel produces d_x, dW_hidden
  * and dW_out and leaves dH_1 in ws; a second, streaming kernel forms dW_in = dH_1^T x.  d_x [rows, lddx] (columns
  * [0, n_in1)) and, with a two-segment input, d_x2 [rows, lddx2] (columns [n_in1, n_in)) are written for valid slots (d_x NULL
  * = skip both); d_params (+=) same layout as params (+ group*param_stride), NULL = skip (no weight-gradient work at all:

@@ -180,6 +180,27 @@ def test_map_step_single_frame_optimises_its_pose():
     assert float((out[1][1] - get_quad_from_c2w(frames["est_c2w"][0])).abs().max()) > 0          # and the pose did move
 
 
+def test_map_step_with_kept_hidden_activations_is_the_same_step():
+    """MapStep(keep_hidden=True): every network's forward keeps its hidden activations and the backward reads them back instead of
+    recomputing them -- the same losses (the kernels' results are bit-identical; float atomics give the usual last-bit noise)."""
+    from dns_slam_amd.fused_step import MapStep
+    out = []
+    for keep in (False, True):
+        cfg, bound, cam, frames, dec, mapper = _setup(64, 2)
+        mapper.static_shapes, mapper.is_BA, mapper.overlap_smooth, mapper.prefetch_draws = True, True, True, True
+        _, ql, Tl = mapper.set_optimizer(frames, fused=True)
+        torch.manual_seed(12)
+        torch.cuda.manual_seed(12)
+        ms = MapStep(mapper, frames, ql, Tl, keep_hidden=keep)
+        hist = []
+        for _ in range(5):
+            ms.step()
+            hist.append(float(ms.losses()[0]))
+        out.append(hist)
+    for a, b in zip(*out):
+        assert abs(a - b) <= 2e-5 * abs(a), out
+
+
 def test_optimize_frames_through_map_step():
     """``Mapper.optimize_frames`` with ``use_map_step``: the reference's driver (set_decoder, the lambda_lt schedule of
     slams/mapping.py:893-896, pose write-back :914-926) around the fixed launch sequence -- same result as the autograd loop."""
