@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class DnsGridMeta(C.Structure):
@@ -66,7 +66,7 @@ SIGNATURES = {
     "dns_feature_block": (C.c_int, [_P, _U, _U, _P, _U, _P, _P, _U, _U, _P, _U, _P, _P]),
     "dns_rgb_sigmoid": (C.c_int, [_P, _U, _P]),
     "dns_raw_bwd": (C.c_int, [_P, _P, _U, _P, _P, _U, _I, _P]),
-    "dns_lattice_points": (C.c_int, [_P, _P, _U, _P, _P]),
+    "dns_lattice_points": (C.c_int, [_P, _P, _U, _P, _P, _P]),
     "dns_draw_finish": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _U, _U, _P, _P, _P, _P]),
     "dns_track_mask": (C.c_int, [_P, _P, _U, C.c_float, _P, _P]),
     "dns_keep_best": (C.c_int, [_P, _P, _P, _P, _P, _P]),

@@ -76,18 +76,19 @@ __global__ __launch_bounds__(256) void raw_bwd_kernel(const float4* __restrict__
 // coordinates of the smoothness lattice (slams/mapping.py:133-143 folded to one affine map, Mapper.smoothness)
 struct LatticeConsts { double vox[3], off[3], mar[3]; };
 __global__ __launch_bounds__(256) void lattice_points_kernel(const float* __restrict__ r6, LatticeConsts c, uint32_t n,
-                                                             float* __restrict__ pts) {
+                                                             const int32_t* __restrict__ order, float* __restrict__ pts) {
   const uint32_t total = n * n * n;
   double b[3];
   for (int a = 0; a < 3; ++a) {
     const double t = c.mar[a] + (double)r6[a] * c.off[a];          // addcmul, then addcmul: two rounded steps each
     b[a] = t + (double)r6[3 + a] * c.vox[a];
   }
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < total; m += gridDim.x * blockDim.x) {
+    const uint32_t e = order ? (uint32_t)order[m] : m;             // output row m holds lattice element e (x-major index)
     const uint32_t k = e % n, j = (e / n) % n, i = e / (n * n);
-    pts[3u * e + 0u] = (float)(b[0] + (double)i * c.vox[0]);
-    pts[3u * e + 1u] = (float)(b[1] + (double)j * c.vox[1]);
-    pts[3u * e + 2u] = (float)(b[2] + (double)k * c.vox[2]);
+    pts[3u * m + 0u] = (float)(b[0] + (double)i * c.vox[0]);
+    pts[3u * m + 1u] = (float)(b[1] + (double)j * c.vox[1]);
+    pts[3u * m + 2u] = (float)(b[2] + (double)k * c.vox[2]);
   }
 }
 
@@ -212,14 +213,14 @@ extern "C" int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, flo
   return check_launch("dns_raw_bwd");
 }
 
-extern "C" int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, float* pts, void* stream) {
+extern "C" int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, const int32_t* order, float* pts, void* stream) {
   if (n == 0) return DNS_OK;
   DNS_REQUIRE(r6 && consts9 && pts, "dns_lattice_points: NULL argument");
   DNS_REQUIRE((uint64_t)n * n * n < (1ull << 30), "dns_lattice_points: lattice too large");
   LatticeConsts c;
   for (int a = 0; a < 3; ++a) { c.vox[a] = consts9[a]; c.off[a] = consts9[3 + a]; c.mar[a] = consts9[6 + a]; }
   hipStream_t st = (hipStream_t)stream;
-  DNS_LAUNCH(lattice_points_kernel, dim3(grid_for((uint64_t)n * n * n)), dim3(256), 0, st, r6, c, n, pts);
+  DNS_LAUNCH(lattice_points_kernel, dim3(grid_for((uint64_t)n * n * n)), dim3(256), 0, st, r6, c, n, order, pts);
   return check_launch("dns_lattice_points");
 }
 

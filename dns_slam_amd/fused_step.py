@@ -200,6 +200,26 @@ class MapStep:
             Pl = self.Pl = n ** 3
             self.bufl, self.occ, self.d_occ, self.d_bufl = f(Pl, ld), f(Pl, 1), f(Pl, 1), f(Pl, ld)
             self.pts_l = f(Pl, 3)
+            # Row m of the lattice branch's buffers holds lattice element lat_order[m], the elements in MORTON order of (i, j, k):
+            # neighbouring rows then share hash-table lines and the lattice's encoding kernel runs 2.3x faster (112 -> 49 us at
+            # 63^3; x-major rows walk the z axis and touch new lines of every fine level at every step).  The scatter does not
+            # care (249 -> 256 us).  lat_slot = the inverse map (row of element e).
+            ar = torch.arange(n, device=dev)
+            ii, jj, kk = torch.meshgrid(ar, ar, ar, indexing="ij")
+
+            def spread(v):                          # bits of v to every third position (10 bits)
+                v = v & 0x3ff
+                v = (v | (v << 16)) & 0x30000ff
+                v = (v | (v << 8)) & 0x300f00f
+                v = (v | (v << 4)) & 0x30c30c3
+                return (v | (v << 2)) & 0x9249249
+
+            code = spread(ii.reshape(-1)) | (spread(jj.reshape(-1)) << 1) | (spread(kk.reshape(-1)) << 2)
+            self.lat_order_l = torch.argsort(code).contiguous()                 # int64, for index_select
+            self.lat_order = self.lat_order_l.to(torch.int32).contiguous()
+            self.lat_slot = torch.empty_like(self.lat_order_l)
+            self.lat_slot[self.lat_order_l] = torch.arange(Pl, device=dev)
+            self.occ_x, self.d_occ_x = f(Pl, 1), f(Pl, 1)
             _, c_vox, c_off, c_mar = m._lattice_consts                    # float64 [3] each, on the device: read once
             self.lat_consts = (C.c_double * 9)(*[float(v) for t in (c_vox, c_off, c_mar) for v in t.cpu().tolist()])
             self.tv = f(1)
@@ -219,7 +239,8 @@ class MapStep:
         lib = ops.lib
         Pl, ld, pe = self.Pl, self.ld, self.pe_dim
         pts = self.pts_l
-        check(lib.dns_lattice_points(ptr(cur.draws["r6"]), self.lat_consts, self.n_lat, ptr(pts), st), "dns_lattice_points")
+        check(lib.dns_lattice_points(ptr(cur.draws["r6"]), self.lat_consts, self.n_lat, ptr(self.lat_order), ptr(pts), st),
+              "dns_lattice_points")
         meta = C.byref(self.meta.c)
         grid_l = _V(self.bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
@@ -227,9 +248,13 @@ class MapStep:
         n_in, _, nn, nl = self.shp_c
         check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
                               None, None, 0, ptr(self.h_l), self.fp16, st), "dns_mlp_fwd")
-        check(lib.dns_tv_fwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.tv), st), "dns_tv_fwd")
-        check(lib.dns_tv_bwd(ptr(self.occ), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ), st),
+        # the branch runs in MORTON order of the lattice elements (see __init__); the TV kernels want the x-major cube: two 1 MB
+        # permutations (the network's occupancy out, its gradient back in)
+        torch.index_select(self.occ, 0, self.lat_slot, out=self.occ_x)
+        check(lib.dns_tv_fwd(ptr(self.occ_x), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.tv), st), "dns_tv_fwd")
+        check(lib.dns_tv_bwd(ptr(self.occ_x), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ_x), st),
               "dns_tv_bwd")
+        torch.index_select(self.d_occ_x, 0, self.lat_order_l, out=self.d_occ)
         check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
                               ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, ptr(self.h_l),
                               self.fp16, st), "dns_mlp_bwd")
