@@ -58,3 +58,25 @@ ii, jj, kk = torch.meshgrid(idx, idx, idx, indexing="ij")
 code = part1by2(ii.reshape(-1)) | (part1by2(jj.reshape(-1)) << 1) | (part1by2(kk.reshape(-1)) << 2)
 xs = xl[torch.argsort(code)].contiguous()
 print(f"lattice, Morton order of the lattice indices: {timeit(xs, False):.1f} us")
+# rays sorted by (frame, 2-D Morton code of the pixel), points taken sample-major inside tiles of 64 neighbouring rays: an order
+# that needs only the drawn pixel indices (known a step ahead), not the sample positions
+P = ms.P
+N, S, K, npf = ms.N, ms.S, ms.K, ms.npf
+pix = ms.cur.draws["pix"].reshape(K, npf)
+W = mapper.W
+row, col = pix // W, pix % W
+def part1by1(v):
+    v = v & 0xffff
+    v = (v | (v << 8)) & 0x00ff00ff
+    v = (v | (v << 4)) & 0x0f0f0f0f
+    v = (v | (v << 2)) & 0x33333333
+    return (v | (v << 1)) & 0x55555555
+key = (torch.arange(K, device="cuda")[:, None] << 40) | (part1by1(row) << 1) | part1by1(col)
+rays = torch.argsort(key.reshape(-1))                         # [N] ray ids in sorted order
+for tile in (64, 32, 16):
+    r = rays.reshape(-1, tile)                                # [N / tile, tile]
+    perm = (r[:, None, :] * S + torch.arange(S, device="cuda")[None, :, None]).reshape(-1)     # tile t, sample s, lane l
+    xs = x[perm].contiguous()
+    print(f"rays by pixel Morton code, sample-major tiles of {tile} rays: {timeit(xs, True):.1f} us (with dy_dx), {timeit(xs, False):.1f} us")
+perm = (rays[:, None] * S + torch.arange(S, device="cuda")[None, :]).reshape(-1)
+print(f"rays by pixel Morton code, ray-major: {timeit(x[perm].contiguous(), True):.1f} us")
