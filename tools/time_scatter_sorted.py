@@ -38,3 +38,12 @@ def timeit(x, dbuf):
 for name, x, d in (("lattice", ms.pts_l.clone(), ms.d_bufl.clone()), ("rays", ms.x3.clone(), ms.d_buf.clone())):
     perm = morton(x)
     print(f"{name}: given order {timeit(x, d):.1f} us, Morton order {timeit(x[perm].contiguous(), d[perm].contiguous()):.1f} us (transpose + scatter)")
+x, d = ms.x3.clone(), ms.d_buf.clone()
+perm = torch.randperm(x.shape[0], device="cuda")
+print(f"rays: random order {timeit(x[perm].contiguous(), d[perm].contiguous()):.1f} us")
+S = ms.S
+perm = torch.arange(x.shape[0], device="cuda").reshape(-1, S).t().reshape(-1)          # sample-major: point (s, ray)
+print(f"rays: sample-major order {timeit(x[perm].contiguous(), d[perm].contiguous()):.1f} us")
+x, d = ms.pts_l.clone(), ms.d_bufl.clone()
+perm = torch.randperm(x.shape[0], device="cuda")
+print(f"lattice (rows as the step has them): {timeit(x, d):.1f} us; random order {timeit(x[perm].contiguous(), d[perm].contiguous()):.1f} us")
