@@ -97,6 +97,17 @@ def kernel_cost(entry, kernel, units, info, wl):
     if k == "mlp_dwin_kernel":
         m_in = mlp_macs(info)[0]
         return ("mfma", 2 * units * m_in, 2 * units * m_in * (3 if wl.get("mlp_dtype") == "fp16" else 6))
+    # the streaming kernels of the losses and of the iteration's glue (units = ray-samples of the launch)
+    if k == "loss_point_sums_kernel":
+        return ("hbm", units * 2 * 33 * 4)                                 # fine + coarse latents read
+    if k == "loss_point_bwd_kernel":
+        return ("hbm", units * 4 * 33 * 4)                                 # ... read again, their gradients written
+    if k == "feature_block_kernel":
+        return ("hbm", units * (33 * 4 + (32 * 4 if wl.get("code_seed") is not None else 0) + 64 * 4))
+    if k == "raw_bwd_kernel":
+        return ("hbm", units * (3 * 16 + 8))
+    if k == "rgb_sigmoid_kernel":
+        return ("hbm", units * 2 * 16)
     return None
 
 

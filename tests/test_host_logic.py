@@ -218,3 +218,14 @@ def test_checkpoint_loads_pickled_tinycudann_module_objects(tmp_path):
     assert sorted(pool.keys()) == [5, 11]
     for c in (5, 11):
         assert torch.equal(pool.params_of(c)[:used], fine[c][:used]) and torch.count_nonzero(pool.params_of(c)[used:]) == 0
+
+
+def test_fixed_launch_sequences_refuse_to_run_without_a_gpu():
+    """MapStep / TrackStep (dns_slam_amd/fused_step.py) are product paths: no CPU fallback, a loud error instead."""
+    import pytest
+    from types import SimpleNamespace
+    from dns_slam_amd.fused_step import MapStep, TrackStep
+    with pytest.raises(ValueError, match="GPU only"):
+        MapStep(SimpleNamespace(device="cpu"), {})
+    with pytest.raises(ValueError, match="GPU only"):
+        TrackStep(SimpleNamespace(device="cpu"), {}, None)
