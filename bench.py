@@ -289,6 +289,7 @@ def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
         code = torch.rand(4 * npf, wl["nu"] + wl["ns"], 32, generator=torch.Generator().manual_seed(wl["code_seed"])) * 2 - 1
     times = []
     t_start = time.perf_counter()
+    warm = True                                  # one untimed warm-up iteration (allocator, thread pool), then timed ones
     while True:
         t0 = time.perf_counter()
         om.zero_grad()
@@ -302,15 +303,22 @@ def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
         so = sr.mapper_target_samples(fr)
         loss, _, _ = sr.mapping_loss(om, so, lc, torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g))
         loss.backward()
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 8:
+        dt = time.perf_counter() - t0
+        if warm:
+            warm = False
+            if time.perf_counter() - t_start + 2 * dt <= budget_s:
+                continue                         # (a host too slow for two iterations inside the budget keeps its only one)
+        times.append(dt)
+        if time.perf_counter() - t_start + dt > budget_s or len(times) >= 20:
             break
-    best = min(times)
+    ts = sorted(times)
+    med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
     n_samples = 4 * npf * (wl["nu"] + wl["ns"])
-    return {"value": n_samples / best, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} full mapping iteration(s) of the same workload (4096 rays x 64 samples + 63^3 "
-                      f"smoothness lattice, fwd+bwd, no optimiser step), best of {len(times)}: {best * 1e3:.0f} ms/iter, "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+    return {"value": n_samples / med, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"full mapping iterations of the same workload ({4 * npf} rays x {wl['nu'] + wl['ns']} samples + "
+                      f"{wl['smooth_pts'] - 1}^3 smoothness lattice, fwd+bwd, no optimiser step): 1 warm-up + {len(times)} timed, "
+                      f"MEDIAN {med * 1e3:.0f} ms/iter (min {ts[0] * 1e3:.0f}); bounded to ~{budget_s:.0f} s of CPU work, so fewer "
+                      f"than SURVEY 8d's 5 warm-up + 20 timed iterations; torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
 def main():
@@ -529,8 +537,9 @@ def main():
         "launch_trial_ms": trial, "final_loss": final_loss,
         "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,
                    "global_rays": job_rays,
-                   "parallelism": f"dp{ctx.world_size} (" + ("union batch: rank slices of one shared-seed batch and of the lattice"
-                                                              if union else "one batch per rank") + ")"},
+                   "parallelism": f"dp{ctx.world_size} (" + ("strong: union batch -- rank slices of ONE shared-seed batch of "
+                                                              f"{n_rays} rays and of the lattice" if union else
+                                                              f"weak: {n_rays} rays per rank, one batch and one lattice per rank") + ")"},
         "roofline": roofline,
         "iteration_roofline": iteration_roofline,
         "kernel_rooflines": per_kernel,

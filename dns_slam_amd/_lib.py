@@ -128,6 +128,14 @@ def check(rc: int, what: str = "") -> None:
     msg = lib.dns_last_error().decode("utf-8", "replace")
     if rc == -1:
         raise ValueError(f"{what}: {msg}")
+    if rc == -2:
+        # DNS_E_LAUNCH can be the STICKY device error word (include/dns_hip.h: set by a kernel that had to clamp a device
+        # counter, reported by whichever entry point polls next).  Read and clear it here, so that ONE fault raises ONE
+        # exception -- naming the word -- instead of failing every later call on the device.
+        word = lib.dns_device_error(1)
+        if word:
+            raise RuntimeError(f"{what}: {msg} (code {rc}; device error word {word:#x} was set by an EARLIER kernel -- bit 0: "
+                               f"dns_group_slots / dns_group_scatter cursor past n_slots -- and has been cleared)")
     raise RuntimeError(f"{what}: {msg} (code {rc})")
 
 

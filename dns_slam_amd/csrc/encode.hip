@@ -12,7 +12,6 @@
 // (__fmul_rn/__fadd_rn, never contracted), the cell is (uint32)(int)floorf(pos); hash primes
 // {1, 2654435761, 805459861}; index % level size.  Those make the table rows bit-exact.
 #include <type_traits>
-#include <stdlib.h>
 #include "common.hpp"
 
 namespace dns {

@@ -79,9 +79,13 @@ class GradBuckets:
         ``finish()``, after ``backward()`` has returned -- the engine has then joined every leaf stream with the caller's.
         Default: every bucket hook-launched (single-stream callers)."""
         self.ctx = ctx
-        self._hook_launch = None if hook_launch is None else [bool(h) for h in hook_launch]
-        self.groups = [[p for p in g if p.requires_grad and p.numel() > 0] for g in groups]
-        self.groups = [g for g in self.groups if g]
+        groups = [[p for p in g if p.requires_grad and p.numel() > 0] for g in groups]
+        if hook_launch is not None and len(hook_launch) != len(groups):
+            raise ValueError("GradBuckets: hook_launch needs one flag per group")
+        flags = [True] * len(groups) if hook_launch is None else [bool(h) for h in hook_launch]
+        kept = [(g, h) for g, h in zip(groups, flags) if g]             # a group can end up empty (all frozen): drop its FLAG with it
+        self.groups = [g for g, _ in kept]
+        self._hook_launch = None if hook_launch is None else [h for _, h in kept]
         self.flat, self._pending, self._works, self._next = [], [], [], 0
         self._hooks = []
         for k, g in enumerate(self.groups):
@@ -132,10 +136,13 @@ class GradBuckets:
 
 
 class DistCtx:
-    def __init__(self, world_size: int = 1, rank: int = 0, group=None, mode: str = "weak"):
+    def __init__(self, world_size: int = 1, rank: int = 0, group=None, mode: str = "weak", force: bool = False):
+        """``force``: issue every collective even with world_size == 1 (a one-rank process group: the collectives are
+        identities, but they run through the backend -- tests/test_dist.py drives RCCL's stream ordering on one GPU that way)."""
         if mode not in ("weak", "union"):
             raise ValueError(f"DistCtx mode '{mode}' (weak | union)")
         self.world_size, self.rank, self.group, self.mode = world_size, rank, group, mode
+        self.force = bool(force)
         self._flat_cache = {}
 
     @property
@@ -150,7 +157,7 @@ class DistCtx:
 
     @property
     def enabled(self):
-        return self.world_size > 1
+        return self.world_size > 1 or self.force
 
     # ---- loss fix-ups -----------------------------------------------------------------------
     def global_mean_scale(self, local_count: torch.Tensor) -> torch.Tensor:
@@ -223,11 +230,20 @@ class DistCtx:
         return float(t.item())
 
 
-def init_from_env(backend: Optional[str] = None, mode: str = "weak") -> DistCtx:
-    """One process per GPU, launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+def init_from_env(backend: Optional[str] = None, mode: str = "weak", force: bool = False) -> DistCtx:
+    """One process per GPU, launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    ``force``: with WORLD_SIZE 1 still create the (one-rank) process group and return a context that issues every collective
+    through it (``DistCtx.force``) -- RCCL's initialisation and stream semantics exercised on a single GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not force:
         return DistCtx(mode=mode)
+    if world <= 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=0, world_size=1)
+        return DistCtx(1, 0, mode=mode, force=True)
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:

@@ -57,7 +57,8 @@ class MapStep:
             raise ValueError("MapStep: union-batch mode runs through the autograd path")
         if features is not None and features.dim() != 3:
             raise ValueError("MapStep takes the per-sample code [N, S, C] (stem feature maps run through the autograd path)")
-        self.world = m.dist.world_size if (m.dist is not None and m.dist.enabled) else 1
+        self.dist_on = m.dist is not None and m.dist.enabled       # (a forced one-rank group counts: tests drive RCCL that way)
+        self.world = m.dist.world_size if self.dist_on else 1
         self.frames = target_frames
         self.prep = prep if prep is not None else m.prepare_frames(target_frames)
         self.features = None if features is None else features.to(dev).float().contiguous()
@@ -290,7 +291,7 @@ class MapStep:
             dmax = torch.gather(prep["depth"].reshape(K, -1), 1, pix2).amax(dim=1).clamp_min(0.0).float().contiguous().view(torch.int32)
             labels = torch.gather(prep["label"].reshape(K, -1), 1, pix2).reshape(-1).long()      # = the gt_label raygen writes
         st_.draws = d
-        if self.world > 1:
+        if self.dist_on:
             fmax = dmax.view(torch.float32)
             m.dist.allreduce_max(fmax)                  # in place on the same storage
         st_.dmax = dmax                                 # bit patterns, as dns_raygen_sample takes them
@@ -302,10 +303,15 @@ class MapStep:
         st_.zb.zero_()            # the fine network's output (points without a network keep zeros, :592) | the gradient buffer
 
     @torch.no_grad()
-    def step(self, draws=None):
+    def step(self, draws=None, last=False):
         """One iteration; returns nothing (``losses()`` reads the terms of the last step).  ``draws``: {'pix': [K * n_per_frame]
-        int64 pixel indices, 'jitter': (t_surf, t_zero), 'r6': [6] lattice offset | jitter} instead of the generator's (tests)."""
+        int64 pixel indices, 'jitter': (t_surf, t_zero), 'r6': [6] lattice offset | jitter} instead of the generator's (tests).
+        ``last``: no further step follows -- the NEXT step's set is not prepared (with ``mapper.prefetch_draws`` every step
+        otherwise consumes the generator's draws of its successor: after the final step of an optimize() the generator would
+        stand one iteration further than the autograd driver leaves it)."""
         m, lib = self.m, ops.lib
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True                      # the loss weights are launch ARGUMENTS: a replay keeps them (set_lambda_lt)
         main = torch.cuda.current_stream()
         st = _V(main.cuda_stream)
         K, npf, N, S, P, ld, pe = self.K, self.npf, self.N, self.S, self.P, self.ld, self.pe_dim
@@ -331,7 +337,7 @@ class MapStep:
                 self._lattice_branch(cur, _V(self.side.cuda_stream))
         elif self.smooth:
             self._lattice_branch(cur, st)
-        if prefetch:                                   # the next step's set, behind the lattice branch on the side stream
+        if prefetch and not last:                      # the next step's set, behind the lattice branch on the side stream
             nxt = self.sets[(self.steps + 1) % 2]
             with torch.cuda.stream(self.side):
                 self._prepare(nxt, _V(self.side.cuda_stream), None)
@@ -379,7 +385,7 @@ class MapStep:
         check(lib.dns_loss_sums(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
                                 ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(fine), ptr(self.coarse),
                                 ptr(self.z), ptr(self.sums_ws), st), "dns_loss_sums")
-        if self.world > 1:
+        if self.dist_on:
             m.dist.allreduce_sums(self.sums_ws[:16])
         check(lib.dns_loss_finalize(lam, N, S, Cn, L, 0, ptr(self.sums_ws), ptr(self.out), st), "dns_loss_finalize")
 
@@ -430,7 +436,7 @@ class MapStep:
         bwd(None, 0, self.d_featx[:, 3:3 + L], self.p_pool, self.shp_f, None, cur.g_pool, row_index, tile_group,
             self.n_slots, self.p_pool.shape[-1], 1, self.h_f)
         work = None
-        if self.world > 1:
+        if self.dist_on:
             # colour | logit | pool gradients are complete once the LAST forked dW_in has run: with the fork the all-reduce is
             # issued from the side stream (behind that kernel, which itself waited for the fine network's backward kernel)
             import torch.distributed as dist
@@ -459,7 +465,7 @@ class MapStep:
                                      None, ptr(self.ray_ws), ptr(cur.g_quat), ptr(cur.g_trans), st), "dns_raygen_bwd")
         if on_side:
             main.wait_stream(self.side)
-        if self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             work2 = dist.all_reduce(cur.G_late, op=dist.ReduceOp.SUM, group=m.dist.group, async_op=True)
             work.wait()
@@ -472,6 +478,9 @@ class MapStep:
     def set_lambda_lt(self, value):
         """Weight of the latent loss for the following steps (slams/mapping.py:893-896: 0 in the first half of an optimize()
         that added decoders)."""
+        if getattr(self, "_captured", False) and float(value) != float(self.lam[3]):
+            raise RuntimeError("MapStep.set_lambda_lt: the step has been captured into a hipGraph -- the loss weights are kernel "
+                               "arguments frozen at capture time; capture one graph per weight schedule phase")
         self.lam[3] = float(value)
 
     # the last step's gradient segments (tests, inspection)

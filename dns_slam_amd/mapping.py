@@ -935,7 +935,7 @@ class Mapper:
             ms = MapStep(self, target_frames, quad_list, T_list, prep=prep, features=features, smooth=smooth)
             for iter_ in range(n_iters):
                 ms.set_lambda_lt(lt_of(iter_))
-                ms.step()
+                ms.step(last=iter_ == n_iters - 1)
             ms.write_back()
             if n_iters > 0:
                 _, terms = ms.losses()

@@ -384,3 +384,72 @@ def test_union_mode_rank_slice_is_a_slice_of_the_whole_batch():
             assert torch.equal(part[key], whole[key][rows]), (W, r, key)
         assert torch.equal(part["point_labels"], tiled[rows].reshape(-1)), (W, r)
     mapper.dist = None
+
+
+def _nccl_one_rank_worker(port, q):
+    """One process, ONE-rank RCCL group (backend "nccl"), ``DistCtx.force``: every distributed branch of ``MapStep.step`` runs
+    -- the MAX of the depth maxima issued from the SIDE stream a step ahead, the 16-float SUM between dns_loss_sums and
+    dns_loss_finalize on the main stream, the early gradient bucket all-reduced asynchronously from the side stream behind the
+    last forked dW_in, the late bucket after the stream join, ``work.wait()`` on both before Adam.  A one-rank all-reduce is the
+    identity, so the result must equal the non-distributed step: what this exercises is RCCL's initialisation and the ordering
+    of its kernels against both of MapStep's streams (gloo synchronises on the host and cannot show that)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import rel_err
+    from dns_slam_amd import dist as dd
+    from dns_slam_amd.fused_step import MapStep
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["WORLD_SIZE"], os.environ["RANK"], os.environ["LOCAL_RANK"] = "1", "0", "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    ctx = dd.init_from_env(backend="nccl", force=True)
+    assert ctx.enabled and ctx.world_size == 1 and dist.get_backend() == "nccl"
+    out = {}
+    for name, c in (("plain", None), ("nccl", ctx)):
+        frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "per_ray")
+        mapper.dist = c
+        mapper.overlap_smooth, mapper.prefetch_draws = True, False
+        ms = MapStep(mapper, frames, ql, Tl, prep=prep)
+        assert ms.dist_on == (c is not None)
+        r6 = torch.cat((u[0].reshape(-1), u[1].reshape(-1))).to("cuda:0")
+        ms.step(draws={"pix": pix, "jitter": jit, "r6": r6})
+        torch.cuda.synchronize()
+        first = _map_step_grads(ms) + [ms.out.cpu().clone()]
+        mapper.prefetch_draws = True                       # free-running: the next step's set (and its MAX) on the side stream
+        torch.manual_seed(321)
+        torch.cuda.manual_seed(321)
+        losses = []
+        for i in range(4):
+            ms.step(last=i == 3)
+            losses.append(ms.out[:7].clone())
+        torch.cuda.synchronize()
+        params = [p.detach().cpu().clone() for p in (ms.p_table, ms.p_coarse, ms.p_color, ms.p_logit, ms.p_pool, ms.Q, ms.T)]
+        out[name] = (first, torch.stack(losses).cpu(), params, float(mapper.lr), float(mapper.BA_cam_lr))
+    a, b = out["plain"], out["nccl"]
+    res = {"grad_err": max(rel_err(x, y) for x, y in zip(b[0], a[0])),
+           "loss_err": float(((b[1] - a[1]).abs() / a[1].abs().clamp_min(1e-12)).max()),
+           "finite": bool(torch.isfinite(b[1]).all())}
+    # parameters after 5 Adam steps: the table scatter's float atomics make two runs of the SAME program differ in the last
+    # bits, and Adam turns a last-bit gradient difference of a near-zero component into a fraction of lr: bound as in
+    # test_gpu_fused_step (1e-4 of the tensor's scale + 5 % of what 5 steps can move)
+    perr = []
+    for k, (x, y) in enumerate(zip(b[2], a[2])):
+        lr = a[4] if k >= 5 else a[3]
+        perr.append(float((x - y).abs().max()) / (1e-4 * float(y.abs().max()) + 0.05 * lr * 5))
+    res["param_err_over_bound"] = max(perr)
+    q.put(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_map_step_collectives_under_rccl_one_rank_group():
+    port = _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=_nccl_one_rank_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res["finite"] and res["grad_err"] < 1e-6 and res["loss_err"] < 1e-6, res
+    assert res["param_err_over_bound"] <= 1.0, res

@@ -399,3 +399,53 @@ def test_draw_finish_equals_the_mapper_draw_arithmetic():
     p2 = want_pix.reshape(K, npf)
     assert torch.equal(labels, torch.gather(prep["label"].reshape(K, -1), 1, p2).reshape(-1).long())
     assert torch.equal(dmax.view(torch.float32), torch.gather(prep["depth"].reshape(K, -1), 1, p2).amax(dim=1).clamp_min(0.0))
+
+
+def test_draw_finish_equals_the_oracle_class_balanced_pick():
+    """a2 on the GPU against the ORACLE: dns_draw_finish's class-balanced half == oracle.render_math.class_balanced_indices
+    (pinned to the imported reference's select_by_class by tests/golden/get_samples_by_class.npz, utils/common.py:307-338)
+    when the oracle's per-class ``draw(k, m)`` takes its integers from the same uniforms u the kernel is given
+    (floor(u k), clamped to k - 1): same classes in ascending order, same remainder rule for the first class (:318-321), same
+    ascending pixel list per class, a one-pixel class repeated (:324-325).  The uniform half is select_uv's plain randint (:274)."""
+    lib, check, ptr, stream_ptr = _lib()
+    from oracle import render_math as rm
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    # a class with exactly ONE pixel in frame 1 (the k == 1 branch) -- written before the class tables are built
+    frames["gt_label"][1] = frames["gt_label"][1].clone()
+    frames["gt_label"][1][3, 5] = 37.0
+    prep = mapper.prepare_frames(frames)
+    K, n1, n2, HW = 4, prep["n1"], prep["n2"], prep["HW"]
+    npf = n1 + n2
+    torch.manual_seed(77)
+    i1 = torch.randint(HW, (K, n1), device=DEV)
+    u = torch.rand(K, n2, device=DEV, dtype=torch.float64)
+    pix = torch.empty(K * npf, device=DEV, dtype=torch.int64)
+    labels = torch.empty(K * npf, device=DEV, dtype=torch.int64)
+    dmax = torch.empty(K, device=DEV, dtype=torch.int32)
+    check(lib.dns_draw_finish(ptr(i1), ptr(u), ptr(prep["counts_f64"]), ptr(prep["counts_m1"]), ptr(prep["starts_flat"]),
+                              ptr(prep["sorted_flat"]), ptr(prep["depth"]), ptr(prep["label"]), K, n1, n2, HW, ptr(pix), ptr(labels),
+                              ptr(dmax), stream_ptr()), "dns_draw_finish")
+    got = pix.reshape(K, npf).cpu()
+    u_h = u.cpu()
+    saw_single = False
+    for f in range(K):
+        lab = frames["gt_label"][f].cpu().float()
+        counts = torch.unique(lab.reshape(-1), return_counts=True)[1]
+        n_class = counts.numel()
+        n_k = n2 // n_class
+        m_of = [n2 - n_k * (n_class - 1) if c == 0 else n_k for c in range(n_class)]
+        first = [sum(m_of[:c]) for c in range(n_class)]          # the kernel's uniforms are laid out class after class
+        # the oracle (like the reference) draws nothing for a one-pixel class: its draw() calls are the other classes, ascending
+        calls = iter([c for c in range(n_class) if int(counts[c]) != 1])
+        saw_single = saw_single or any(int(counts[c]) == 1 for c in range(n_class))
+
+        def draw(k, m):
+            c = next(calls)
+            assert m == m_of[c] and k == int(counts[c])
+            uu = u_h[f, first[c]:first[c] + m]
+            return torch.minimum((uu * float(k)).to(torch.int64), torch.tensor(k - 1))
+
+        want = rm.class_balanced_indices(lab, n2, draw=draw)
+        assert torch.equal(got[f, n1:], want), f
+        assert torch.equal(got[f, :n1], i1[f].cpu())
+    assert saw_single
