@@ -70,7 +70,7 @@ def kernel_cost(entry, kernel, units, info, wl):
     16-bit MFMA flops actually issued for them).  units = points / slots / rays of the launch."""
     S = wl["nu"] + wl["ns"]
     k = kernel.split("<")[0]
-    if k == "encode_fwd_kernel":
+    if k in ("encode_fwd_kernel", "encode_fwd_split_kernel"):
         return ("hbm", units * (16 * 8 * 2 * 4 + 12))                     # 128 table cells of 8 B gathered + the point
     if k == "encode_bwd_kernel":
         return ("hbm", units * (16 * 3 * 8 + 80 * 4 + 12 + 12))            # the forward's dy_dx + the gradient row + x in, d_x out
@@ -102,7 +102,7 @@ def kernel_cost(entry, kernel, units, info, wl):
         return ("hbm", units * 2 * 33 * 4)                                 # fine + coarse latents read
     if k == "loss_point_bwd_kernel":
         return ("hbm", units * 4 * 33 * 4)                                 # ... read again, their gradients written
-    if k == "feature_block_kernel":
+    if k in ("feature_block_kernel", "feature_block_split_kernel"):
         return ("hbm", units * (33 * 4 + (32 * 4 if wl.get("code_seed") is not None else 0) + 64 * 4))
     if k == "raw_bwd_kernel":
         return ("hbm", units * (3 * 16 + 8))

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class DnsGridMeta(C.Structure):
@@ -22,6 +22,10 @@ class DnsGridMeta(C.Structure):
         ("size", C.c_uint32 * DNS_MAX_LEVELS), ("offset", C.c_uint32 * DNS_MAX_LEVELS),
         ("hashed", C.c_uint32 * DNS_MAX_LEVELS),
     ]
+
+
+class DnsSplitRows(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("exps", C.c_void_p), ("ld", C.c_uint32), ("lo_off", C.c_uint32)]
 
 
 class DnsAdamTensor(C.Structure):
@@ -58,6 +62,12 @@ SIGNATURES = {
     "dns_mlp_dwin": (C.c_int, [_P, _U, _P, _U, _U, _U, _U, _U, _P, _P, _U, _P, _P, _U, _U, _P]),
     "dns_mlp_prepared_floats": (C.c_uint64, [_U, _U, _U, _U]),
     "dns_mlp_prepare": (C.c_int, [_P, _U, _U, _U, _U, _U, _U, _P, _P]),
+    "dns_encode_fwd_split": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _P, _U, _P, _U, _P, _U, _P, _P]),
+    "dns_mlp_fwd_split": (C.c_int, [C.POINTER(DnsSplitRows), C.POINTER(DnsSplitRows), _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U,
+                                    _U, _P]),
+    "dns_mlp_bwd_split": (C.c_int, [C.POINTER(DnsSplitRows), C.POINTER(DnsSplitRows), _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U,
+                                    _P, _P, _U, _P, _P, _U, _I, _P]),
+    "dns_feature_block_split": (C.c_int, [_P, _U, _U, _P, _U, _U, _U, _P, _P, _U, _U, _P, _U, _P, _U, _P, _U, _P, _P]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,

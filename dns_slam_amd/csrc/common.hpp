@@ -92,17 +92,19 @@ inline GridLevels to_levels(const DnsGridMeta* m) {
   return g;
 }
 
+namespace sp { struct XsIn; }                // split-row input of the MLP kernels (mlp_split.hpp); NULL = fp32 rows
 // split-operand MLP kernels (mlp_split.hip); arguments validated by the C-ABI wrappers in mlp.hip
 int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* params,
                          uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
                          uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
-                         float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, hipStream_t st);
+                         float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, const sp::XsIn* xs,
+                         hipStream_t st);
 int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
                          uint32_t lddy, const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
-                         bool with_dwin, const float* h_saved, hipStream_t st);
+                         bool with_dwin, const float* h_saved, const sp::XsIn* xs, hipStream_t st);
 int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                     uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
                     const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st);

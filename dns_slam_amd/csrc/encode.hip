@@ -13,6 +13,7 @@
 // {1, 2654435761, 805459861}; index % level size.  Those make the table rows bit-exact.
 #include <type_traits>
 #include "common.hpp"
+#include "split_rows.hpp"
 
 namespace dns {
 
@@ -241,6 +242,166 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
     if (TILED) flush(grid_out, ld_grid, g_dim);
   }
 }
+// The same encoding written in the SPLIT-ROW format of split_rows.hpp (and, optionally, as fp32 rows as well): what the MLP
+// kernels of fused_step.MapStep / TrackStep read.  One lane = one point, outputs through the same two-phase LDS tile as
+// encode_fwd_kernel<true> (max(pe_dim, g_dim) + 1 floats per point: LDS, not registers, limits the occupancy of this gather
+// kernel).  The row's exponent needs max |row| over BOTH halves before the first value is converted:
+//   A  OneBlob -> tile (fp32), its maximum; flushed as fp32 columns [0, pe_dim) when f32_out is wanted
+//   B  grid gather -> tile (fp32), its maximum -> e = scale_exp(max) (bit for bit what mlp_split.hpp's x_row_max / scale_exp
+//      derived from the fp32 row); fp32 flush; then the 2 L values as hi | lo pairs, flushed into the row's two planes
+//   C  OneBlob evaluated a second time (the OneBlob half of this kernel is free: measured 99.7 vs 96.0 us with / without it),
+//      converted with e and flushed.
+// xs_out [P][ldxs] halfs: columns [0, K) hi, [K, 2K) lo (K = pe_dim + g_dim); hi_only: the lo plane is not written.
+__global__ __launch_bounds__(128) void encode_fwd_split_kernel(const float* __restrict__ in, Bound6 bd, int normalise, uint32_t P,
+                                                               uint32_t n_bins, const float2* __restrict__ table, GridLevels lv,
+                                                               float* __restrict__ x_out, float* __restrict__ f32_out, uint32_t ld32,
+                                                               uint32_t* __restrict__ xs_out, uint32_t ldxs_w, int32_t* __restrict__ xexp,
+                                                               int hi_only, float2* __restrict__ dydx) {
+  extern __shared__ float tile[];
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels, K = pe_dim + g_dim;
+  const uint32_t ldt = max(pe_dim, g_dim) + 1;
+  const bool live = p < P;
+  float x[3] = {0.f, 0.f, 0.f};
+  if (live) load_point(in, bd, normalise != 0, p, x);
+  if (live && x_out) {
+    x_out[(size_t)p * 3 + 0] = x[0];
+    x_out[(size_t)p * 3 + 1] = x[1];
+    x_out[(size_t)p * 3 + 2] = x[2];
+  }
+  float* trow = tile + threadIdx.x * ldt;
+  // tile columns [tc0, tc0 + nc) of the workgroup's rows -> columns [c0, c0 + nc) of the row-major `out` (32-bit words, leading
+  // dimension ld); nc, c0, ld multiples of 4 and out 16-byte aligned (checked on the host): 16-byte global stores
+  auto flush = [&](uint32_t* out_base, uint32_t ld, uint32_t c0, uint32_t nc, uint32_t tc0) {
+    __syncthreads();
+    const uint32_t p0 = blockIdx.x * blockDim.x;
+    const uint32_t rows = min(blockDim.x, P - p0);
+    uint32_t* out = out_base + (size_t)p0 * ld + c0;
+    const uint32_t nq = nc >> 2, dr = blockDim.x / nq, dc = blockDim.x - dr * nq;
+    uint32_t r = threadIdx.x / nq, c = threadIdx.x - r * nq;
+    for (uint32_t i = threadIdx.x; i < rows * nq; i += blockDim.x) {
+      const uint32_t* t = reinterpret_cast<const uint32_t*>(tile) + r * ldt + tc0 + 4 * c;
+      *reinterpret_cast<uint4*>(out + (size_t)r * ld + 4 * c) = make_uint4(t[0], t[1], t[2], t[3]);
+      r += dr;
+      c += dc;
+      if (c >= nq) { c -= nq; ++r; }
+    }
+    __syncthreads();
+  };
+  auto oneblob_row = [&]() -> float {                     // the lane's pe_dim OneBlob values -> its tile row; their maximum
+    const float n = (float)n_bins;
+    float m = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float xa = x[a];
+      if (n_bins >= 8u && fabsf(xa) < 4.0f) {
+        for (uint32_t b = 0; b < n_bins; ++b) trow[a * n_bins + b] = 0.f;
+        oneblob_windows<false>(n_bins, n, xa, [&](uint32_t j, float v) { trow[a * n_bins + j] = v; m = fmaxf(m, fabsf(v)); });
+        continue;
+      }
+      float first = 0.f, left = 0.f;
+      for (uint32_t b = 0; b <= n_bins; ++b) {
+        float g;
+        if (b < n_bins) {
+          const float d = (float)b / n - xa;
+          g = quartic_cdf(d, n) + quartic_cdf(d - 1.0f, n) + quartic_cdf(d + 1.0f, n);
+          if (b == 0) first = g;
+        } else {
+          g = first + 1.0f;
+        }
+        if (b > 0) { trow[a * n_bins + b - 1] = g - left; m = fmaxf(m, fabsf(g - left)); }
+        left = g;
+      }
+    }
+    return m;
+  };
+  // ---- A
+  float rmax = 0.f;
+  bool bad = false;                                       // fmaxf drops a NaN: a non-finite value must reach the exponent rule
+  if (live) {
+    rmax = oneblob_row();
+    for (uint32_t c = 0; c < pe_dim; ++c) bad = bad || !(fabsf(trow[c]) < INFINITY);
+  }
+  if (f32_out) flush(reinterpret_cast<uint32_t*>(f32_out), ld32, 0, pe_dim, 0);
+  else __syncthreads();
+  // ---- B
+  if (live) {
+#pragma unroll 4
+    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+      const float s = lv.scale[l];
+      const uint32_t res = lv.resolution[l], size = lv.size[l], hashed = lv.hashed[l];
+      const float2* __restrict__ t = table + lv.offset[l];
+      float f[3];
+      uint32_t g[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float pos = __fadd_rn(__fmul_rn(x[a], s), 0.5f);
+        const float fl = floorf(pos);
+        g[a] = (uint32_t)(int)fl;
+        f[a] = pos - fl;
+      }
+      float2 v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        v[c] = t[grid_row(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, size, hashed)];
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float w = ((c & 1) ? f[0] : 1.0f - f[0]) * ((c & 2) ? f[1] : 1.0f - f[1]) * ((c & 4) ? f[2] : 1.0f - f[2]);
+        a0 += w * v[c].x;
+        a1 += w * v[c].y;
+      }
+      trow[2 * l] = a0;
+      trow[2 * l + 1] = a1;
+      rmax = fmaxf(rmax, fmaxf(fabsf(a0), fabsf(a1)));
+      bad = bad || !(fabsf(a0) < INFINITY) || !(fabsf(a1) < INFINITY);
+      if (dydx) {
+        const float wx0 = 1.0f - f[0], wx1 = f[0], wy0 = 1.0f - f[1], wy1 = f[1], wz0 = 1.0f - f[2], wz1 = f[2];
+        float2 jx, jy, jz;
+        jx.x = s * (wy0 * wz0 * (v[1].x - v[0].x) + wy1 * wz0 * (v[3].x - v[2].x) + wy0 * wz1 * (v[5].x - v[4].x) + wy1 * wz1 * (v[7].x - v[6].x));
+        jx.y = s * (wy0 * wz0 * (v[1].y - v[0].y) + wy1 * wz0 * (v[3].y - v[2].y) + wy0 * wz1 * (v[5].y - v[4].y) + wy1 * wz1 * (v[7].y - v[6].y));
+        jy.x = s * (wx0 * wz0 * (v[2].x - v[0].x) + wx1 * wz0 * (v[3].x - v[1].x) + wx0 * wz1 * (v[6].x - v[4].x) + wx1 * wz1 * (v[7].x - v[5].x));
+        jy.y = s * (wx0 * wz0 * (v[2].y - v[0].y) + wx1 * wz0 * (v[3].y - v[1].y) + wx0 * wz1 * (v[6].y - v[4].y) + wx1 * wz1 * (v[7].y - v[5].y));
+        jz.x = s * (wx0 * wy0 * (v[4].x - v[0].x) + wx1 * wy0 * (v[5].x - v[1].x) + wx0 * wy1 * (v[6].x - v[2].x) + wx1 * wy1 * (v[7].x - v[3].x));
+        jz.y = s * (wx0 * wy0 * (v[4].y - v[0].y) + wx1 * wy0 * (v[5].y - v[1].y) + wx0 * wy1 * (v[6].y - v[2].y) + wx1 * wy1 * (v[7].y - v[3].y));
+        dydx[((size_t)l * 3 + 0) * P + p] = jx;
+        dydx[((size_t)l * 3 + 1) * P + p] = jy;
+        dydx[((size_t)l * 3 + 2) * P + p] = jz;
+      }
+    }
+  }
+  const int e = sr::scale_exp(bad ? INFINITY : rmax);
+  const float sc = ldexpf(1.0f, e);
+  if (live) xexp[p] = e;
+  if (f32_out) flush(reinterpret_cast<uint32_t*>(f32_out), ld32, pe_dim, g_dim, 0);
+  // the lane's own row back out of the tile, as packed pairs: hi pairs at tile columns [0, n/2), lo pairs at [n/2, n)
+  auto repack = [&](uint32_t n) {
+    uint32_t* urow = reinterpret_cast<uint32_t*>(trow);
+    uint32_t hi[32], lo[32];                               // n <= 64 values (host-checked)
+#pragma unroll
+    for (uint32_t i = 0; i < 32; ++i) {
+      if (2 * i < n) sr::split_pair(trow[2 * i], trow[2 * i + 1], sc, hi[i], lo[i]);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 32; ++i) {
+      if (2 * i < n) {
+        urow[i] = hi[i];
+        urow[n / 2 + i] = lo[i];
+      }
+    }
+  };
+  if (live) repack(g_dim);
+  flush(xs_out, ldxs_w, pe_dim / 2, g_dim / 2, 0);
+  if (!hi_only) flush(xs_out, ldxs_w, K / 2 + pe_dim / 2, g_dim / 2, g_dim / 2);
+  // ---- C
+  if (live) {
+    (void)oneblob_row();
+    repack(pe_dim);
+  }
+  flush(xs_out, ldxs_w, 0, pe_dim / 2, 0);
+  if (!hi_only) flush(xs_out, ldxs_w, K / 2, pe_dim / 2, pe_dim / 2);
+}
+
 template <bool TILED>
 __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict__ xin, Bound6 bd, int scale_by_bound,
                                                          uint32_t P, uint32_t n_bins,
@@ -968,6 +1129,31 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
                        (float2*)dy_dx);
   }
   return check_launch("dns_encode_fwd");
+}
+
+extern "C" int dns_encode_fwd_split(const float* in, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
+                                    const DnsGridMeta* meta, float* x_out, float* f32_out, uint32_t ld32, void* xs_out,
+                                    uint32_t ldxs, int32_t* xexp, uint32_t flags, float* dy_dx, void* stream) {
+  if (P == 0) return DNS_OK;
+  DNS_REQUIRE(in && table && meta && xs_out && xexp, "dns_encode_fwd_split: NULL argument");
+  DNS_REQUIRE((flags & ~DNS_SPLIT_HI_ONLY) == 0, "dns_encode_fwd_split: unknown flags 0x%x", flags);
+  DNS_REQUIRE(meta->n_features == 2, "dns_encode_fwd_split: n_features must be 2");
+  DNS_REQUIRE(!dy_dx || (((uintptr_t)dy_dx) & 7u) == 0, "dns_encode_fwd_split: dy_dx must be 8-byte aligned");
+  const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * meta->n_levels, K = pe_dim + g_dim;
+  const bool hi_only = (flags & DNS_SPLIT_HI_ONLY) != 0;
+  DNS_REQUIRE(n_bins >= 1 && (pe_dim % 8) == 0 && (g_dim % 8) == 0 && pe_dim <= 64 && g_dim <= 64,
+              "dns_encode_fwd_split: OneBlob / grid widths %u / %u must be multiples of 8 and <= 64", pe_dim, g_dim);
+  DNS_REQUIRE((ldxs % 8) == 0 && ldxs >= (hi_only ? K : 2 * K) && (((uintptr_t)xs_out) & 15u) == 0,
+              "dns_encode_fwd_split: xs_out must be 16-byte aligned with ldxs %% 8 == 0 and ldxs >= %u", hi_only ? K : 2 * K);
+  DNS_REQUIRE(!f32_out || ((ld32 % 4) == 0 && ld32 >= K && (((uintptr_t)f32_out) & 15u) == 0),
+              "dns_encode_fwd_split: f32_out must be 16-byte aligned with ld32 %% 4 == 0 and ld32 >= %u", K);
+  GridLevels lv = to_levels(meta);
+  const uint32_t blocks = (P + 127) / 128;
+  const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
+  DNS_LAUNCH(encode_fwd_split_kernel, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
+             n_bins, (const float2*)table, lv, x_out, f32_out, ld32, (uint32_t*)xs_out, ldxs / 2, xexp, hi_only ? 1 : 0,
+             (float2*)dy_dx);
+  return check_launch("dns_encode_fwd_split");
 }
 
 extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins, const float* table,

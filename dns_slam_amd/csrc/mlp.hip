@@ -3,7 +3,7 @@
 // mlp_split_bwd.inc (f16 hi/lo operands on v_mfma_f32_32x32x16_f16, fp32 accumulation; see mlp_split.hpp).  The exact-fp32
 // kernels on v_mfma_f32_32x32x2_f32 that this file used to hold were retired with them: three f16 products are 3.3x faster
 // than the fp32 instruction and their error is below an fp32 fma chain's (tools/mfma_f16x3_probe.hip).
-#include "common.hpp"
+#include "mlp_split.hpp"
 
 namespace dns {
 
@@ -53,7 +53,7 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   const unsigned char* prep = prepared ? reinterpret_cast<const unsigned char*>(params) : nullptr;
   return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
                               row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, prep,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (hipStream_t)stream);
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
@@ -89,7 +89,7 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                               (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
                               prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
                                        : nullptr,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, st);
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, nullptr, st);
 }
 
 extern "C" int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in,
@@ -130,4 +130,90 @@ extern "C" int dns_mlp_prepare(const float* params, uint32_t n_in, uint32_t n_ou
   if (rc != DNS_OK) return rc;
   return launch_mlp_prepare(params, param_stride, n_in, n_out, n_neurons, n_hidden_layers, n_sets,
                             reinterpret_cast<unsigned char*>(prepared), st);
+}
+
+// ---- split-row input (include/dns_hip.h, DnsSplitRows) ---------------------------------------------------------------
+static int make_xs(const char* who, const DnsSplitRows* x, const DnsSplitRows* x2, uint32_t n_in1, uint32_t n_in, bool hi_only_ok,
+                   sp::XsIn& out) {
+  DNS_REQUIRE(x && x->rows && x->exps, "%s: x / its rows / its exponents are NULL", who);
+  DNS_REQUIRE((n_in % 16) == 0, "%s: split-row input needs n_in %% 16 == 0 (got %u)", who, n_in);
+  auto seg_ok = [&](const DnsSplitRows* s, uint32_t k) {
+    return (s->ld % 8) == 0 && (((uintptr_t)s->rows) % 16) == 0 && (s->lo_off % 8) == 0 && s->ld >= k &&
+           (s->lo_off == 0 ? hi_only_ok : (s->lo_off >= k && s->ld >= s->lo_off + k));
+  };
+  if (x2) {
+    DNS_REQUIRE(x2->rows && x2->exps, "%s: x2 rows / exponents are NULL", who);
+    DNS_REQUIRE(n_in1 >= 16 && n_in1 < n_in && (n_in1 % 16) == 0, "%s: n_in1 must be a multiple of 16 in (0, n_in)", who);
+    DNS_REQUIRE(seg_ok(x, n_in1) && seg_ok(x2, n_in - n_in1), "%s: split rows must be 16-byte aligned, ld %% 8 == 0, planes inside the row "
+                "(a missing lo plane needs DNS_MLP_FP16)", who);
+  } else {
+    DNS_REQUIRE(seg_ok(x, n_in), "%s: split rows must be 16-byte aligned, ld %% 8 == 0, planes inside the row (a missing lo plane "
+                "needs DNS_MLP_FP16)", who);
+  }
+  out.s1 = {reinterpret_cast<const _Float16*>(x->rows), x->exps, x->ld, x->lo_off};
+  if (x2) out.s2 = {reinterpret_cast<const _Float16*>(x2->rows), x2->exps, x2->ld, x2->lo_off};
+  else out.s2 = {nullptr, nullptr, 0u, 0u};
+  out.n_in1 = x2 ? n_in1 : n_in;
+  return DNS_OK;
+}
+
+extern "C" int dns_mlp_fwd_split(const DnsSplitRows* x, const DnsSplitRows* x2, uint32_t n_in1, const float* params, uint32_t n_in,
+                                 uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
+                                 uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
+                                 uint32_t flags, void* stream) {
+  if (n_slots == 0) return DNS_OK;
+  DNS_REQUIRE(params && y, "dns_mlp_fwd_split: NULL argument");
+  DNS_REQUIRE((flags & ~(DNS_MLP_FP16 | DNS_MLP_PREPARED)) == 0, "dns_mlp_fwd_split: unknown flags 0x%x", flags);
+  const bool prepared = (flags & DNS_MLP_PREPARED) != 0;
+  DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_fwd_split: prepared images must be 16-byte aligned");
+  DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd_split: unsupported shape in=%u out=%u neurons=%u layers=%u",
+              n_in, n_out, n_neurons, n_hidden_layers);
+  DNS_REQUIRE(ldy >= n_out, "dns_mlp_fwd_split: ldy < n_out");
+  sp::XsIn xs;
+  {
+    const int rc = make_xs("dns_mlp_fwd_split", x, x2, n_in1, n_in, (flags & DNS_MLP_FP16) != 0, xs);
+    if (rc != DNS_OK) return rc;
+  }
+  const int rc = ensure_ready((hipStream_t)stream, "dns_mlp_fwd_split");
+  if (rc != DNS_OK) return rc;
+  const unsigned char* prep = prepared ? reinterpret_cast<const unsigned char*>(params) : nullptr;
+  return launch_mlp_fwd_split(nullptr, 0, nullptr, 0, xs.n_in1, params, n_in, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
+                              row_index, tile_group, param_stride, nullptr, (flags & DNS_MLP_FP16) != 0, prep,
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), &xs, (hipStream_t)stream);
+}
+
+extern "C" int dns_mlp_bwd_split(const DnsSplitRows* x, const DnsSplitRows* x2, uint32_t n_in1, const float* dy, uint32_t lddy,
+                                 const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
+                                 float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params, float* ws, uint32_t n_slots,
+                                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, int accumulate_dx,
+                                 void* stream) {
+  if (n_slots == 0) return DNS_OK;
+  DNS_REQUIRE(dy && params, "dns_mlp_bwd_split: NULL argument");
+  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN)) == 0,
+              "dns_mlp_bwd_split: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  const bool prepared = (accumulate_dx & (int)DNS_MLP_PREPARED) != 0;
+  DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_bwd_split: prepared images must be 16-byte aligned");
+  DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd_split: unsupported shape in=%u out=%u neurons=%u layers=%u",
+              n_in, n_out, n_neurons, n_hidden_layers);
+  DNS_REQUIRE(!d_params || (ws && (((uintptr_t)ws) % 16) == 0), "dns_mlp_bwd_split: d_params needs a 16-byte aligned workspace ws");
+  sp::XsIn xs;
+  {
+    const int rc = make_xs("dns_mlp_bwd_split", x, x2, n_in1, n_in, (accumulate_dx & (int)DNS_MLP_FP16) != 0, xs);
+    if (rc != DNS_OK) return rc;
+  }
+  n_in1 = xs.n_in1;
+  DNS_REQUIRE(!x2 || !d_x || d_x2, "dns_mlp_bwd_split: d_x2 is required with a two-segment input when d_x is asked for");
+  if (d_x) DNS_REQUIRE(lddx >= n_in1 && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd_split: d_x alignment / lddx");
+  if (d_x && x2) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd_split: lddx2 < n_in - n_in1");
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = ensure_ready(st, "dns_mlp_bwd_split");
+  if (rc != DNS_OK) return rc;
+  // (x2 of the fp32 form is only consulted for "two segments": hand the launcher a non-NULL token when there are two)
+  const float* two = x2 ? reinterpret_cast<const float*>(x2->rows) : nullptr;
+  return launch_mlp_bwd_split(nullptr, 0, two, 0, n_in1, dy, lddy, params, n_in, n_out, n_neurons, n_hidden_layers, d_x, lddx,
+                              d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride, accumulate_dx & 1,
+                              (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
+                              prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
+                                       : nullptr,
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), false, nullptr, &xs, st);
 }

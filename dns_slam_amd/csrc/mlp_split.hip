@@ -22,9 +22,11 @@ struct FwdArgs {
   float* h_save;
   const unsigned char* prep;                 // prepared images (NULL: build them from params)
   uint32_t prep_stride;                      // bytes per weight set
+  XsIn xs;                                   // split-row input (XS kernels; x / seg unused then)
 };
 
-template <int NN, int NL, int PREC>
+// XS: the input arrives in the split-row format (split_rows.hpp) and goes from memory straight into the B operand
+template <int NN, int NL, int PREC, bool XS = false>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
   constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
   int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
   float* stg = reinterpret_cast<float*>(lds + L::stage(n_in, n_out)) + wave * STG_WAVE_FLOATS;
   int* rows_all = reinterpret_cast<int*>(stg + STG_FLOATS);
-  XChunk xc[4];                                  // n_in <= 128: at most 4 chunks of 32 columns
+  XChunk xc[XS ? 1 : 4];                         // n_in <= 128: at most 4 chunks of 32 columns
+  XsTile xt;                                     // (XS) the tile's operand fragments
   bool have_x = false;
   uint32_t cur_buf = 0;
   int cur_group = -2;
@@ -69,19 +72,28 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
       cur_buf ^= 1u;
     } else {
       tile_rows_publish(rows_all + 32u * cur_buf, a.row_index, slot0, a.n_slots, lane);
+      if constexpr (XS) {
+        xs_issue<PREC>(xt, a.xs, ns0, rows_all + 32u * cur_buf, lane);
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * cur_buf, c, lane);
+        for (int c = 0; c < 4; ++c)
+          if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * cur_buf, c, lane);
+      }
     }
     const int* rows_lds = rows_all + 32u * cur_buf;
-    float* rmax = stg + STG_FLOATS + STG_ROWS;
-    x_row_max<4>(xc, n_chunks, rmax, lane);
-    int kc = scale_exp(rmax[lane & 31u]);          // cumulative exponent: accumulators hold 2^kc * (true value)
-    const float sx = pow2f(kc);
-    kc += wexp[0];
+    int kc;                                        // cumulative exponent: accumulators hold 2^kc * (true value)
     f32x16 a0[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) a0[t] = zero16();
+    if constexpr (XS) {
+      kc = xs_align<PREC>(xt, a.xs, ns0) + wexp[0];
+      layer_first_xs<PREC, NT>(xt, ns0, img_in, ns0, lane, a0);
+    } else {
+    float* rmax = stg + STG_FLOATS + STG_ROWS;
+    x_row_max<4>(xc, n_chunks, rmax, lane);
+    kc = scale_exp(rmax[lane & 31u]);
+    const float sx = pow2f(kc);
+    kc += wexp[0];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if ((uint32_t)c < n_chunks) {                // uniform
@@ -102,15 +114,20 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
         }
       }
     }
+    }
     // request the next live tile's rows now: they arrive while this tile runs its later layers
     have_x = false;
     for (uint32_t nbt = bt + 1; nbt < bt1; ++nbt) {
       if ((a.tile_group ? a.tile_group[nbt] : 0) < 0) continue;
       int* nrows_lds = rows_all + 32u * (cur_buf ^ 1u);
       tile_rows_publish(nrows_lds, a.row_index, nbt * 128u + wave * 32u, a.n_slots, lane);
+      if constexpr (XS) {
+        xs_issue<PREC>(xt, a.xs, ns0, nrows_lds, lane);
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, nrows_lds, c, lane);
+        for (int c = 0; c < 4; ++c)
+          if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, nrows_lds, c, lane);
+      }
       have_x = true;
       break;
     }
@@ -276,7 +293,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dwin_kernel(DwinArgs a) {
 template <int NN, int NL>
 static bool set_fwd_attrs() {
   return hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess &&
-         hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess;
+         hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mlp_fwd_kernel<NN, NL, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) == hipSuccess;
 }
 
 static int split_init_attrs() {
@@ -295,9 +314,11 @@ static AttrRegistrar split_attr_registrar(split_init_attrs);
 int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* params,
                          uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
                          uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
-                         float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, hipStream_t st) {
+                         float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, const sp::XsIn* xs,
+                         hipStream_t st) {
   using namespace sp;
   FwdArgs a;
+  a.xs = xs ? *xs : XsIn{};
   a.prep = prep; a.prep_stride = prep_stride;
   a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.params = params; a.n_in = n_in; a.n_out = n_out;
   a.y = y; a.ldy = ldy; a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
@@ -310,8 +331,11 @@ int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
 #define LAUNCH_FWD(NN, NL)                                                                                           \
   {                                                                                                                  \
     const size_t lds_bytes = FwdLds<NN, NL>::total(n_in, n_out, 4);                                                  \
-    if (fp16_single) DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 1>), dim3(blocks), dim3(256), lds_bytes, st, a);     \
-    else DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 3>), dim3(blocks), dim3(256), lds_bytes, st, a);                 \
+    if (xs) {                                                                                                        \
+      if (fp16_single) DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 1, true>), dim3(blocks), dim3(256), lds_bytes, st, a);     \
+      else DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 3, true>), dim3(blocks), dim3(256), lds_bytes, st, a);                 \
+    } else if (fp16_single) DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 1>), dim3(blocks), dim3(256), lds_bytes, st, a);      \
+    else DNS_LAUNCH((mlp_fwd_kernel<NN, NL, 3>), dim3(blocks), dim3(256), lds_bytes, st, a);                         \
   }
   if (n_neurons == 32 && n_hidden_layers == 1) LAUNCH_FWD(32, 1)
   else if (n_neurons == 32 && n_hidden_layers == 2) LAUNCH_FWD(32, 2)
@@ -326,9 +350,10 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
-                         bool with_dwin, const float* h_saved, hipStream_t st) {
+                         bool with_dwin, const float* h_saved, const sp::XsIn* xs, hipStream_t st) {
   using namespace sp;
   BwdArgs a;
+  a.xs = xs ? *xs : XsIn{};
   a.h_saved = h_saved;
   a.prep = prep; a.prep_stride = prep_stride;
 #ifdef DNS_BWD_TRACE

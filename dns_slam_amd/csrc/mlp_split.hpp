@@ -23,6 +23,7 @@
 // exponents and undone exactly with ldexp.  NaN / Inf propagate (a non-finite maximum leaves the scale at 1).
 #pragma once
 #include "common.hpp"
+#include "split_rows.hpp"
 
 namespace dns {
 namespace sp {
@@ -31,7 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-constexpr int TGT_EXP = 14;                  // scaled maxima lie in [2^13, 2^14)
+using sr::TGT_EXP;                           // scaled maxima lie in [2^13, 2^14)
+using sr::scale_exp;                         // exponent k such that m * 2^k lies there; 0 for m = 0 or a non-finite m
 
 struct Frag {
   half8 hi, lo;
@@ -44,14 +46,6 @@ __device__ __forceinline__ f32x16 zero16() {
 #pragma unroll
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
-}
-
-// exponent k such that m * 2^k lies in [2^(TGT_EXP-1), 2^TGT_EXP); 0 for m = 0 or a non-finite m (which then propagates)
-__device__ __forceinline__ int scale_exp(float m) {
-  if (!(m > 0.f) || !(m < INFINITY)) return 0;
-  int ex;
-  (void)frexpf(m, &ex);                      // m = f 2^ex, f in [0.5, 1)
-  return min(max(TGT_EXP - ex, -110), 110);
 }
 
 __device__ __forceinline__ float pow2f(int k) { return ldexpf(1.0f, k); }
@@ -321,6 +315,96 @@ __device__ __forceinline__ void x_chunk_issue(XChunk& xc, const float* __restric
   for (int i = 0; i < 4; ++i) rows[i] = max(rows_lds[(lane >> 3) + 8 * i], 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) xc.v[i] = *reinterpret_cast<const float4*>(base + (size_t)(uint32_t)rows[i] * ld);
+}
+
+// ---- SPLIT-ROW input (split_rows.hpp): the tile's operand fragments straight from memory ------------------------------
+// The producer of the rows (dns_encode_fwd_split, dns_feature_block_split) has already scaled and split them: lane (r = l & 31,
+// h = l >> 5) loads, for K-step s, the 8 halfs at columns 16 s + 8 h of row r of the hi plane (and of the lo plane, lo_off halfs
+// further) -- its B-operand fragment in the NAT map, 16 bytes per part and lane; the row's exponent is one more dword.  No LDS
+// staging tile, no row maximum, no conversion: what x_chunk_issue / x_row_max / x_chunk_commit / x_chunk_read / split8 did per
+// tile in every launch that reads the rows.  Two segments (columns [0, n_in1) of s1's rows, the rest from s2's; n_in1 % 16 == 0):
+// the segments carry their own exponents; xs_align brings both to the smaller one with an exact power-of-two multiply of the
+// packed halfs (a down-scaled lo part may lose bits below 2^-24 of the scaled row: < 2^-37 of the row's maximum).
+struct XsSeg {
+  const _Float16* rows;
+  const int32_t* exps;
+  uint32_t ld, lo_off;                       // halfs; lo_off = 0: no lo plane (half-width rows, PREC 1 only)
+};
+struct XsIn {
+  XsSeg s1, s2;                              // s2.rows == nullptr: one segment
+  uint32_t n_in1;
+};
+struct XsTile {
+  Frag f[8];                                 // n_in <= 128: at most 8 K-steps
+  int e1, e2;
+};
+
+template <int PREC>
+__device__ __forceinline__ void xs_issue(XsTile& t, const XsIn& in, uint32_t ns0, const int* __restrict__ rows_lds, uint32_t lane) {
+  const uint32_t row = (uint32_t)max(rows_lds[lane & 31u], 0);      // a padding slot reads row 0: nothing of it is stored
+  const uint32_t h8 = 8u * (lane >> 5);
+  const bool two = in.s2.rows != nullptr;
+  const uint32_t ns1 = two ? (in.n_in1 >> 4) : ns0;
+  const _Float16* r1 = in.s1.rows + (size_t)row * in.s1.ld + h8;
+  const _Float16* r2 = two ? in.s2.rows + (size_t)row * in.s2.ld + h8 : r1;
+  const uint32_t lo1 = in.s1.lo_off, lo2 = in.s2.lo_off;
+  t.e1 = in.s1.exps[row];
+  t.e2 = two ? in.s2.exps[row] : t.e1;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if ((uint32_t)s < ns0) {                 // uniform
+      const bool second = (uint32_t)s >= ns1;
+      const _Float16* ph = second ? r2 + 16u * ((uint32_t)s - ns1) : r1 + 16u * (uint32_t)s;
+      t.f[s].hi = *reinterpret_cast<const half8*>(ph);
+      if (PREC == 3) t.f[s].lo = *reinterpret_cast<const half8*>(ph + (second ? lo2 : lo1));
+      else t.f[s].lo = t.f[s].hi;
+    }
+  }
+}
+
+// the point's exponent (operands hold 2^e * value); with two segments both are brought to the smaller exponent first
+template <int PREC>
+__device__ __forceinline__ int xs_align(XsTile& t, const XsIn& in, uint32_t ns0) {
+  if (in.s2.rows == nullptr) return t.e1;
+  const int e = min(t.e1, t.e2);
+  const _Float16 m1 = (_Float16)ldexpf(1.0f, max(e - t.e1, -24)), m2 = (_Float16)ldexpf(1.0f, max(e - t.e2, -24));
+  const uint32_t ns1 = in.n_in1 >> 4;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if ((uint32_t)s < ns0) {
+      const _Float16 m = (uint32_t)s >= ns1 ? m2 : m1;
+      t.f[s].hi = t.f[s].hi * m;
+      if (PREC == 3) t.f[s].lo = t.f[s].lo * m;
+      else t.f[s].lo = t.f[s].hi;
+    }
+  }
+  return e;
+}
+
+// first layer on split-row fragments: out[t] += W_in[t-th 32 rows] * x.  The A fragments of K-step s+1 are requested before step
+// s's matrix instructions (as in layer_chain); the scheduling barrier per step keeps hipcc from hoisting ALL steps' fragment reads
+// in front of the first product (16 fragments of 8 registers: measured as 130 spilled registers in the forward kernel).
+template <int PREC, int NT_OUT>
+__device__ __forceinline__ void layer_first_xs(const XsTile& x, uint32_t ns_live, const _Float16* img, uint32_t nsteps, uint32_t lane,
+                                               f32x16 (&out)[NT_OUT]) {
+  Frag an[NT_OUT];
+#pragma unroll
+  for (int t = 0; t < NT_OUT; ++t) an[t] = load_frag<PREC>(img, nsteps, t, 0, lane);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if ((uint32_t)ks < ns_live) {              // uniform
+      Frag ac[NT_OUT];
+#pragma unroll
+      for (int t = 0; t < NT_OUT; ++t) ac[t] = an[t];
+      if ((uint32_t)ks + 1u < ns_live) {
+#pragma unroll
+        for (int t = 0; t < NT_OUT; ++t) an[t] = load_frag<PREC>(img, nsteps, t, ks + 1, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < NT_OUT; ++t) out[t] = mma<PREC>(ac[t], x.f[ks], out[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 }
 
 // Saved hidden activations (dns_mlp_fwd's h_save, slot-major rows of n_neurons floats): 32 columns of the tile's 32 slots in
@@ -689,6 +773,7 @@ struct BwdArgs {
   const float* h_saved;                      // [n_hidden_layers][n_slots][n_neurons] hidden activations the forward kept (NULL: recompute)
   const unsigned char* prep;                 // prepared images of the backward kernel (NULL: build them from params)
   uint32_t prep_stride;                      // bytes per weight set
+  XsIn xs;                                   // split-row input (xs.s1.rows != NULL: x / seg are unused)
 #ifdef DNS_BWD_TRACE
   unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
 #endif

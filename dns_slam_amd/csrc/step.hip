@@ -2,6 +2,7 @@
 // handful of elementwise torch ops in the reference (and in this package's autograd path); written out they cost one launch
 // each and no intermediate tensors.  HBM-bound streaming kernels, no LDS, no matrix work.
 #include "common.hpp"
+#include "split_rows.hpp"
 
 namespace dns {
 
@@ -45,6 +46,82 @@ __global__ __launch_bounds__(256) void feature_block_kernel(const float* __restr
     if (lat) *reinterpret_cast<float4*>(o + 4u * q) = make_float4(f0, f1, f2, f3);
     if (cod) *reinterpret_cast<float4*>(o + hidden + 4u * q) = make_float4(cv.x * t, cv.y * t, cv.z * t, cv.w * t);
     if (q == 0 && raw) raw[(size_t)p * 4u + 3u] = occ;
+  }
+}
+
+// The same block written in the split-row format (split_rows.hpp) for the colour / logit networks' second input segment, plus
+// -- optionally -- as fp32 rows (the streaming dW_in kernel reads fp32).  The point's qn lanes hold its hidden + C values: the
+// row maximum is three or four lane-exchange steps.  The code may come as n_ref slabs that are AVERAGED (the mean over the
+// reference frames of Decoder.merge's latents, models/decoder.py:76): code [n_frames][n_ref][pts_per_frame][C].
+__global__ __launch_bounds__(256) void feature_block_split_kernel(const float* __restrict__ fine, uint32_t ld_fine, uint32_t hidden,
+                                                                  const float* __restrict__ code, uint32_t C, uint32_t n_ref,
+                                                                  uint32_t pts_per_frame, const float* __restrict__ z,
+                                                                  const float* __restrict__ gt_depth, uint32_t P, uint32_t S,
+                                                                  float* __restrict__ feat, uint32_t ld_feat,
+                                                                  _Float16* __restrict__ xs, uint32_t ldxs, int32_t* __restrict__ xexp,
+                                                                  uint32_t hi_only, float* __restrict__ raw, uint32_t qn) {
+  const uint32_t qh = hidden / 4u, qc = C / 4u;
+  const uint32_t total = P * qn, F = hidden + C;
+  const float inv_ref = n_ref > 1u ? 1.0f / (float)n_ref : 1.0f;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t p = i / qn, q = i - p * qn;
+    const bool lat = q < qh, cod = q < qc;
+    const float* f = fine + (size_t)p * ld_fine + 1u + 4u * (lat ? q : 0u);
+    float f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+    const float occ = f[-1];
+    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (code) {
+      float t;
+      {
+        const float d = gt_depth[p / S], zz = z[p];
+        const float front = zz < d * 0.95f ? 1.f : 0.f, back = zz > d * 1.05f ? 1.f : 0.f, pos = d > 0.f ? 1.f : 0.f;
+        t = (1.f - front) * (1.f - back) * pos;
+      }
+      if (n_ref <= 1u) {
+        cv = *reinterpret_cast<const float4*>(code + (size_t)p * C + 4u * (cod ? q : 0u));
+      } else {
+        const uint32_t fr = p / pts_per_frame, pl = p - fr * pts_per_frame;
+        const float* c0 = code + ((size_t)fr * n_ref * pts_per_frame + pl) * C + 4u * (cod ? q : 0u);
+        for (uint32_t r = 0; r < n_ref; ++r) {
+          const float4 v = *reinterpret_cast<const float4*>(c0 + (size_t)r * pts_per_frame * C);
+          cv.x += v.x; cv.y += v.y; cv.z += v.z; cv.w += v.w;
+        }
+        cv.x *= inv_ref; cv.y *= inv_ref; cv.z *= inv_ref; cv.w *= inv_ref;
+      }
+      cv.x *= t; cv.y *= t; cv.z *= t; cv.w *= t;
+    }
+    if (!lat) f0 = f1 = f2 = f3 = 0.f;
+    if (!cod) cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3))),
+                    fmaxf(fmaxf(fabsf(cv.x), fabsf(cv.y)), fmaxf(fabsf(cv.z), fabsf(cv.w))));
+    const float sum = ((f0 + f1) + (f2 + f3)) + ((cv.x + cv.y) + (cv.z + cv.w));
+    if (!(fabsf(sum) < INFINITY)) m = INFINITY;            // fmaxf drops a NaN: a non-finite row keeps exponent 0 and propagates
+    for (uint32_t o = 1; o < qn; o <<= 1) m = fmaxf(m, __shfl_xor(m, (int)o));
+    const int e = sr::scale_exp(m);
+    const float sc = ldexpf(1.0f, e);
+    if (feat) {
+      float* o = feat + (size_t)p * ld_feat;
+      if (lat) *reinterpret_cast<float4*>(o + 4u * q) = make_float4(f0, f1, f2, f3);
+      if (cod) *reinterpret_cast<float4*>(o + hidden + 4u * q) = cv;
+    }
+    _Float16* row = xs + (size_t)p * ldxs;
+    uint2 h, l;
+    if (lat) {
+      sr::split_pair(f0, f1, sc, h.x, l.x);
+      sr::split_pair(f2, f3, sc, h.y, l.y);
+      *reinterpret_cast<uint2*>(row + 4u * q) = h;
+      if (!hi_only) *reinterpret_cast<uint2*>(row + F + 4u * q) = l;
+    }
+    if (cod) {
+      sr::split_pair(cv.x, cv.y, sc, h.x, l.x);
+      sr::split_pair(cv.z, cv.w, sc, h.y, l.y);
+      *reinterpret_cast<uint2*>(row + hidden + 4u * q) = h;
+      if (!hi_only) *reinterpret_cast<uint2*>(row + F + hidden + 4u * q) = l;
+    }
+    if (q == 0) {
+      xexp[p] = e;
+      if (raw) raw[(size_t)p * 4u + 3u] = occ;
+    }
   }
 }
 
@@ -192,6 +269,35 @@ extern "C" int dns_feature_block(const float* fine, uint32_t ld_fine, uint32_t h
   DNS_LAUNCH(feature_block_kernel, dim3(grid_for(P * qn, 16384)), dim3(256), 0, st, fine, ld_fine, hidden, code, C, z,
              gt_depth, (uint32_t)P, S, feat, ld_feat, raw);
   return check_launch("dns_feature_block");
+}
+
+extern "C" int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C,
+                                       uint32_t n_ref, uint32_t pts_per_frame, const float* z, const float* gt_depth, uint32_t N,
+                                       uint32_t S, float* feat, uint32_t ld_feat, void* xs_out, uint32_t ldxs, int32_t* xexp,
+                                       uint32_t flags, float* raw, void* stream) {
+  const uint64_t P = (uint64_t)N * S;
+  if (P == 0) return DNS_OK;
+  DNS_REQUIRE(fine && xs_out && xexp, "dns_feature_block_split: NULL argument");
+  DNS_REQUIRE((flags & ~DNS_SPLIT_HI_ONLY) == 0, "dns_feature_block_split: unknown flags 0x%x", flags);
+  DNS_REQUIRE(P < (1ull << 31), "dns_feature_block_split: too many points");
+  const uint32_t F = hidden + C;
+  const bool hi_only = (flags & DNS_SPLIT_HI_ONLY) != 0;
+  DNS_REQUIRE(hidden % 4 == 0 && C % 4 == 0 && hidden >= 4 && ld_fine >= hidden + 1 && F % 8 == 0,
+              "dns_feature_block_split: hidden %u / C %u / ld_fine %u", hidden, C, ld_fine);
+  DNS_REQUIRE(!feat || (ld_feat % 4 == 0 && ld_feat >= F && ((uintptr_t)feat & 15) == 0), "dns_feature_block_split: feat alignment / ld_feat");
+  DNS_REQUIRE(ldxs % 8 == 0 && ldxs >= (hi_only ? F : 2 * F) && ((uintptr_t)xs_out & 15) == 0,
+              "dns_feature_block_split: xs_out must be 16-byte aligned with ldxs %% 8 == 0 and ldxs >= %u", hi_only ? F : 2 * F);
+  DNS_REQUIRE(!code || ((uintptr_t)code & 15) == 0, "dns_feature_block_split: code must be 16-byte aligned");
+  DNS_REQUIRE(!code || (z && gt_depth), "dns_feature_block_split: a code needs z and gt_depth");
+  DNS_REQUIRE(n_ref <= 1 || (pts_per_frame > 0 && P % pts_per_frame == 0), "dns_feature_block_split: n_ref slabs need pts_per_frame dividing N S");
+  const uint32_t qn = (hidden > C ? hidden : C) / 4u;
+  DNS_REQUIRE(qn >= 1 && qn <= 16 && (qn & (qn - 1)) == 0, "dns_feature_block_split: max(hidden, C) / 4 must be a power of two <= 16");
+  DNS_REQUIRE(P * qn < (1ull << 32), "dns_feature_block_split: too many points");
+  hipStream_t st = (hipStream_t)stream;
+  DNS_LAUNCH(feature_block_split_kernel, dim3(grid_for(P * qn, 16384)), dim3(256), 0, st, fine, ld_fine, hidden, code, C, n_ref,
+             pts_per_frame, z, gt_depth, (uint32_t)P, S, feat, ld_feat, reinterpret_cast<_Float16*>(xs_out), ldxs, xexp,
+             hi_only ? 1u : 0u, raw, qn);
+  return check_launch("dns_feature_block_split");
 }
 
 extern "C" int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream) {

@@ -32,7 +32,7 @@ import ctypes as C
 import torch
 
 from . import ops
-from ._lib import DnsAdamTensor, check, ptr
+from ._lib import DnsAdamTensor, DnsSplitRows, check, ptr
 from .common import get_quad_from_c2w, get_rotation_from_quad
 
 _V = C.c_void_p
@@ -46,7 +46,7 @@ class _Set:
 
 class MapStep:
     def __init__(self, mapper, target_frames, quad_list=None, T_list=None, prep=None, features=None, lambda_lt=10.0,
-                 smooth=True, betas=(0.9, 0.999), eps=1e-8, keep_hidden=False):
+                 smooth=True, betas=(0.9, 0.999), eps=1e-8, keep_hidden=False, split_rows=None):
         m = self.m = mapper
         dev = self.dev = torch.device(m.device)
         if dev.type != "cuda":
@@ -138,6 +138,27 @@ class MapStep:
         ld = self.ld = self.pe_dim + self.grid_dim
         self.x3, self.buf = f(P, 3), f(P, ld)
         self.dydx = f(self.meta.n_levels * 3 * P * 2) if self.is_BA else None
+        # Split rows (include/dns_hip.h, ABI v9): the encoder and the feature block write their rows ONCE in the form the MLP
+        # kernels' matrix instructions take (f16 hi | lo halfs + one exponent per row) and every forward / backward launch loads
+        # its operand fragments straight from memory; the fp32 rows are still written for the streaming dW_in kernels.
+        # Measured (round 4): at fp32 grade the MLP kernels do NOT get faster (vector instructions -12 %,
+        # time +-0: they are not bound by the input handling) while the encoder pays for the second row format, so the default
+        # is off there; with half-width (fp16) networks the rows are hi planes only -- half the bytes of the most-read buffer.
+        import os
+        if split_rows is None:
+            env = os.environ.get("DNS_SPLIT_ROWS")
+            split_rows = (env != "0") if env is not None else bool(self.fp16)
+        self.sr = bool(split_rows) and ld % 16 == 0 and self.pe_dim % 16 == 0 and self.n_feat % 16 == 0 and not keep_hidden
+        self.sr_planes = 1 if self.fp16 else 2           # half-width networks read the hi plane only
+        self.sr_flags = 1 if self.fp16 else 0            # DNS_SPLIT_HI_ONLY
+        if self.sr:
+            np_ = self.sr_planes
+            h16 = lambda *s_: torch.empty(*s_, device=dev, dtype=torch.float16)
+            i32 = lambda n_: torch.empty(n_, device=dev, dtype=torch.int32)
+            self.xs, self.xexp = h16(P, np_ * ld), i32(P)
+            self.fxs, self.fexp = h16(P, np_ * self.n_feat), i32(P)
+            self.rows_x = DnsSplitRows(self.xs.data_ptr(), self.xexp.data_ptr(), np_ * ld, ld if np_ == 2 else 0)
+            self.rows_f = DnsSplitRows(self.fxs.data_ptr(), self.fexp.data_ptr(), np_ * self.n_feat, self.n_feat if np_ == 2 else 0)
         nf = self.hid + 1
         self.coarse = f(P, nf)
         n_groups = self.n_groups = max(len(pool), 1)
@@ -200,6 +221,10 @@ class MapStep:
             n = self.n_lat = sp - 1
             Pl = self.Pl = n ** 3
             self.bufl, self.occ, self.d_occ, self.d_bufl = f(Pl, ld), f(Pl, 1), f(Pl, 1), f(Pl, ld)
+            if self.sr:
+                np_ = self.sr_planes
+                self.xsl, self.xexpl = torch.empty(Pl, np_ * ld, device=dev, dtype=torch.float16), torch.empty(Pl, device=dev, dtype=torch.int32)
+                self.rows_l = DnsSplitRows(self.xsl.data_ptr(), self.xexpl.data_ptr(), np_ * ld, ld if np_ == 2 else 0)
             self.pts_l = f(Pl, 3)
             # Row m of the lattice branch's buffers holds lattice element lat_order[m], the elements in MORTON order of (i, j, k):
             # neighbouring rows then share hash-table lines and the lattice's encoding kernel runs 2.3x faster (112 -> 49 us at
@@ -244,11 +269,17 @@ class MapStep:
               "dns_lattice_points")
         meta = C.byref(self.meta.c)
         grid_l = _V(self.bufl.data_ptr() + 4 * pe)
-        check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
-                                 grid_l, ld, None, st), "dns_encode_fwd")
         n_in, _, nn, nl = self.shp_c
-        check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
-                              None, None, 0, ptr(self.h_l), self.fp16, st), "dns_mlp_fwd")
+        if self.sr:
+            check(lib.dns_encode_fwd_split(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
+                                           ptr(self.xsl), self.sr_planes * ld, ptr(self.xexpl), self.sr_flags, None, st), "dns_encode_fwd_split")
+            check(lib.dns_mlp_fwd_split(C.byref(self.rows_l), None, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
+                                        None, None, 0, self.fp16, st), "dns_mlp_fwd_split")
+        else:
+            check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
+                                     grid_l, ld, None, st), "dns_encode_fwd")
+            check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
+                                  None, None, 0, ptr(self.h_l), self.fp16, st), "dns_mlp_fwd")
         # the branch runs in MORTON order of the lattice elements (see __init__); the TV kernels want the x-major cube: two 1 MB
         # permutations (the network's occupancy out, its gradient back in)
         torch.index_select(self.occ, 0, self.lat_slot, out=self.occ_x)
@@ -256,9 +287,16 @@ class MapStep:
         check(lib.dns_tv_bwd(ptr(self.occ_x), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ_x), st),
               "dns_tv_bwd")
         torch.index_select(self.d_occ_x, 0, self.lat_order_l, out=self.d_occ)
-        check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
-                              ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, ptr(self.h_l),
-                              self.fp16, st), "dns_mlp_bwd")
+        if self.sr:
+            check(lib.dns_mlp_bwd_split(C.byref(self.rows_l), None, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
+                                        ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0,
+                                        self.fp16, st), "dns_mlp_bwd_split")
+            check(lib.dns_mlp_dwin(ptr(self.bufl), ld, None, 0, 0, n_in, nn, nl, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None,
+                                   0, self.fp16, st), "dns_mlp_dwin")
+        else:
+            check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
+                                  ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, ptr(self.h_l),
+                                  self.fp16, st), "dns_mlp_bwd")
         d_grid_l = _V(self.d_bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
                                  ptr(cur.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),
@@ -358,13 +396,25 @@ class MapStep:
         # ---- encoding (slams/mapping.py:608 + models/decoder.py:45-48)
         meta = C.byref(self.meta.c)
         grid = _V(self.buf.data_ptr() + 4 * pe)
-        check(lib.dns_encode_fwd(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf),
-                                 ld, grid, ld, ptr(self.dydx), st), "dns_encode_fwd")
+        sr = self.sr
+        if sr:
+            check(lib.dns_encode_fwd_split(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf),
+                                           ld, ptr(self.xs), self.sr_planes * ld, ptr(self.xexp), self.sr_flags, ptr(self.dydx), st),
+                  "dns_encode_fwd_split")
+        else:
+            check(lib.dns_encode_fwd(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf),
+                                     ld, grid, ld, ptr(self.dydx), st), "dns_encode_fwd")
         # ---- the four networks (slams/mapping.py:616-626)
         fp16 = self.fp16
+        rows_x = C.byref(self.rows_x) if sr else None
+        rows_f = C.byref(self.rows_f) if sr else None
 
         def fwd(x2, n_in1, params, shape, y, ri, tg, n_slots, stride, hs):
             n_in, n_out, nn, nl = shape
+            if sr:
+                check(lib.dns_mlp_fwd_split(rows_x, None if x2 is None else rows_f, n_in1, ptr(params), n_in, n_out, nn, nl, ptr(y),
+                                            y.stride(0), n_slots, ptr(ri), ptr(tg), stride, fp16, st), "dns_mlp_fwd_split")
+                return
             check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
                                   nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(hs), fp16, st), "dns_mlp_fwd")
 
@@ -372,8 +422,14 @@ class MapStep:
         fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
         fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1], self.h_f)
         # (latents | truncated 2-D code) for the colour / logit networks, occupancy into the compositing input (:553-556, :622-627)
-        check(lib.dns_feature_block(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
-                                    ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
+        if sr:
+            check(lib.dns_feature_block_split(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, 1, 0,
+                                              ptr(self.z), ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.fxs),
+                                              self.sr_planes * self.n_feat, ptr(self.fexp), self.sr_flags, ptr(self.raw), st),
+                  "dns_feature_block_split")
+        else:
+            check(lib.dns_feature_block(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
+                                        ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
         fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0, self.h_col)
         fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0, self.h_log)
         check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
@@ -414,10 +470,18 @@ class MapStep:
             n_in, n_out, nn, nl = shape
             ws = self.ws_mlp4[nws[0]] if fork_dwin else self.ws_mlp
             nws[0] += 1
-            check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
-                                  ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
-                                  0 if d_x2 is None else d_x2.stride(0), ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg),
-                                  stride, ptr(hs), acc | fp16 | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
+            if sr:
+                check(lib.dns_mlp_bwd_split(rows_x, None if x2 is None else rows_f, n_in1, ptr(dy), dy.stride(0), ptr(params), n_in,
+                                            n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2), 0 if d_x2 is None else d_x2.stride(0),
+                                            ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg), stride, acc | fp16, st), "dns_mlp_bwd_split")
+                if not fork_dwin:
+                    check(lib.dns_mlp_dwin(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, n_in, nn, nl, ptr(d_p),
+                                           ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16, st), "dns_mlp_dwin")
+            else:
+                check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
+                                      ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
+                                      0 if d_x2 is None else d_x2.stride(0), ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg),
+                                      stride, ptr(hs), acc | fp16 | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
             if fork_dwin:
                 # dW_in = dH_1^T x (memory-bound, needs only what this launch left in ws) on the side stream, beside the next
                 # network's vector-bound backward kernel

@@ -48,14 +48,17 @@ class _TimedLib:
     # per-call facts the roofline needs: the network shape of an MLP launch and which gradients it produces
     _INFO = {"dns_mlp_fwd": lambda a: {"n_in": a[6], "n_out": a[7], "nn": a[8], "nl": a[9]},
              "dns_mlp_dwin": lambda a: {"n_in": a[5], "n_out": 0, "nn": a[6], "nl": a[7]},
-             "dns_mlp_bwd": lambda a: {"n_in": a[8], "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]), "dw": bool(a[16])}}
+             "dns_mlp_bwd": lambda a: {"n_in": a[8], "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]), "dw": bool(a[16])},
+             "dns_mlp_fwd_split": lambda a: {"n_in": a[4], "n_out": a[5], "nn": a[6], "nl": a[7]},
+             "dns_mlp_bwd_split": lambda a: {"n_in": a[6], "n_out": a[7], "nn": a[8], "nl": a[9], "dx": bool(a[10]), "dw": bool(a[14])}}
 
     # argument index holding the number of units (points / slots / rays) a launch processes
     _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 12, "dns_mlp_bwd": 18,
                   "dns_composite_fwd": 3, "dns_composite_bwd": 3, "dns_raygen_sample": (14, 15), "dns_raygen_bwd": (7, 8),
                   "dns_rays_from_pixels": 12, "dns_mlp_dwin": 10, "dns_feature_block": (7, 8), "dns_loss_sums": (1, 2),
                   "dns_loss_bwd": (1, 2), "dns_raw_bwd": 2, "dns_rgb_sigmoid": 1, "dns_class_slots": (1, 2),
-                  "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5)}
+                  "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5),
+                  "dns_encode_fwd_split": 2, "dns_mlp_fwd_split": 10, "dns_mlp_bwd_split": 16, "dns_feature_block_split": (9, 10)}
 
     def arm(self, kernels=False):
         self.kernels = bool(kernels)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 8
+#define DNS_ABI_VERSION 9
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -142,6 +142,32 @@ int dns_encode_fwd(const float* in, const double* bound, uint32_t P, uint32_t n_
                    float* x_out, float* pe_out, uint32_t ld_pe, float* grid_out, uint32_t ld_grid,
                    float* dy_dx, void* stream);
 
+/* ---- split rows: the activation format between the encoders and the MLP kernels (ABI v9) ---------------------------
+ * Replaces, on the fixed launch sequence of dns_slam_amd/fused_step.py, the fp32 [P, K] rows that tcnn hands from its encodings
+ * to its networks (models/decoder.py:45-48 -> :93-94, :123-124).  A row of K values travels as K halfs hi[j] = f16(v[j] 2^e)
+ * followed by K halfs lo[j] = f16(v[j] 2^e - hi[j]) plus ONE int32 exponent e per row (e puts max |row| into [2^13, 2^14)):
+ * exactly the operand parts the MLP kernels otherwise derive from the fp32 row in every launch that reads it (row maximum,
+ * scale, two conversions per value, an LDS transpose) -- the rows of a mapping iteration are read by ~15 launches.  The
+ * bytes per row are those of the fp32 row; DNS_SPLIT_HI_ONLY (half-width mode, with DNS_MLP_FP16 consumers: tcnn's own fp16
+ * activations, models/decoder.py:58-64,94) writes the hi plane only: half the bytes.
+ *   rows: 16-byte aligned, ld halfs per row (ld % 8 == 0); hi plane at columns [0, K), lo plane at [lo_off, lo_off + K)
+ *   (lo_off = 0: no lo plane); exps [rows] int32.  The kernels that take the format need K % 16 == 0. */
+typedef struct DnsSplitRows {
+  const void* rows;
+  const int32_t* exps;
+  uint32_t ld;
+  uint32_t lo_off;
+} DnsSplitRows;
+#define DNS_SPLIT_HI_ONLY 1u
+/* dns_encode_fwd with the (OneBlob | grid) row written in the split-row format: xs_out [P, ldxs] halfs (ldxs >= 2 K, or >= K
+ * with DNS_SPLIT_HI_ONLY; K = 3 n_bins + 2 n_levels, both parts multiples of 8), xexp [P]; f32_out (NULL = skip) [P, ld32]
+ * additionally receives the fp32 row (the streaming dW_in kernel dns_mlp_dwin reads fp32 rows).  x_out, dy_dx, bound as in
+ * dns_encode_fwd.  The exponent is scale_exp(max |row|) -- bit for bit what the MLP kernels derive from the fp32 row, so a
+ * one-segment network gives IDENTICAL results on either input form. */
+int dns_encode_fwd_split(const float* in, const double* bound, uint32_t P, uint32_t n_bins, const float* table,
+                         const DnsGridMeta* meta, float* x_out, float* f32_out, uint32_t ld32, void* xs_out, uint32_t ldxs,
+                         int32_t* xexp, uint32_t flags, float* dy_dx, void* stream);
+
 /* Backward.  x [P,3] normalised coordinates.  d_pe / d_grid may be NULL.  d_table (+=) [total_rows,F]
  * (NULL = skip), d_x [P,3] (overwritten; NULL = skip) = dL/dx of the NORMALISED coordinate; if
  * bound != NULL it is scaled by 1/(b1-b0) so it is dL/d(world point).  dy_dx: NULL, or what dns_encode_fwd wrote for the
@@ -228,6 +254,20 @@ int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, ui
                 const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, const float* h_saved,
                 int accumulate_dx, void* stream);
 uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, uint32_t n_hidden_layers);
+/* The same two entry points reading their input in the split-row format (above): x [host] describes the rows of input columns
+ * [0, n_in1) (or all n_in columns when x2 == NULL), x2 [host] those of columns [n_in1, n_in); n_in, n_in1 multiples of 16.  The
+ * operand fragments go from memory straight into the matrix instruction (one 16-byte load per part, lane and K-step).  With
+ * DNS_MLP_FP16 only the hi planes are read (lo_off may be 0).  Everything else as in dns_mlp_fwd / dns_mlp_bwd, except:
+ * dns_mlp_bwd_split never launches the streaming dW_in kernel (DNS_MLP_NO_DWIN is implied): the caller runs dns_mlp_dwin on fp32
+ * rows or dns_mlp_dwin_split on the same split rows. */
+int dns_mlp_fwd_split(const DnsSplitRows* x, const DnsSplitRows* x2, uint32_t n_in1, const float* params, uint32_t n_in,
+                      uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
+                      const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);
+int dns_mlp_bwd_split(const DnsSplitRows* x, const DnsSplitRows* x2, uint32_t n_in1, const float* dy, uint32_t lddy,
+                      const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
+                      float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params, float* ws, uint32_t n_slots,
+                      const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, int accumulate_dx,
+                      void* stream);
 
 /* ---- occupancy compositing (raw2nerf_color, utils/common.py:506-537, + the logit composite of
  * slams/mapping.py:633 / slams/tracking.py:212) ----------------------------------------------
@@ -335,6 +375,13 @@ int dns_class_slots(const int64_t* labels, uint32_t N, uint32_t S, int tiled, co
                     int64_t* slot_of_point, void* stream);
 int dns_feature_block(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C, const float* z,
                       const float* gt_depth, uint32_t N, uint32_t S, float* feat, uint32_t ld_feat, float* raw, void* stream);
+/* dns_feature_block with the block written in the split-row format (above; ABI v9): xs_out [P, ldxs] halfs (hidden + C values
+ * per row), xexp [P]; feat (NULL = skip) additionally receives the fp32 block.  n_ref > 1: code is [n_frames][n_ref]
+ * [pts_per_frame][C] and the n_ref slabs of a point are AVERAGED before the truncation mask -- the mean over the reference frames
+ * of Decoder.merge's latents (models/decoder.py:76, utils/common.py:677).  max(hidden, C) / 4 must be a power of two <= 16. */
+int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C, uint32_t n_ref,
+                            uint32_t pts_per_frame, const float* z, const float* gt_depth, uint32_t N, uint32_t S, float* feat,
+                            uint32_t ld_feat, void* xs_out, uint32_t ldxs, int32_t* xexp, uint32_t flags, float* raw, void* stream);
 int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream);
 int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, float* d_col, float* d_occ, uint32_t ld_occ, int accumulate,
                 void* stream);
