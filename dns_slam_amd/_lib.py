@@ -82,6 +82,10 @@ SIGNATURES = {
     "dns_keep_best": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "dns_force_half": (C.c_int, [_P, _U, _U, _P]),
     "dns_feature_gather": (C.c_int, [_P, _P, _P, _P, _U, _U, _U, _I, _I, _I, _I, _P, _P, _P]),
+    "dns_feature_gather_frames": (C.c_int, [_P, _P, _P, _P, _P, _U, _U, _U, _U, _I, _I, _I, _I, _P, _U, _P, _P]),
+    "dns_refer_poses": (C.c_int, [_P, _P, _P, _P, _U, _P, _P, _P]),
+    "dns_merge_dy": (C.c_int, [_P, _U, _U, _U, _U, _P, _P, _U, _U, _P, _P]),
+    "dns_add_ref_sum": (C.c_int, [_P, _U, _U, _U, _P, _P]),
     "dns_tv_fwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P]),
     "dns_tv_bwd": (C.c_int, [_P, _U, _U, _U, _I, _U, _P, _P, _P]),
     "dns_group_slots": (C.c_int, [_P, _U, _U, _U, _U, _P, _P, _P, _P]),

@@ -1117,7 +1117,10 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
   }
   const uint32_t blocks = (P + 127) / 128;
   const uint32_t pe_dim = 3 * n_bins, g_dim = grid_out ? 2 * meta->n_levels : 0;
-  const bool tiled = pe_out && grid_out && ld_pe == pe_dim + g_dim && ld_grid == ld_pe && grid_out == pe_out + pe_dim;
+  // (OneBlob alone into rows of any width -- Decoder.merge's input rows -- also leaves through the LDS tile: direct row stores at
+  //  a lane stride of a whole row cost 3.4x the bytes in HBM writes)
+  const bool tiled = (pe_out && grid_out && ld_pe == pe_dim + g_dim && ld_grid == ld_pe && grid_out == pe_out + pe_dim) ||
+                     (pe_out && !grid_out && pe_dim > 0);
   if (tiled) {
     const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
     DNS_LAUNCH(encode_fwd_kernel<true>, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound),

@@ -64,8 +64,10 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                            void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params, "dns_mlp_bwd: NULL argument");
-  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN)) == 0,
+  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN | (int)DNS_MLP_DX_FIRST)) == 0,
               "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  const bool dx_first = (accumulate_dx & (int)DNS_MLP_DX_FIRST) != 0;
+  DNS_REQUIRE(!dx_first || x2, "dns_mlp_bwd: DNS_MLP_DX_FIRST needs a two-segment input");
   const bool prepared = (accumulate_dx & (int)DNS_MLP_PREPARED) != 0;
   DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_bwd: prepared images must be 16-byte aligned");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_bwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
@@ -78,9 +80,10 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
     if (rc != DNS_OK) return rc;
   }
   if (!x2) n_in1 = n_in;
-  DNS_REQUIRE(!x2 || !d_x || d_x2, "dns_mlp_bwd: d_x2 is required with a two-segment input when d_x is asked for");
+  DNS_REQUIRE(!x2 || !d_x || d_x2 || dx_first, "dns_mlp_bwd: d_x2 is required with a two-segment input when d_x is asked for");
   if (d_x) DNS_REQUIRE(lddx >= n_in1 && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
-  if (d_x && x2) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd: lddx2 < n_in - n_in1");
+  if (d_x && x2 && !dx_first) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd: lddx2 < n_in - n_in1");
+  if (dx_first) d_x2 = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int rc = ensure_ready(st, "dns_mlp_bwd");
   if (rc != DNS_OK) return rc;

@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void feature_block_split_kernel(const float* _
       if (lat) *reinterpret_cast<float4*>(o + 4u * q) = make_float4(f0, f1, f2, f3);
       if (cod) *reinterpret_cast<float4*>(o + hidden + 4u * q) = cv;
     }
+    if (xs == nullptr) {
+      if (q == 0 && raw) raw[(size_t)p * 4u + 3u] = occ;
+      continue;
+    }
     _Float16* row = xs + (size_t)p * ldxs;
     uint2 h, l;
     if (lat) {
@@ -277,7 +281,7 @@ extern "C" int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint
                                        uint32_t flags, float* raw, void* stream) {
   const uint64_t P = (uint64_t)N * S;
   if (P == 0) return DNS_OK;
-  DNS_REQUIRE(fine && xs_out && xexp, "dns_feature_block_split: NULL argument");
+  DNS_REQUIRE(fine && (xs_out ? xexp != nullptr : feat != nullptr), "dns_feature_block_split: NULL argument");
   DNS_REQUIRE((flags & ~DNS_SPLIT_HI_ONLY) == 0, "dns_feature_block_split: unknown flags 0x%x", flags);
   DNS_REQUIRE(P < (1ull << 31), "dns_feature_block_split: too many points");
   const uint32_t F = hidden + C;
@@ -285,7 +289,7 @@ extern "C" int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint
   DNS_REQUIRE(hidden % 4 == 0 && C % 4 == 0 && hidden >= 4 && ld_fine >= hidden + 1 && F % 8 == 0,
               "dns_feature_block_split: hidden %u / C %u / ld_fine %u", hidden, C, ld_fine);
   DNS_REQUIRE(!feat || (ld_feat % 4 == 0 && ld_feat >= F && ((uintptr_t)feat & 15) == 0), "dns_feature_block_split: feat alignment / ld_feat");
-  DNS_REQUIRE(ldxs % 8 == 0 && ldxs >= (hi_only ? F : 2 * F) && ((uintptr_t)xs_out & 15) == 0,
+  DNS_REQUIRE(!xs_out || (ldxs % 8 == 0 && ldxs >= (hi_only ? F : 2 * F) && ((uintptr_t)xs_out & 15) == 0),
               "dns_feature_block_split: xs_out must be 16-byte aligned with ldxs %% 8 == 0 and ldxs >= %u", hi_only ? F : 2 * F);
   DNS_REQUIRE(!code || ((uintptr_t)code & 15) == 0, "dns_feature_block_split: code must be 16-byte aligned");
   DNS_REQUIRE(!code || (z && gt_depth), "dns_feature_block_split: a code needs z and gt_depth");

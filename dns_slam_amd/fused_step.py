@@ -46,7 +46,7 @@ class _Set:
 
 class MapStep:
     def __init__(self, mapper, target_frames, quad_list=None, T_list=None, prep=None, features=None, lambda_lt=10.0,
-                 smooth=True, betas=(0.9, 0.999), eps=1e-8, keep_hidden=False, split_rows=None):
+                 smooth=True, betas=(0.9, 0.999), eps=1e-8, keep_hidden=False, split_rows=None, refer_frames=None):
         m = self.m = mapper
         dev = self.dev = torch.device(m.device)
         if dev.type != "cuda":
@@ -55,13 +55,19 @@ class MapStep:
             raise ValueError("MapStep needs mapper.static_shapes and mapper.fused_losses (the sync-free iteration)")
         if m.dist is not None and m.dist.union:
             raise ValueError("MapStep: union-batch mode runs through the autograd path")
-        if features is not None and features.dim() != 3:
-            raise ValueError("MapStep takes the per-sample code [N, S, C] (stem feature maps run through the autograd path)")
+        # features: None | the per-sample code [N, S, C] | the stem feature maps [n_target, n_refer, C, h, w] of the reference
+        # views (+ refer_frames): then the 2-D branch of slams/mapping.py:532-557 -- feature_matching + Decoder.merge -- runs
+        # INSIDE every step, forward and backward (Merge's weights train, its OneBlob input carries pose gradient)
+        self.stem = features is not None and features.dim() == 5
+        if features is not None and features.dim() not in (3, 5):
+            raise ValueError("MapStep: features is the per-sample code [N, S, C] or the stem feature maps [K, R, C, h, w]")
+        if self.stem and refer_frames is None:
+            raise ValueError("MapStep: stem feature maps need refer_frames (kf_idx, est_c2w)")
         self.dist_on = m.dist is not None and m.dist.enabled       # (a forced one-rank group counts: tests drive RCCL that way)
         self.world = m.dist.world_size if self.dist_on else 1
         self.frames = target_frames
         self.prep = prep if prep is not None else m.prepare_frames(target_frames)
-        self.features = None if features is None else features.to(dev).float().contiguous()
+        self.features = None if (features is None or self.stem) else features.to(dev).float().contiguous()
         self.lambda_lt, self.smooth = float(lambda_lt), bool(smooth)
         self.betas, self.eps = betas, eps
         K = self.K = m.n_target_frame
@@ -74,7 +80,7 @@ class MapStep:
         shp = lambda n: (n.n_input_dims, n.n_output_dims, n.n_neurons, n.n_hidden_layers)
         self.shp_c, self.shp_col, self.shp_log = (shp(n) for n in nets)
         self.shp_f = (self.pe_dim + self.grid_dim, self.hid + 1, pool.nn_, pool.nl)
-        self.n_feat = self.hid + (self.hid if features is None else self.features.shape[-1])
+        self.n_feat = self.hid + (self.hid if (features is None or self.stem) else self.features.shape[-1])
         if not (self.pe_dim % 4 == 0 and self.pe_dim <= 64 and self.n_feat <= 64 and self.n_feat % 4 == 0
                 and self.shp_col[0] == self.pe_dim + self.n_feat):
             raise ValueError("MapStep: network shapes outside the two-segment input form (ops.render_nets has the same limits)")
@@ -96,21 +102,33 @@ class MapStep:
         self.n_bins = dec.pe_fn.pe_fn.n_bins
         self.p_coarse, self.p_color, self.p_logit = (n.params for n in nets)
         self.p_pool = pool.pool
-        plist = [self.p_color, self.p_logit, self.p_pool, self.p_table, self.p_coarse, self.Q, self.T]
+        # [colour | logit | pool | merge (with stem features) || table | coarse | quat | trans]: what stands in front of the bar is
+        # complete when the ray branch's MLP backward ends (the early all-reduce bucket under data parallelism)
+        names = ["color", "logit", "pool"] + (["merge"] if self.stem else []) + ["table", "coarse", "quat", "trans"]
+        if self.stem:
+            mg = dec.merge.decoder
+            self.shp_m = shp(mg)
+            self.p_merge = mg.params
+        byname = {"color": self.p_color, "logit": self.p_logit, "pool": self.p_pool, "table": self.p_table, "coarse": self.p_coarse,
+                  "quat": self.Q, "trans": self.T}
+        if self.stem:
+            byname["merge"] = self.p_merge
+        plist = [byname[n] for n in names]
         for p in plist:
             if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
                 raise ValueError("MapStep: parameters must be contiguous fp32 CUDA tensors")
         sizes = [(p.numel() + 3) // 4 * 4 for p in plist]                  # 16-byte aligned segments
         offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        off_of = dict(zip(names, offs))
         n_G = sum(sizes)
         self.M, self.V = torch.zeros(n_G, device=dev), torch.zeros(n_G, device=dev)
         self.adam_state = torch.zeros(3, device=dev)
         lr_pose = float(m.BA_cam_lr) * float(self.is_BA)
-        items = [(plist[i], offs[i], plist[i].numel(), float(m.lr)) for i in range(5)]
+        items = [(byname[n], off_of[n], byname[n].numel(), float(m.lr)) for n in names if n not in ("quat", "trans")]
         if self.is_BA:
             a4, a3 = 4 * self.pose_row0, 3 * self.pose_row0
-            items.append((self.Q.view(-1)[a4:], offs[5] + a4, self.Q.numel() - a4, lr_pose))
-            items.append((self.T.view(-1)[a3:], offs[6] + a3, self.T.numel() - a3, lr_pose))
+            items.append((self.Q.view(-1)[a4:], off_of["quat"] + a4, self.Q.numel() - a4, lr_pose))
+            items.append((self.T.view(-1)[a3:], off_of["trans"] + a3, self.T.numel() - a3, lr_pose))
         items = [it for it in items if it[2] > 0]
         self.n_adam = len(items)
 
@@ -141,13 +159,13 @@ class MapStep:
         # Split rows (include/dns_hip.h, ABI v9): the encoder and the feature block write their rows ONCE in the form the MLP
         # kernels' matrix instructions take (f16 hi | lo halfs + one exponent per row) and every forward / backward launch loads
         # its operand fragments straight from memory; the fp32 rows are still written for the streaming dW_in kernels.
-        # Measured (round 4): at fp32 grade the MLP kernels do NOT get faster (vector instructions -12 %,
-        # time +-0: they are not bound by the input handling) while the encoder pays for the second row format, so the default
-        # is off there; with half-width (fp16) networks the rows are hi planes only -- half the bytes of the most-read buffer.
+        # Measured (round 4): the MLP kernels do NOT get faster at fp32 grade (vector instructions -12 %,
+        # time +-0: they are not bound by their input handling; cfg2 step 1.89 -> 2.04 ms) and with half-width networks the
+        # forward's gain (0.60 -> 0.49 ms at cfg5_fp16) is eaten by the encoder writing a second row format (0.40 -> 0.51):
+        # 6.19 -> 6.34 ms.  OFF by default; DNS_SPLIT_ROWS=1 / split_rows=True turns it on (tests/test_gpu_split_rows.py).
         import os
         if split_rows is None:
-            env = os.environ.get("DNS_SPLIT_ROWS")
-            split_rows = (env != "0") if env is not None else bool(self.fp16)
+            split_rows = os.environ.get("DNS_SPLIT_ROWS", "0") == "1"
         self.sr = bool(split_rows) and ld % 16 == 0 and self.pe_dim % 16 == 0 and self.n_feat % 16 == 0 and not keep_hidden
         self.sr_planes = 1 if self.fp16 else 2           # half-width networks read the hi plane only
         self.sr_flags = 1 if self.fp16 else 0            # DNS_SPLIT_HI_ONLY
@@ -173,9 +191,9 @@ class MapStep:
             o_G = (P * nf + 3) // 4 * 4                                   # G starts 16-byte aligned
             st_.zb = torch.zeros(o_G + n_G, device=dev)                   # [fine | G]: one fill per step clears both
             st_.fine, st_.G = st_.zb[:P * nf].view(P, nf), st_.zb[o_G:]
-            seg = lambda i: st_.G[offs[i]:offs[i] + plist[i].numel()]
-            st_.g_color, st_.g_logit, st_.g_pool, st_.g_table, st_.g_coarse, st_.g_quat, st_.g_trans = (seg(i) for i in range(7))
-            st_.G_early, st_.G_late = st_.G[:offs[3]], st_.G[offs[3]:]
+            for n_ in names:
+                setattr(st_, "g_" + n_, st_.G[off_of[n_]:off_of[n_] + byname[n_].numel()])
+            st_.G_early, st_.G_late = st_.G[:off_of["table"]], st_.G[off_of["table"]:]
             st_.adam_items = adam_items(st_.G)
             st_.row_index = torch.empty(self.n_slots, device=dev, dtype=torch.int32)
             st_.tile_group = torch.empty(self.n_slots // 128, device=dev, dtype=torch.int32)
@@ -193,6 +211,41 @@ class MapStep:
         self.d_featx = torch.zeros(P, 4 + self.n_feat, device=dev)        # zeroed once: the code columns only accumulate
         self.d_x3 = f(P, 3)
         raw_lib = ops.lib._raw
+        if self.stem:
+            Kf, R, Cs, fh, fw = features.shape
+            if Kf != K:
+                raise ValueError("MapStep: stem feature maps must have one set of reference views per target frame")
+            self.R, self.Cs, self.fh, self.fw = int(R), int(Cs), int(fh), int(fw)
+            self.feat_maps = features.detach().to(dev).float().permute(0, 1, 3, 4, 2).contiguous().reshape(K * R, fh, fw, Cs)
+            mrg = dec.merge
+            self.n_bins_m = mrg.pe_fn.n_bins
+            self.pe_m = 3 * self.n_bins_m
+            n_in_m, n_out_m = self.shp_m[0], self.shp_m[1]
+            if not (n_in_m == self.pe_m + Cs and n_out_m == self.hid and self.pe_m % 4 == 0):
+                raise ValueError("MapStep: Decoder.merge's network does not match the stem features / hidden width")
+            self.b6m = ops._bound6(mrg.bound)
+            # which pose every reference view takes (slams/mapping.py:534-545): -1 = the target frame itself, a keyframe that is
+            # also a target = that target's pose under optimisation, anything else = the stored keyframe pose
+            target_idx = list(target_frames["kf_idx"])
+            src, fixed = [], []
+            for i in range(K):
+                ridx = list(refer_frames["kf_idx"][i])
+                if len(ridx) != R:
+                    raise ValueError("MapStep: refer_frames['kf_idx'] must list n_refer views per target frame")
+                for r, rid in enumerate(ridx):
+                    k = i if rid == -1 else (target_idx.index(rid) if rid in target_idx else -1)
+                    src.append(k)
+                    fixed.append(refer_frames["est_c2w"][i][ridx.index(rid)].detach().to(dev).float().reshape(16))
+            self.ref_src = torch.tensor(src, dtype=torch.int32, device=dev)
+            self.ref_fixed = torch.stack(fixed).contiguous()
+            self.w2c, self.origin = f(K * R, 16), f(K * R, 3)
+            Mr = self.Mr = R * P
+            self.Pf = npf * S                                             # points per target frame
+            self.mbuf, self.rel, self.xm = f(Mr, n_in_m), f(Mr, 3), f(Mr, 3)
+            self.mlat, self.mdy = f(Mr, n_out_m), f(Mr, n_out_m)
+            self.d_mpe, self.d_rel = (f(Mr, self.pe_m), f(Mr, 3)) if self.is_BA else (None, None)
+            self.ws_m = f(max(int(raw_lib.dns_mlp_bwd_ws_floats(Mr, self.shp_m[2], self.shp_m[3])), 4))
+            self.K9 = (C.c_float * 9)(float(m.fx), 0.0, float(m.cx), 0.0, float(m.fy), float(m.cy), 0.0, 0.0, 1.0)
         self.ray_ws = f(max(int(raw_lib.dns_raygen_bwd_ws_floats(K, npf)), 1))
         mlp_ws = lambda n_slots, s: f(max(int(raw_lib.dns_mlp_bwd_ws_floats(n_slots, s[2], s[3])), 4))
         self.ws_mlp = max((mlp_ws(self.n_slots, s) for s in (self.shp_f, self.shp_c, self.shp_col, self.shp_log)),
@@ -404,6 +457,20 @@ class MapStep:
         else:
             check(lib.dns_encode_fwd(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf),
                                      ld, grid, ld, ptr(self.dydx), st), "dns_encode_fwd")
+        # ---- the 2-D branch inside the iteration (slams/mapping.py:532-551): reference poses -> projected image code + relative
+        # point -> OneBlob -> Merge network; its mean over the views is taken by the feature block below
+        if self.stem:
+            R, Pf = self.R, self.Pf
+            n_in_m, n_out_m, nn_m, nl_m = self.shp_m
+            check(lib.dns_refer_poses(ptr(self.Q), ptr(self.T), ptr(self.ref_src), ptr(self.ref_fixed), K * R, ptr(self.w2c),
+                                      ptr(self.origin), st), "dns_refer_poses")
+            check(lib.dns_feature_gather_frames(ptr(self.pts), ptr(self.w2c), ptr(self.origin), self.K9, ptr(self.feat_maps), K, R, Pf,
+                                                self.Cs, self.fh, self.fw, H, W, _V(self.mbuf.data_ptr() + 4 * self.pe_m), n_in_m,
+                                                ptr(self.rel), st), "dns_feature_gather_frames")
+            check(lib.dns_encode_fwd(ptr(self.rel), self.b6m, self.Mr, self.n_bins_m, None, None, ptr(self.xm), ptr(self.mbuf), n_in_m,
+                                     None, 0, None, st), "dns_encode_fwd")
+            check(lib.dns_mlp_fwd(ptr(self.mbuf), n_in_m, None, 0, 0, ptr(self.p_merge), n_in_m, n_out_m, nn_m, nl_m, ptr(self.mlat),
+                                  n_out_m, self.Mr, None, None, 0, None, self.fp16, st), "dns_mlp_fwd")
         # ---- the four networks (slams/mapping.py:616-626)
         fp16 = self.fp16
         rows_x = C.byref(self.rows_x) if sr else None
@@ -422,10 +489,12 @@ class MapStep:
         fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
         fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1], self.h_f)
         # (latents | truncated 2-D code) for the colour / logit networks, occupancy into the compositing input (:553-556, :622-627)
-        if sr:
-            check(lib.dns_feature_block_split(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, 1, 0,
-                                              ptr(self.z), ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.fxs),
-                                              self.sr_planes * self.n_feat, ptr(self.fexp), self.sr_flags, ptr(self.raw), st),
+        if sr or self.stem:
+            code, n_ref, Pf_ = (self.mlat, self.R, self.Pf) if self.stem else (self.features, 1, 0)
+            check(lib.dns_feature_block_split(ptr(fine), self.hid + 1, self.hid, ptr(code), self.n_feat - self.hid, n_ref, Pf_,
+                                              ptr(self.z), ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat,
+                                              ptr(self.fxs) if sr else None, self.sr_planes * self.n_feat,
+                                              ptr(self.fexp) if sr else None, self.sr_flags, ptr(self.raw), st),
                   "dns_feature_block_split")
         else:
             check(lib.dns_feature_block(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
@@ -497,6 +566,27 @@ class MapStep:
         check(lib.dns_raw_bwd(ptr(self.d_raw), ptr(self.raw), P, ptr(self.d_col), d_fine_dst, ldf, 1, st), "dns_raw_bwd")
         bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, cur.g_color, None, None, P, 0, 3, self.h_col)
         bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, cur.g_logit, None, None, P, 0, 3, self.h_log)
+        if self.stem:
+            # Merge's backward (models/decoder.py:67-77): d code -> the R views' latent gradients -> weight gradients and, under
+            # bundle adjustment, d OneBlob -> d(relative point) (added to the points' gradient before the pose reduction)
+            n_in_m, n_out_m, nn_m, nl_m = self.shp_m
+            pe_m = self.pe_m
+            check(lib.dns_merge_dy(_V(self.d_featx.data_ptr() + 4 * (4 + self.hid)), ldf, n_out_m, self.R, self.Pf, ptr(self.z),
+                                   ptr(self.gt_depth), N, S, ptr(self.mdy), st), "dns_merge_dy")
+            check(lib.dns_mlp_bwd(ptr(self.mbuf), n_in_m, _V(self.mbuf.data_ptr() + 4 * pe_m), n_in_m, pe_m, ptr(self.mdy), n_out_m,
+                                  ptr(self.p_merge), n_in_m, n_out_m, nn_m, nl_m, ptr(self.d_mpe), pe_m, None, 0, ptr(cur.g_merge),
+                                  ptr(self.ws_m), self.Mr, None, None, 0, None,
+                                  ops.MLP_DX_FIRST_FLAG | fp16 | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
+            if fork_dwin:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    check(lib.dns_mlp_dwin(ptr(self.mbuf), n_in_m, None, 0, 0, n_in_m, nn_m, nl_m, ptr(cur.g_merge), ptr(self.ws_m),
+                                           self.Mr, None, None, 0, fp16, side_st), "dns_mlp_dwin")
+            if self.is_BA:
+                check(lib.dns_encode_bwd(ptr(self.xm), self.b6m, self.Mr, self.n_bins_m, None, None, ptr(self.d_mpe), pe_m, None, 0,
+                                         None, ptr(self.d_rel), None, None, 0, 0, st), "dns_encode_bwd")
         bwd(None, 0, self.d_featx[:, 3:3 + L], self.p_pool, self.shp_f, None, cur.g_pool, row_index, tile_group,
             self.n_slots, self.p_pool.shape[-1], 1, self.h_f)
         work = None
@@ -519,12 +609,16 @@ class MapStep:
                 st2 = _V(self.side.cuda_stream)
                 check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld, d_grid,
                                          ld, None, ptr(self.d_x3), ptr(self.dydx), None, 0, 0, st2), "dns_encode_bwd")
+                if self.stem:
+                    check(lib.dns_add_ref_sum(ptr(self.d_rel), self.R, self.Pf, P, ptr(self.d_x3), st2), "dns_add_ref_sum")
                 check(lib.dns_raygen_bwd(ptr(pix), ptr(self.Q), self.camv, 0, H, 0, W, K, npf, S, ptr(self.z), ptr(self.d_x3), None,
                                          None, ptr(self.ray_ws), ptr(cur.g_quat), ptr(cur.g_trans), st2), "dns_raygen_bwd")
         check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld, d_grid, ld,
                                  ptr(cur.g_table), ptr(self.d_x3) if (self.is_BA and not fork_pose) else None, ptr(self.dydx),
                                  ptr(self.ws_enc), self.scatter_form, self.scatter_cap, st), "dns_encode_bwd")
         if self.is_BA and not fork_pose:
+            if self.stem:
+                check(lib.dns_add_ref_sum(ptr(self.d_rel), self.R, self.Pf, P, ptr(self.d_x3), st), "dns_add_ref_sum")
             check(lib.dns_raygen_bwd(ptr(pix), ptr(self.Q), self.camv, 0, H, 0, W, K, npf, S, ptr(self.z), ptr(self.d_x3), None,
                                      None, ptr(self.ray_ws), ptr(cur.g_quat), ptr(cur.g_trans), st), "dns_raygen_bwd")
         if on_side:
@@ -553,6 +647,7 @@ class MapStep:
     g_color = property(lambda self: self.cur.g_color)
     g_logit = property(lambda self: self.cur.g_logit)
     g_pool = property(lambda self: self.cur.g_pool)
+    g_merge = property(lambda self: self.cur.g_merge)
     g_quat = property(lambda self: self.cur.g_quat)
     g_trans = property(lambda self: self.cur.g_trans)
 
@@ -586,16 +681,21 @@ class TrackStep:
     table scatter.  Same kernels, arithmetic and generator calls as ``Tracker.track_frame`` (tests/test_gpu_fused_step.py).
     ``features``: None or the per-sample 2-D code [n_pixels, S, C] (stem feature maps run through ``Tracker.track_frame``)."""
 
-    def __init__(self, tracker, cur_frames, est_c2w, features=None, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, tracker, cur_frames, est_c2w, features=None, betas=(0.9, 0.999), eps=1e-8, refer_frames=None):
         t = self.t = tracker
         dev = self.dev = torch.device(t.device)
         if dev.type != "cuda":
             raise ValueError("dns_slam_amd ops run on the GPU only; there is no CPU fallback")
-        if features is not None and features.dim() != 3:
-            raise ValueError("TrackStep takes the per-sample code [N, S, C] (stem feature maps run through Tracker.track_frame)")
+        # features: None | per-sample code [N, S, C] | stem maps [1, n_refer, C, h, w] + refer_frames['est_w2c'] [n_refer, 4, 4]:
+        # then feature_matching + Decoder.merge run inside every iteration (slams/tracking.py:162-165), Merge frozen like the scene
+        self.stem = features is not None and features.dim() == 5
+        if features is not None and features.dim() not in (3, 5):
+            raise ValueError("TrackStep: features is the per-sample code [N, S, C] or the stem feature maps [1, R, C, h, w]")
+        if self.stem and refer_frames is None:
+            raise ValueError("TrackStep: stem feature maps need refer_frames['est_w2c']")
         dec = t.decoder
         self.prep = t.prepare_frame(cur_frames)
-        self.features = None if features is None else features.to(dev).float().contiguous()
+        self.features = None if (features is None or self.stem) else features.to(dev).float().contiguous()
         self.betas, self.eps = betas, eps
         self.pe_dim, self.grid_dim, self.hid = dec.pe_dim, dec.grid_dim, dec.hidden_dim
         nets = (dec.coarse_fn.decoder, dec.out_fn.color_decoder, dec.out_fn.logit_decoder)
@@ -604,7 +704,7 @@ class TrackStep:
         self.shp_c, self.shp_col, self.shp_log = (shp(n) for n in nets)
         self.p_coarse, self.p_color, self.p_logit = (n.params for n in nets)
         self.p_table, self.meta, self.n_bins = dec.pe_fn.grid_fn.params, dec.pe_fn.grid_fn.meta, dec.pe_fn.pe_fn.n_bins
-        self.n_feat = self.hid + (self.hid if features is None else self.features.shape[-1])
+        self.n_feat = self.hid + (self.hid if (features is None or self.stem) else self.features.shape[-1])
         if not (self.pe_dim % 4 == 0 and self.pe_dim <= 64 and self.n_feat <= 64 and self.n_feat % 4 == 0
                 and self.shp_col[0] == self.pe_dim + self.n_feat and self.shp_c[1] == self.hid + 1):
             raise ValueError("TrackStep: network shapes outside the two-segment input form")
@@ -645,9 +745,28 @@ class TrackStep:
         self.sums_ws, self.out, self.one = f(ops.LOSS_SUMS_FLOATS), f(16), torch.ones(1, device=dev)
         self.d_color, self.d_depth, self.d_var, self.d_sem = f(N, 3), f(N), f(N), f(N, self.n_class)
         self.d_raw, self.d_logit, self.d_col = f(P, 4), f(P, self.n_class), f(P, 4)
-        self.d_featx = f(P, 4 + self.n_feat)
+        self.d_featx = torch.zeros(P, 4 + self.n_feat, device=dev)
         self.d_x3 = f(P, 3)
         raw_lib = ops.lib._raw
+        if self.stem:
+            _, R, Cs, fh, fw = features.shape
+            self.R, self.Cs, self.fh, self.fw = int(R), int(Cs), int(fh), int(fw)
+            self.feat_maps = features.detach().to(dev).float()[0].permute(0, 2, 3, 1).contiguous()
+            mg = dec.merge.decoder
+            self.shp_m, self.p_merge = shp(mg), mg.params
+            self.n_bins_m = dec.merge.pe_fn.n_bins
+            self.pe_m = 3 * self.n_bins_m
+            if not (self.shp_m[0] == self.pe_m + Cs and self.shp_m[1] == self.hid and self.pe_m % 4 == 0):
+                raise ValueError("TrackStep: Decoder.merge's network does not match the stem features / hidden width")
+            self.b6m = ops._bound6(dec.merge.bound)
+            w2c = refer_frames["est_w2c"].clone().detach().to(dev).float()                 # slams/tracking.py:162
+            self.w2c = w2c.reshape(R, 16).contiguous()
+            self.origin = torch.inverse(w2c)[:, :3, 3].contiguous()                          # utils/common.py:672-674
+            Mr = self.Mr = R * P
+            self.mbuf, self.rel, self.xm = f(Mr, self.shp_m[0]), f(Mr, 3), f(Mr, 3)
+            self.mlat, self.mdy = f(Mr, self.hid), f(Mr, self.hid)
+            self.d_mpe, self.d_rel = f(Mr, self.pe_m), f(Mr, 3)
+            self.K9 = (C.c_float * 9)(float(t.fx), 0.0, float(t.cx), 0.0, float(t.fy), float(t.cy), 0.0, 0.0, 1.0)
         self.ray_ws = f(max(int(raw_lib.dns_raygen_bwd_ws_floats(1, N)), 1))
         # The scene is frozen for the whole loop: its networks' operand images are built ONCE (DNS_MLP_PREPARED) and every
         # launch copies them in instead of rebuilding them per workgroup (0.253 -> 0.245 ms per iteration).  MapStep does not
@@ -656,12 +775,16 @@ class TrackStep:
         # re-preparation, 2.133 with both; stand-alone the prepared launches are 1-3 us (forward) and 4-7 us (backward) faster).
         self.PREP = ops.MLP_PREPARED_FLAG
         self.w = []
-        for p_, shp_ in ((self.p_coarse, self.shp_c), (self.p_color, self.shp_col), (self.p_logit, self.shp_log)):
+        nets_w = [(self.p_coarse, self.shp_c), (self.p_color, self.shp_col), (self.p_logit, self.shp_log)]
+        if self.stem:
+            nets_w.append((self.p_merge, self.shp_m))
+        for p_, shp_ in nets_w:
             w = f(int(raw_lib.dns_mlp_prepared_floats(*shp_)))
             check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w),
                                           _V(torch.cuda.current_stream().cuda_stream)), "dns_mlp_prepare")
             self.w.append(w)
-        self.w_coarse, self.w_color, self.w_logit = self.w
+        self.w_coarse, self.w_color, self.w_logit = self.w[:3]
+        self.w_merge = self.w[3] if self.stem else None
         self.lam = (C.c_float * 8)(t.lambda_p, t.lambda_d, t.lambda_l, 0.0, 0.0, 0.0, 0.0, 1.0)
         self.camv = (C.c_double * 4)(float(t.fx), float(t.fy), float(t.cx), float(t.cy))
         self.b6 = ops._bound6(t.bound)
@@ -701,8 +824,21 @@ class TrackStep:
                                   nn, nl, ptr(y), y.stride(0), P, None, None, 0, None, fp16, st), "dns_mlp_fwd")
 
         fwd(None, 0, self.w_coarse, self.shp_c, self.lat)                  # coarse-only render (slams/tracking.py:196-200)
-        check(lib.dns_feature_block(ptr(self.lat), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
-                                    ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
+        if self.stem:
+            n_in_m, n_out_m, nn_m, nl_m = self.shp_m
+            check(lib.dns_feature_gather_frames(ptr(self.pts), ptr(self.w2c), ptr(self.origin), self.K9, ptr(self.feat_maps), 1, self.R,
+                                                P, self.Cs, self.fh, self.fw, H, W, _V(self.mbuf.data_ptr() + 4 * self.pe_m), n_in_m,
+                                                ptr(self.rel), st), "dns_feature_gather_frames")
+            check(lib.dns_encode_fwd(ptr(self.rel), self.b6m, self.Mr, self.n_bins_m, None, None, ptr(self.xm), ptr(self.mbuf), n_in_m,
+                                     None, 0, None, st), "dns_encode_fwd")
+            check(lib.dns_mlp_fwd(ptr(self.mbuf), n_in_m, None, 0, 0, ptr(self.w_merge), n_in_m, n_out_m, nn_m, nl_m, ptr(self.mlat),
+                                  n_out_m, self.Mr, None, None, 0, None, fp16, st), "dns_mlp_fwd")
+            check(lib.dns_feature_block_split(ptr(self.lat), self.hid + 1, self.hid, ptr(self.mlat), self.hid, self.R, P, ptr(self.z),
+                                              ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, None, 0, None, 0, ptr(self.raw), st),
+                  "dns_feature_block_split")
+        else:
+            check(lib.dns_feature_block(ptr(self.lat), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, ptr(self.z),
+                                        ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
         fwd(self.feat, pe, self.w_color, self.shp_col, self.raw)
         fwd(self.feat, pe, self.w_logit, self.shp_log, self.logit)
         check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
@@ -738,10 +874,22 @@ class TrackStep:
         d_feat = self.d_featx[:, 4:]
         bwd(self.feat, pe, self.d_col, self.w_color, self.shp_col, d_feat, 1)        # d_buf (zeroed) += ; feature block =
         bwd(self.feat, pe, self.d_logit, self.w_logit, self.shp_log, d_feat, 3)
+        if self.stem:
+            n_in_m, n_out_m, nn_m, nl_m = self.shp_m
+            pe_m = self.pe_m
+            check(lib.dns_merge_dy(_V(self.d_featx.data_ptr() + 4 * (4 + self.hid)), ldf, n_out_m, self.R, P, ptr(self.z),
+                                   ptr(self.gt_depth), N, S, ptr(self.mdy), st), "dns_merge_dy")
+            check(lib.dns_mlp_bwd(ptr(self.mbuf), n_in_m, _V(self.mbuf.data_ptr() + 4 * pe_m), n_in_m, pe_m, ptr(self.mdy), n_out_m,
+                                  ptr(self.w_merge), n_in_m, n_out_m, nn_m, nl_m, ptr(self.d_mpe), pe_m, None, 0, None, None, self.Mr,
+                                  None, None, 0, None, ops.MLP_DX_FIRST_FLAG | fp16, st), "dns_mlp_bwd")
+            check(lib.dns_encode_bwd(ptr(self.xm), self.b6m, self.Mr, self.n_bins_m, None, None, ptr(self.d_mpe), pe_m, None, 0, None,
+                                     ptr(self.d_rel), None, None, 0, 0, st), "dns_encode_bwd")
         bwd(None, 0, self.d_featx[:, 3:3 + self.hid + 1], self.w_coarse, self.shp_c, None, 1)
         check(lib.dns_encode_bwd(ptr(self.x3), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.d_buf), ld,
                                  _V(self.d_buf.data_ptr() + 4 * pe), ld, None, ptr(self.d_x3), ptr(self.dydx), None, 0, 0, st),
               "dns_encode_bwd")
+        if self.stem:
+            check(lib.dns_add_ref_sum(ptr(self.d_rel), self.R, P, P, ptr(self.d_x3), st), "dns_add_ref_sum")
         check(lib.dns_raygen_bwd(ptr(pix), ptr(self.Q), self.camv, b, H - b, b, W - b, 1, N, S, ptr(self.z), ptr(self.d_x3), None,
                                  None, ptr(self.ray_ws), ptr(self.g_quat), ptr(self.g_trans), st), "dns_raygen_bwd")
         check(lib.dns_adam_step(self.adam_items, 2, self.betas[0], self.betas[1], self.eps, ptr(self.adam_state), st),

@@ -239,6 +239,7 @@ MLP_SAVE_HIDDEN = False
 MLP_FP16_FLAG = 0x100                      # include/dns_hip.h DNS_MLP_FP16
 MLP_PREPARED_FLAG = 0x200                  # include/dns_hip.h DNS_MLP_PREPARED
 MLP_NO_DWIN_FLAG = 0x400                   # include/dns_hip.h DNS_MLP_NO_DWIN
+MLP_DX_FIRST_FLAG = 0x800                  # include/dns_hip.h DNS_MLP_DX_FIRST
 
 
 class _MlpFn(torch.autograd.Function):

@@ -156,25 +156,28 @@ class Tracker:
                 p.requires_grad_(True)
 
     # slams/tracking.py:313-340
-    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None, fused=False, graph=False, graph_warmup=0):
+    def track_frame(self, cur_frames, est_c2w, n_iters=None, features=None, fused=False, graph=False, graph_warmup=0,
+                    refer_frames=None):
         """Optimise (quat, T) of one frame against the frozen scene; returns the best-loss camera tensor [7].
         ``graph=True`` captures ONE iteration (sampling, render, losses, backward, fused Adam, keep-best) into a hipGraph
         and replays it n_iters times: tracking is 30-50 tiny latency-bound iterations per frame."""
         n_iters = self.n_iters if n_iters is None else n_iters
-        if getattr(self, "use_track_step", False) and (features is None or features.dim() == 3):
+        if getattr(self, "use_track_step", False) and (features is None or features.dim() == 3 or refer_frames is not None):
             # the same loop as a fixed launch sequence over preallocated buffers (no autograd graph; draws on the device
-            # generator like static_shapes); graph=True replays one captured iteration
+            # generator like static_shapes); graph=True replays one captured iteration.  `fused` / `graph_warmup` do not apply
+            # (Adam is the library's own kernel, a capture needs no warm-up); there is no torch optimizer object afterwards
             from .fused_step import TrackStep
-            ts = TrackStep(self, cur_frames, est_c2w, features=features)
+            ts = TrackStep(self, cur_frames, est_c2w, features=features, refer_frames=refer_frames)
             cam, best = ts.run(n_iters, graph=graph)
             self.last_track_step = ts
+            self.last_optimizer = None
             return cam, best
         with self.frozen_scene():
             if graph:
-                return self._track_frame_graphed(cur_frames, est_c2w, n_iters, features, graph_warmup)
-            return self._track_frame_eager(cur_frames, est_c2w, n_iters, features, fused)
+                return self._track_frame_graphed(cur_frames, est_c2w, n_iters, features, graph_warmup, refer_frames)
+            return self._track_frame_eager(cur_frames, est_c2w, n_iters, features, fused, refer_frames)
 
-    def _track_frame_eager(self, cur_frames, est_c2w, n_iters, features, fused):
+    def _track_frame_eager(self, cur_frames, est_c2w, n_iters, features, fused, refer_frames=None):
         optimizer, quad, T = self.set_optimizer(est_c2w, fused=fused)
         frames = dict(cur_frames)
         frames["est_quad"], frames["est_T"] = quad, T
@@ -183,7 +186,7 @@ class Tracker:
         best_cam = torch.cat((quad, T), 0).detach().clone()
         for _ in range(n_iters):
             optimizer.zero_grad()
-            samples = self.get_target_samples(frames, features=features, prep=prep)
+            samples = self.get_target_samples(frames, refer_frames=refer_frames, features=features, prep=prep)
             pred_color, pred_depth, pred_depth_var, pred_logits = self.renderer(samples)
             loss, _terms = ops.tracking_losses(pred_color, pred_depth, pred_depth_var, pred_logits, samples["gt_color"],
                                                samples["gt_depth"], samples["gt_label"], samples["mask"],
@@ -197,7 +200,7 @@ class Tracker:
         self.last_optimizer = optimizer
         return best_cam, best_loss
 
-    def _track_frame_graphed(self, cur_frames, est_c2w, n_iters, features, warmup=0):
+    def _track_frame_graphed(self, cur_frames, est_c2w, n_iters, features, warmup=0, refer_frames=None):
         from ._lib import ensure_init
         ensure_init()                                    # kernel attributes are set outside the capture (dns_init)
         self.static_shapes = True
@@ -210,7 +213,7 @@ class Tracker:
 
         def one_iter():
             optimizer.zero_grad(set_to_none=True)
-            samples = self.get_target_samples(frames, features=features, prep=prep)
+            samples = self.get_target_samples(frames, refer_frames=refer_frames, features=features, prep=prep)
             pc, pd, pv, pl = self.renderer(samples)
             loss, _ = ops.tracking_losses(pc, pd, pv, pl, samples["gt_color"], samples["gt_depth"], samples["gt_label"],
                                           samples["mask"], (self.lambda_p, self.lambda_d, self.lambda_l))

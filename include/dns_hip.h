@@ -223,6 +223,10 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * slot arguments -- possibly on ANOTHER stream: it is memory-bound and independent of everything that follows in the
  * backward pass except d_params, so it runs beside the next network's (vector-bound) backward kernel (fused_step.MapStep). */
 #define DNS_MLP_NO_DWIN 0x400u
+/* DNS_MLP_DX_FIRST (bit 11 of accumulate_dx of dns_mlp_bwd, two-segment input only): only d_x -- the gradient of input columns
+ * [0, n_in1) -- is produced; d_x2 may be NULL and the products of the second segment's columns are skipped (Decoder.merge: the
+ * OneBlob columns carry the pose gradient, the looked-up image code has none, models/decoder.py:70-74). */
+#define DNS_MLP_DX_FIRST 0x800u
 int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                  uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
                  const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);
@@ -376,7 +380,7 @@ int dns_class_slots(const int64_t* labels, uint32_t N, uint32_t S, int tiled, co
 int dns_feature_block(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C, const float* z,
                       const float* gt_depth, uint32_t N, uint32_t S, float* feat, uint32_t ld_feat, float* raw, void* stream);
 /* dns_feature_block with the block written in the split-row format (above; ABI v9): xs_out [P, ldxs] halfs (hidden + C values
- * per row), xexp [P]; feat (NULL = skip) additionally receives the fp32 block.  n_ref > 1: code is [n_frames][n_ref]
+ * per row), xexp [P] (xs_out NULL: the fp32 block only); feat (NULL = skip) receives the fp32 block.  n_ref > 1: code is [n_frames][n_ref]
  * [pts_per_frame][C] and the n_ref slabs of a point are AVERAGED before the truncation mask -- the mean over the reference frames
  * of Decoder.merge's latents (models/decoder.py:76, utils/common.py:677).  max(hidden, C) / 4 must be a power of two <= 16. */
 int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint32_t hidden, const float* code, uint32_t C, uint32_t n_ref,
@@ -412,6 +416,28 @@ int dns_force_half(float* t, uint32_t n, uint32_t idx, void* stream);
  * the rounded projected full-resolution pixel, zero where the projection is invalid; mask [R,P] uint8 (NULL = skip). */
 int dns_feature_gather(const float* pts, const float* w2c, const float* K, const float* feat, uint32_t R, uint32_t P,
                        uint32_t C, int h, int w, int H, int W, float* code, uint8_t* mask, void* stream);
+
+/* The same lookup for the K target frames of one optimise iteration in ONE launch (slams/mapping.py:532-551 per target frame,
+ * slams/tracking.py:162-165; ABI v9): reference rr = f R + r (R views per frame) looks at the points of frame f: pts
+ * [n_frames, pts_per_frame, 3], w2c [n_frames R, 16], feat [n_frames R, h, w, C] channels last.  code row (rr, p) starts at
+ * code + (rr pts_per_frame + p) ld_code -- e.g. column 3 n_bins of the Merge network's input rows -- and rel_out (NULL = skip)
+ * [n_frames R, pts_per_frame, 3] receives pts - origin[rr] (refer_p, utils/common.py:675), origin [n_frames R, 3].
+ * dns_refer_poses: the w2c / origin of those views: src[rr] >= 0 takes target frame src[rr]'s pose as it stands in the optimiser
+ * (quat [K,4] (w,x,y,z), trans [K,3]; get_rotation_from_quad, detached: slams/mapping.py:537-543), src[rr] < 0 the stored pose
+ * fixed_c2w[rr] [16] (:545); w2c = its inverse (torch.inverse, :547).
+ * dns_merge_dy: backward of (mean over the R views, truncation mask) -- d_lat [n_frames, R, pts_per_frame, C] = d_code[p] *
+ * trunc(p) / R for every view (models/decoder.py:76, slams/mapping.py:553-557); d_code [P, ld_dcode] (the first C columns of each
+ * row) is CLEARED afterwards: the colour / logit networks add their input gradients into it every iteration.
+ * dns_add_ref_sum: d_pts [P,3] += sum over the R views of d_rel [n_frames, R, pts_per_frame, 3] (the points' share of Merge's
+ * gradient, through refer_p = pts - refer_o). */
+int dns_feature_gather_frames(const float* pts, const float* w2c, const float* origin, const float* K, const float* feat,
+                              uint32_t n_frames, uint32_t R, uint32_t pts_per_frame, uint32_t C, int h, int w, int H, int W,
+                              float* code, uint32_t ld_code, float* rel_out, void* stream);
+int dns_refer_poses(const float* quat, const float* trans, const int32_t* src, const float* fixed_c2w, uint32_t n, float* w2c,
+                    float* origin, void* stream);
+int dns_merge_dy(float* d_code, uint32_t ld_dcode, uint32_t C, uint32_t R, uint32_t pts_per_frame, const float* z,
+                 const float* gt_depth, uint32_t N, uint32_t S, float* d_lat, void* stream);
+int dns_add_ref_sum(const float* d_rel, uint32_t R, uint32_t pts_per_frame, uint32_t P, float* d_pts, void* stream);
 
 #ifdef __cplusplus
 }
