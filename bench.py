@@ -146,7 +146,7 @@ def kernel_rooflines(spans, wl, steps, pmc):
     return rows
 
 
-def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None, fused_step=True):
+def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None, fused_step=True, stem_features=False):
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder
     from dns_slam_amd.mapping import Mapper
@@ -189,11 +189,27 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None,
         code = (torch.rand(4 * n_per_frame, wl["nu"] + wl["ns"], 32, generator=g) * 2 - 1).to(device)
 
     mapper.bench_code = code
-    if fused_step and not dist_ctx.union:
+    refer = None
+    if stem_features:
+        # the reference's REAL iteration: feature_matching + Decoder.merge inside every step (slams/mapping.py:532-557) on the
+        # frozen image stem's maps of three reference views per target frame (two keyframes + the frame itself, :399-419);
+        # stem = conv 7x7 / 2 + BN + ReLU of models/encoder.py:9-17 with random-init weights (no checkpoint offline), run ONCE
+        from dns_slam_amd.encoder import ResNet
+        frames = dict(frames)
+        frames["kf_idx"] = [0, 10, 20, 30]
+        refs = [[98, 99, -1], [0, 99, -1], [10, 0, -1], [20, 10, -1]]            # foreign keyframes keep their stored pose
+        src_of = lambda i, rid: i if rid == -1 else (frames["kf_idx"].index(rid) if rid in frames["kf_idx"] else (i + 1) % 4)
+        refer = {"kf_idx": refs,
+                 "gt_color": torch.stack([torch.stack([frames["gt_color"][src_of(i, r)] for r in refs[i]]) for i in range(4)]),
+                 "est_c2w": torch.stack([torch.stack([frames["est_c2w"][src_of(i, r)] for r in refs[i]]) for i in range(4)])}
+        stem = ResNet(seed=3).to(device)
+        code = stem(refer["gt_color"].to(device)).detach()                      # [4, 3, 64, H/2, W/2]
+    if fused_step:
         # the iteration as a fixed launch sequence over preallocated buffers (dns_slam_amd/fused_step.py): same kernels and
         # draws as the autograd-driven step below, without autograd's glue launches and host time
         from dns_slam_amd.fused_step import MapStep
-        ms = mapper.map_step = MapStep(mapper, frames, quad_list, T_list, prep=prep, features=code, lambda_lt=10.0, smooth=True)
+        ms = mapper.map_step = MapStep(mapper, frames, quad_list, T_list, prep=prep, features=code, lambda_lt=10.0, smooth=True,
+                                       refer_frames=refer)
 
         def step():
             ms.step()
@@ -206,7 +222,7 @@ def build(wl, device, seed, dist_ctx, overlap=False, graph=False, prefetch=None,
             buckets.zero()
         else:
             optimizer.zero_grad(set_to_none=True)
-        samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep, features=code)
+        samples = mapper.get_target_samples(frames, quad_list, T_list, prep=prep, features=code, refer_frames=refer)
         loss, terms = mapper.iteration_loss(samples, lambda_lt=10.0, smooth=True)
         loss.backward()
         if buckets is not None:
@@ -340,6 +356,9 @@ def main():
     ap.add_argument("--autograd-step", action="store_true",
                     help="drive the iteration through torch.autograd (Mapper.iteration_loss + backward + FusedAdam) instead of "
                          "the fixed launch sequence of dns_slam_amd/fused_step.py")
+    ap.add_argument("--stem-features", action="store_true",
+                    help="run the 2-D feature branch INSIDE every iteration (feature_matching + Decoder.merge on stem feature maps of 3 "
+                         "reference views per target frame, slams/mapping.py:532-557) instead of a precomputed per-sample code")
     ap.add_argument("--union-batch", action="store_true",
                     help="N>1: the N ranks share ONE batch of the configured size (shared-seed draws, rank slices of the rays and "
                          "of the smoothness lattice; strong scaling) instead of one batch per rank (weak scaling, the default)")
@@ -369,7 +388,7 @@ def main():
     overlap = (not use_graph or args.graph_branches) and not args.no_overlap
     union = ctx.union
     cfg, bound, cam, frames, mapper, step = build(wl, device, seed=100 + (0 if union else ctx.rank), dist_ctx=ctx, overlap=overlap,
-                                                  graph=use_graph, fused_step=not args.autograd_step)
+                                                  graph=use_graph, fused_step=not args.autograd_step, stem_features=args.stem_features)
     n_rays = 4 * sum(wl["rays"])
     job_rays = n_rays if union else n_rays * ctx.world_size          # rays the whole job renders per step
     S = wl["nu"] + wl["ns"]
@@ -535,7 +554,8 @@ def main():
                   "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "launch_mode": "hipGraph replay" if graphed else "eager",
         "step_driver": "fixed launch sequence (fused_step.MapStep)" if getattr(mapper, "map_step", None) is not None else "torch.autograd",
         "launch_trial_ms": trial, "final_loss": final_loss,
-        "config": {"workload": args.workload + ": " + wl["desc"], "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,
+        "config": {"workload": args.workload + ": " + wl["desc"] + (" -- with --stem-features: the 2-D branch (feature_matching + "
+                                "Decoder.merge on 3 reference views per target frame) runs inside every iteration" if args.stem_features else ""), "rays_per_gpu": job_rays // ctx.world_size, "samples_per_ray": S,
                    "global_rays": job_rays,
                    "parallelism": f"dp{ctx.world_size} (" + ("strong: union batch -- rank slices of ONE shared-seed batch of "
                                                               f"{n_rays} rays and of the lattice" if union else

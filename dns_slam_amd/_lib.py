@@ -76,7 +76,7 @@ SIGNATURES = {
     "dns_feature_block": (C.c_int, [_P, _U, _U, _P, _U, _P, _P, _U, _U, _P, _U, _P, _P]),
     "dns_rgb_sigmoid": (C.c_int, [_P, _U, _P]),
     "dns_raw_bwd": (C.c_int, [_P, _P, _U, _P, _P, _U, _I, _P]),
-    "dns_lattice_points": (C.c_int, [_P, _P, _U, _P, _P, _P]),
+    "dns_lattice_points": (C.c_int, [_P, _P, _U, _P, _U, _P, _P]),
     "dns_draw_finish": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _U, _U, _P, _P, _P, _P]),
     "dns_track_mask": (C.c_int, [_P, _P, _U, C.c_float, _P, _P]),
     "dns_keep_best": (C.c_int, [_P, _P, _P, _P, _P, _P]),

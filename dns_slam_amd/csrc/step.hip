@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void raw_bwd_kernel(const float4* __restrict__
 // coordinates of the smoothness lattice (slams/mapping.py:133-143 folded to one affine map, Mapper.smoothness)
 struct LatticeConsts { double vox[3], off[3], mar[3]; };
 __global__ __launch_bounds__(256) void lattice_points_kernel(const float* __restrict__ r6, LatticeConsts c, uint32_t n,
-                                                             const int32_t* __restrict__ order, float* __restrict__ pts) {
-  const uint32_t total = n * n * n;
+                                                             const int32_t* __restrict__ order, uint32_t total,
+                                                             float* __restrict__ pts) {
   double b[3];
   for (int a = 0; a < 3; ++a) {
     const double t = c.mar[a] + (double)r6[a] * c.off[a];          // addcmul, then addcmul: two rounded steps each
@@ -323,14 +323,17 @@ extern "C" int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, flo
   return check_launch("dns_raw_bwd");
 }
 
-extern "C" int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, const int32_t* order, float* pts, void* stream) {
+extern "C" int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, const int32_t* order, uint32_t count,
+                                  float* pts, void* stream) {
   if (n == 0) return DNS_OK;
   DNS_REQUIRE(r6 && consts9 && pts, "dns_lattice_points: NULL argument");
   DNS_REQUIRE((uint64_t)n * n * n < (1ull << 30), "dns_lattice_points: lattice too large");
+  const uint32_t total = count ? count : n * n * n;
+  DNS_REQUIRE(total <= n * n * n && (count == 0 || order), "dns_lattice_points: count needs an element list of at most n^3 entries");
   LatticeConsts c;
   for (int a = 0; a < 3; ++a) { c.vox[a] = consts9[a]; c.off[a] = consts9[3 + a]; c.mar[a] = consts9[6 + a]; }
   hipStream_t st = (hipStream_t)stream;
-  DNS_LAUNCH(lattice_points_kernel, dim3(grid_for((uint64_t)n * n * n)), dim3(256), 0, st, r6, c, n, order, pts);
+  DNS_LAUNCH(lattice_points_kernel, dim3(grid_for((uint64_t)total)), dim3(256), 0, st, r6, c, n, order, total, pts);
   return check_launch("dns_lattice_points");
 }
 

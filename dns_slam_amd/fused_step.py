@@ -53,8 +53,6 @@ class MapStep:
             raise ValueError("dns_slam_amd ops run on the GPU only; there is no CPU fallback")
         if not (m.static_shapes and m.fused_losses):
             raise ValueError("MapStep needs mapper.static_shapes and mapper.fused_losses (the sync-free iteration)")
-        if m.dist is not None and m.dist.union:
-            raise ValueError("MapStep: union-batch mode runs through the autograd path")
         # features: None | the per-sample code [N, S, C] | the stem feature maps [n_target, n_refer, C, h, w] of the reference
         # views (+ refer_frames): then the 2-D branch of slams/mapping.py:532-557 -- feature_matching + Decoder.merge -- runs
         # INSIDE every step, forward and backward (Merge's weights train, its OneBlob input carries pose gradient)
@@ -65,9 +63,18 @@ class MapStep:
             raise ValueError("MapStep: stem feature maps need refer_frames (kf_idx, est_c2w)")
         self.dist_on = m.dist is not None and m.dist.enabled       # (a forced one-rank group counts: tests drive RCCL that way)
         self.world = m.dist.world_size if self.dist_on else 1
+        # union-batch mode (dist.py, SURVEY 8e's partitioning): every rank draws the SAME lists; this rank renders rays [a, b) of
+        # every frame's list and x-planes [a_l, b_l) (+ one halo plane) of the ONE smoothness lattice
+        self.union = self.dist_on and m.dist.union
         self.frames = target_frames
         self.prep = prep if prep is not None else m.prepare_frames(target_frames)
+        self.npf_g = self.prep["n1"] + self.prep["n2"]                     # rays per frame of the whole (drawn) list
+        self.ray_a, self.ray_b = m.dist.shard(self.npf_g) if self.union else (0, self.npf_g)
         self.features = None if (features is None or self.stem) else features.to(dev).float().contiguous()
+        if self.features is not None and self.union:                        # the code of the rank's rays
+            K_ = m.n_target_frame
+            fs = self.features
+            self.features = fs.reshape(K_, self.npf_g, *fs.shape[1:])[:, self.ray_a:self.ray_b].reshape(-1, *fs.shape[1:]).contiguous()
         self.lambda_lt, self.smooth = float(lambda_lt), bool(smooth)
         self.betas, self.eps = betas, eps
         K = self.K = m.n_target_frame
@@ -142,7 +149,7 @@ class MapStep:
             return arr
 
         # ---- ray-branch buffers
-        npf = self.npf = self.prep["n1"] + self.prep["n2"]
+        npf = self.npf = self.ray_b - self.ray_a
         nu = 0 if m.t_uniform is None else m.t_uniform.numel()
         ns = m.n_surface_ray
         N, S = K * npf, nu + ns
@@ -272,7 +279,10 @@ class MapStep:
             sp = self.sp = tr["smooth_pts"]
             m._ensure_lattice(sp, 0.1, 0.05)
             n = self.n_lat = sp - 1
-            Pl = self.Pl = n ** 3
+            la, lb = m.dist.shard(n) if self.union else (0, n)
+            lhi = min(lb + 1, n)                                          # + the next slab's first plane (halo: closes the x-differences)
+            self.lat_nx, self.lat_halo = lhi - la, 1 if lhi > lb else 0
+            Pl = self.Pl = self.lat_nx * n * n
             self.bufl, self.occ, self.d_occ, self.d_bufl = f(Pl, ld), f(Pl, 1), f(Pl, 1), f(Pl, ld)
             if self.sr:
                 np_ = self.sr_planes
@@ -284,7 +294,8 @@ class MapStep:
             # 63^3; x-major rows walk the z axis and touch new lines of every fine level at every step).  The scatter does not
             # care (249 -> 256 us).  lat_slot = the inverse map (row of element e).
             ar = torch.arange(n, device=dev)
-            ii, jj, kk = torch.meshgrid(ar, ar, ar, indexing="ij")
+            ii, jj, kk = torch.meshgrid(ar[la:lhi], ar, ar, indexing="ij")      # the rank's x-planes (the whole cube without union mode)
+            elem = (ii * (n * n) + jj * n + kk).reshape(-1)                      # x-major index of every element of the slab
 
             def spread(v):                          # bits of v to every third position (10 bits)
                 v = v & 0x3ff
@@ -294,15 +305,17 @@ class MapStep:
                 return (v | (v << 2)) & 0x9249249
 
             code = spread(ii.reshape(-1)) | (spread(jj.reshape(-1)) << 1) | (spread(kk.reshape(-1)) << 2)
-            self.lat_order_l = torch.argsort(code).contiguous()                 # int64, for index_select
-            self.lat_order = self.lat_order_l.to(torch.int32).contiguous()
+            self.lat_order_l = torch.argsort(code).contiguous()                 # int64, for index_select: row m = slab element [m]
+            self.lat_order = elem[self.lat_order_l].to(torch.int32).contiguous()  # ... as x-major index in the CUBE (the kernel's input)
             self.lat_slot = torch.empty_like(self.lat_order_l)
             self.lat_slot[self.lat_order_l] = torch.arange(Pl, device=dev)
             self.occ_x, self.d_occ_x = f(Pl, 1), f(Pl, 1)
             _, c_vox, c_off, c_mar = m._lattice_consts                    # float64 [3] each, on the device: read once
             self.lat_consts = (C.c_double * 9)(*[float(v) for t in (c_vox, c_off, c_mar) for v in t.cpu().tolist()])
             self.tv = f(1)
-            self.w_sm = torch.full((1,), m.lambda_sm / self.world, device=dev)
+            # gradients are SUMMED over the ranks: weak mode averages the ranks' own lattices (1 / world each), union mode adds
+            # up the slabs of one lattice
+            self.w_sm = torch.full((1,), m.lambda_sm if self.union else m.lambda_sm / self.world, device=dev)
             self.ws_mlp_l = mlp_ws(Pl, self.shp_c)
             self.h_l = f(self.shp_c[3] * Pl * self.shp_c[2]) if self.keep_h_lat else None
             self.ws_enc_l = enc_ws(Pl)
@@ -318,7 +331,7 @@ class MapStep:
         lib = ops.lib
         Pl, ld, pe = self.Pl, self.ld, self.pe_dim
         pts = self.pts_l
-        check(lib.dns_lattice_points(ptr(cur.draws["r6"]), self.lat_consts, self.n_lat, ptr(self.lat_order), ptr(pts), st),
+        check(lib.dns_lattice_points(ptr(cur.draws["r6"]), self.lat_consts, self.n_lat, ptr(self.lat_order), Pl, ptr(pts), st),
               "dns_lattice_points")
         meta = C.byref(self.meta.c)
         grid_l = _V(self.bufl.data_ptr() + 4 * pe)
@@ -336,8 +349,8 @@ class MapStep:
         # the branch runs in MORTON order of the lattice elements (see __init__); the TV kernels want the x-major cube: two 1 MB
         # permutations (the network's occupancy out, its gradient back in)
         torch.index_select(self.occ, 0, self.lat_slot, out=self.occ_x)
-        check(lib.dns_tv_fwd(ptr(self.occ_x), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.tv), st), "dns_tv_fwd")
-        check(lib.dns_tv_bwd(ptr(self.occ_x), 1, self.n_lat, self.n_lat, 0, self.sp, ptr(self.w_sm), ptr(self.d_occ_x), st),
+        check(lib.dns_tv_fwd(ptr(self.occ_x), 1, self.lat_nx, self.n_lat, self.lat_halo, self.sp, ptr(self.tv), st), "dns_tv_fwd")
+        check(lib.dns_tv_bwd(ptr(self.occ_x), 1, self.lat_nx, self.n_lat, self.lat_halo, self.sp, ptr(self.w_sm), ptr(self.d_occ_x), st),
               "dns_tv_bwd")
         torch.index_select(self.d_occ_x, 0, self.lat_order_l, out=self.d_occ)
         if self.sr:
@@ -362,6 +375,7 @@ class MapStep:
         every sample to its class's decoder (slams/mapping.py:590-601,613) and the zero fills of what the step adds into."""
         m, lib = self.m, ops.lib
         K, npf, N, S, P = self.K, self.npf, self.N, self.S, self.P
+        npf_g = self.npf_g                                              # the drawn list (all ranks' rays in union mode)
         prep = self.prep
         if draws is None:
             # Mapper._draw_all's generator calls in its order (pixels: randint then float64 rand; jitter; lattice), the index
@@ -369,25 +383,39 @@ class MapStep:
             n1, n2 = prep["n1"], prep["n2"]
             i1 = torch.randint(prep["HW"], (K, n1), device=self.dev)
             u = torch.rand(K, n2, device=self.dev, dtype=torch.float64)
-            pix = torch.empty(K * npf, device=self.dev, dtype=torch.int64)
-            labels = torch.empty(K * npf, device=self.dev, dtype=torch.int64)
+            pix = torch.empty(K * npf_g, device=self.dev, dtype=torch.int64)
+            labels = torch.empty(K * npf_g, device=self.dev, dtype=torch.int64)
             dmax = torch.empty(K, device=self.dev, dtype=torch.int32)
             check(lib.dns_draw_finish(ptr(i1), ptr(u), ptr(prep["counts_f64"]), ptr(prep["counts_m1"]), ptr(prep["starts_flat"]),
                                       ptr(prep["sorted_flat"]), ptr(prep["depth"]), ptr(prep["label"]), K, n1, n2, prep["HW"],
                                       ptr(pix), ptr(labels), ptr(dmax), stream), "dns_draw_finish")
             d = {"pix": pix, "jitter": m.draw_jitter(), "r6": torch.rand(6, device=self.dev) if self.smooth else None}
         else:                                          # given draws (tests): the same quantities with torch ops
-            d = draws
-            pix2 = d["pix"].reshape(K, npf)
+            d = dict(draws)                                # ('pix' = the WHOLE drawn list in union mode, like the generator's)
+            pix2 = d["pix"].reshape(K, npf_g)
             dmax = torch.gather(prep["depth"].reshape(K, -1), 1, pix2).amax(dim=1).clamp_min(0.0).float().contiguous().view(torch.int32)
             labels = torch.gather(prep["label"].reshape(K, -1), 1, pix2).reshape(-1).long()      # = the gt_label raygen writes
+        tiled = m.label_layout == "reference_tiled"
+        n_lab, s_lab = N, S
+        if self.union:
+            # every rank holds the whole list: the per-frame depth maximum (utils/common.py:581,591) needs no collective; the rank
+            # renders rays [a, b) of every frame; under the reference's tiled label layout (slams/mapping.py:613) point
+            # k of the WHOLE batch is routed by labels[k mod N_whole] -- a function of the global index (dist.union_point_labels)
+            m._check_same_draws(d["pix"].reshape(K, npf_g))
+            a, b = self.ray_a, self.ray_b
+            d["pix"] = d["pix"].reshape(K, npf_g)[:, a:b].reshape(-1).contiguous()
+            if tiled:
+                from .dist import union_point_labels
+                labels, n_lab, s_lab, tiled = union_point_labels(labels, K, npf_g, a, b, S).contiguous(), P, 1, False
+            else:
+                labels = labels.reshape(K, npf_g)[:, a:b].reshape(-1).contiguous()
         st_.draws = d
-        if self.dist_on:
+        if self.dist_on and not self.union:
             fmax = dmax.view(torch.float32)
             m.dist.allreduce_max(fmax)                  # in place on the same storage
         st_.dmax = dmax                                 # bit patterns, as dns_raygen_sample takes them
         lut = m.fine_decoders.lut(0)                                       # class id -> pool row; :613 tiles the labels
-        check(lib.dns_class_slots(ptr(labels), N, S, 1 if m.label_layout == "reference_tiled" else 0, ptr(lut), lut.numel(),
+        check(lib.dns_class_slots(ptr(labels), n_lab, s_lab, 1 if tiled else 0, ptr(lut), lut.numel(),
                                   ptr(self.slot), stream), "dns_class_slots")
         check(lib.dns_group_slots(ptr(self.slot), P, self.n_groups, 2, self.n_slots, ptr(self.group_ws), ptr(st_.row_index),
                                   ptr(st_.tile_group), stream), "dns_group_slots")

@@ -928,8 +928,7 @@ class Mapper:
         terms = {}
         lt_of = lambda it: (10 if it > n_iters // 2 else 0) if len(new_decoder_idx) > 0 else 10
         if getattr(self, "use_map_step", False) and self.static_shapes and self.fused_losses and \
-                (features is None or features.dim() == 3 or refer_frames is not None) and \
-                not (self.dist is not None and self.dist.union):
+                (features is None or features.dim() == 3 or refer_frames is not None):
             # the same iterations as the loop below as a fixed launch sequence over preallocated buffers (fused_step.MapStep:
             # no autograd graph, draws and routing prepared a step ahead on the side stream); Adam state lives in the MapStep
             from .fused_step import MapStep

@@ -372,7 +372,8 @@ int dns_group_scatter(const int64_t* slot_of_point, uint32_t P, uint32_t n_group
  *   d_occ[p * ld_occ] = (accumulate ? += : =) d_raw[p, 3].
  * dns_lattice_points: normalised coordinates of the n^3 smoothness lattice (slams/mapping.py:133-143 as one float64 affine
  *   map): pts[i,j,k] = float(mar + r6[0:3] * off + r6[3:6] * vox + (i,j,k) * vox); consts9 [host, 9 doubles] = vox, off, mar;
- *   r6 [device, 6 floats] = the offset and jitter draws.  order (NULL = x-major): output row m holds lattice element order[m]
+ *   r6 [device, 6 floats] = the offset and jitter draws.  order (NULL = x-major): output row m holds lattice element order[m];
+ *   count (0 = n^3): the number of rows / entries of order -- a rank's slab of x-planes of the ONE lattice in union-batch mode
  *   (x-major index i n^2 + j n + k) -- a Morton order of the elements makes the hash-grid gather of the lattice 2.3x faster
  *   (neighbouring rows share table lines: 112 -> 49 us at 63^3), the caller maps the network's output back for the TV kernel. */
 int dns_class_slots(const int64_t* labels, uint32_t N, uint32_t S, int tiled, const int64_t* lut, uint32_t n_lut,
@@ -389,7 +390,8 @@ int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint32_t hidden
 int dns_rgb_sigmoid(float* raw, uint32_t P, void* stream);
 int dns_raw_bwd(const float* d_raw, const float* raw, uint32_t P, float* d_col, float* d_occ, uint32_t ld_occ, int accumulate,
                 void* stream);
-int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, const int32_t* order, float* pts, void* stream);
+int dns_lattice_points(const float* r6, const double* consts9, uint32_t n, const int32_t* order, uint32_t count, float* pts,
+                       void* stream);
 /* dns_draw_finish: the index arithmetic behind one iteration's pixel draws for all K frames (select_uv + select_by_class,
  * utils/common.py:274,313-328) plus what follows from the drawn pixels alone.  The RANDOM NUMBERS come from the caller's
  * generator: i1 [K, n1] int64 uniform picks in [0, HW), u [K, n2] float64 in [0, 1).  Per frame f: pix[f, 0:n1] = i1[f],

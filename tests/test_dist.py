@@ -263,26 +263,38 @@ def _map_step_grads(ms):
     return [g.detach().cpu().clone() for g in (ms.g_table, ms.g_coarse, ms.g_color, ms.g_logit, ms.g_pool, ms.g_quat[4:], ms.g_trans[3:])]
 
 
-def _map_step_worker(rank, world, port, q):
+def _map_step_worker(rank, world, port, q, mode="weak"):
     from dns_slam_amd.fused_step import MapStep
     ctx = _init(rank, world, port)
-    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "per_ray")
+    ctx.mode = mode
+    union = mode == "union"
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "reference_tiled" if union else "per_ray")
     mapper.dist = ctx
     mapper.overlap_smooth = True
     part = npf // world
-    mapper.rays_per_frame = (part, 0)                      # the buffers are sized for this rank's share
-    prep = mapper.prepare_frames(frames)
-    ms = MapStep(mapper, frames, ql, Tl, prep=prep)
-    shard = torch.cat([pix[f * npf + rank * part: f * npf + (rank + 1) * part] for f in range(4)])
+    g = torch.Generator().manual_seed(8)
+    code = (torch.rand(4 * npf, 32 + 15, 32, generator=g) * 2 - 1).to("cuda:0") if union else None
+    if union:
+        # union-batch mode: every rank is handed the WHOLE list (what a shared seed gives) and takes its slice of the rays, of the
+        # per-sample code and of the lattice (slab + halo plane); the reference's tiled labels route by the GLOBAL point index
+        ms = MapStep(mapper, frames, ql, Tl, prep=prep, features=code)
+        assert ms.union and ms.N == 4 * (ms.ray_b - ms.ray_a) and ms.Pl < (10 - 1) ** 3
+        shard = pix
+    else:
+        mapper.rays_per_frame = (part, 0)                  # the buffers are sized for this rank's share
+        prep = mapper.prepare_frames(frames)
+        ms = MapStep(mapper, frames, ql, Tl, prep=prep)
+        shard = torch.cat([pix[f * npf + rank * part: f * npf + (rank + 1) * part] for f in range(4)])
     r6 = torch.cat((u[0].reshape(-1), u[1].reshape(-1))).to("cuda:0")
     ms.step(draws={"pix": shard, "jitter": jit, "r6": r6})
     torch.cuda.synchronize()
     first = [g.numpy() for g in _map_step_grads(ms)] + [ms.out.cpu().numpy()]
-    # then free-running steps, every rank on its own draws (per-rank seed), the next step's set prepared on the side stream
-    # (its MAX all-reduce of the depth maxima is issued from there): the replicas must stay bit-identical
+    # then free-running steps, every rank on its own draws (per-rank seed; union mode: the SAME seed), the next step's set
+    # prepared on the side stream (weak mode: its MAX all-reduce of the depth maxima is issued from there): the replicas must
+    # stay bit-identical
     mapper.prefetch_draws = True
-    torch.manual_seed(100 + rank)
-    torch.cuda.manual_seed(100 + rank)
+    torch.manual_seed(100 + (0 if union else rank))
+    torch.cuda.manual_seed(100 + (0 if union else rank))
     for _ in range(3):
         ms.step()
     torch.cuda.synchronize()
@@ -297,26 +309,34 @@ def _map_step_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_map_step_rank_shards_equal_whole_batch_on_gpu():
-    """The fixed-launch-sequence iteration (fused_step.MapStep) under weak-mode data parallelism, 2 ranks over gloo on one GPU:
-    the all-reduced gradient buffer (early segment launched asynchronously after the MLP backward, late segment after the stream
-    join) and the loss terms (global numerators / denominators) equal the one-process step on the whole pixel list."""
+@pytest.mark.parametrize("world,mode", [(2, "weak"), (2, "union"), (3, "union")])
+def test_map_step_rank_shards_equal_whole_batch_on_gpu(world, mode):
+    """The fixed-launch-sequence iteration (fused_step.MapStep) under data parallelism, ranks over gloo on one GPU: the
+    all-reduced gradient buffer (early segment launched asynchronously after the MLP backward, late segment after the stream join)
+    and the loss terms (global numerators / denominators) equal the one-process step on the whole pixel list.  weak: explicit
+    shards, per_ray labels; union (SURVEY 8e's partitioning): shared draws, rank slices of the rays (ragged with 3 ranks) and of
+    the per-sample code, lattice slabs + halo planes, the reference's tiled labels."""
     from dns_slam_amd.fused_step import MapStep
-    world = 2
     port = _free_port()
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_map_step_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctxm.Process(target=_map_step_worker, args=(r, world, port, q, mode)) for r in range(world)]
     [p.start() for p in procs]
     got = [torch.from_numpy(a) for a in q.get(timeout=300)]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "per_ray")
+    union = mode == "union"
+    frames, dec, mapper, ql, Tl, prep, pix, jit, u, npf = _gpu_setup("cuda:0", "reference_tiled" if union else "per_ray")
     part = npf // world
-    mapper.rays_per_frame = (world * part, 0)
-    prep = mapper.prepare_frames(frames)
-    ms = MapStep(mapper, frames, ql, Tl, prep=prep)
-    whole = torch.cat([pix[f * npf: f * npf + world * part] for f in range(4)])
+    code = None
+    if union:
+        g = torch.Generator().manual_seed(8)
+        code = (torch.rand(4 * npf, 32 + 15, 32, generator=g) * 2 - 1).to("cuda:0")
+    else:
+        mapper.rays_per_frame = (world * part, 0)
+        prep = mapper.prepare_frames(frames)
+    ms = MapStep(mapper, frames, ql, Tl, prep=prep, features=code)
+    whole = pix if union else torch.cat([pix[f * npf: f * npf + world * part] for f in range(4)])
     r6 = torch.cat((u[0].reshape(-1), u[1].reshape(-1))).to("cuda:0")
     ms.step(draws={"pix": whole, "jitter": jit, "r6": r6})
     torch.cuda.synchronize()

@@ -366,14 +366,18 @@ def test_lattice_points_equal_the_float64_affine_map():
     n = sp - 1
     got = torch.empty(n ** 3, 3, device=DEV)
     c9 = (c_double * 9)(*[float(v) for t in (c_vox, c_off, c_mar) for v in t.cpu().tolist()])
-    check(lib.dns_lattice_points(ptr(r), c9, n, None, ptr(got), stream_ptr()), "dns_lattice_points")
+    check(lib.dns_lattice_points(ptr(r), c9, n, None, 0, ptr(got), stream_ptr()), "dns_lattice_points")
     # float64 arithmetic rounded to float32 once: at most the last bit where torch contracts a multiply-add
     assert float((got - want).abs().max()) <= 6e-8 * float(want.abs().max())
     assert float((got != want).float().mean()) < 1e-3
     order = torch.randperm(n ** 3, device=DEV).to(torch.int32)            # any element order: row m = element order[m]
     got2 = torch.empty(n ** 3, 3, device=DEV)
-    check(lib.dns_lattice_points(ptr(r), c9, n, ptr(order), ptr(got2), stream_ptr()), "dns_lattice_points")
+    check(lib.dns_lattice_points(ptr(r), c9, n, ptr(order), 0, ptr(got2), stream_ptr()), "dns_lattice_points")
     assert torch.equal(got2, got[order.long()])
+    part = order[100:100 + 777].contiguous()                              # a sub-list (a rank's slab of the lattice): count rows
+    got3 = torch.full((777 + 5, 3), -7.0, device=DEV)
+    check(lib.dns_lattice_points(ptr(r), c9, n, ptr(part), 777, ptr(got3), stream_ptr()), "dns_lattice_points")
+    assert torch.equal(got3[:777], got[part.long()]) and bool((got3[777:] == -7.0).all())
 
 
 def test_draw_finish_equals_the_mapper_draw_arithmetic():
