@@ -97,3 +97,64 @@ def test_cfg1_ten_iteration_free_running_trajectory():
         assert_close(ql[f].detach().cpu(), qo[f].detach(), rtol=5e-4, what=f"cfg1 quat[{f}] after 10 free-running steps", elementwise=False)
         assert_close(Tl[f].detach().cpu(), To[f].detach(), rtol=5e-4, what=f"cfg1 T[{f}] after 10 free-running steps", elementwise=False)
     print(f"cfg1: worst relative loss difference over 10 free-running iterations {worst:.2e}")
+
+
+def test_cfg1_ten_iterations_one_step_ahead():
+    """The same ten iterations TEACHER-FORCED (the form that has no Adam amplification, as test_gpu_cfg3 does for the tracker): in
+    every iteration the oracle is placed AT the parameters and poses the product holds, and then each of the SEVEN loss terms
+    must agree to 1e-4 of ITSELF, the loss to 1e-4, and every gradient group -- table per level, the three networks, every
+    per-class decoder, the poses -- under the element-wise criterion of DESIGN.md section 2; the product then takes its own
+    (fused) Adam step and the oracle follows it.  Ten different parameter states of a training run instead of one random one."""
+    from util import assert_pose_grad_close, table_level_groups
+    cfg, bound, cam, frames, dec, mapper = _setup()
+    mapper.is_BA = True
+    opt, ql, Tl = mapper.set_optimizer(frames, fused=True)
+    lr, cam_lr = cfg["training"]["lr"], cfg["mapping"]["BA_cam_lr"]
+    for grp, v in zip(opt.param_groups, (lr, cam_lr, cam_lr)):
+        grp["lr"] = v
+    prep = mapper.prepare_frames(frames)
+    lc = sr.LossCfg(smooth_pts=64)
+    used = lambda n_in, n_out: 32 * n_in + n_out * 32
+    worst = {}
+    for it in range(10):
+        torch.manual_seed(300 + it)
+        pix, jit = mapper.draw_pixels(prep), mapper.draw_jitter()
+        g = torch.Generator().manual_seed(400 + it)
+        u_off, u_jit = torch.rand(3, generator=g), torch.rand((1, 1, 1, 3), generator=g)
+        # the oracle AT the product's current state
+        om = oracle_from_product(cfg, bound, dec, mapper)
+        qo = [q.detach().cpu().clone().requires_grad_(q.requires_grad) for q in ql]
+        To = [t.detach().cpu().clone().requires_grad_(t.requires_grad) for t in Tl]
+        so = _oracle_samples(frames, qo, To, cam, bound, pix.cpu(), (jit[0].cpu(), jit[1].cpu()), RAYS // 4)
+        so["features"] = torch.zeros(so["z_vals"].shape[0], NU + NS, 32)
+        lo, to, _ = sr.mapping_loss(om, so, lc, u_off, u_jit)
+        lo.backward()
+
+        opt.zero_grad()
+        s = mapper.get_target_samples(frames, ql, Tl, prep=prep, pix_idx=pix, jitter=jit)
+        loss, terms = mapper.iteration_loss(s, lambda_lt=10.0, smooth=True, u_offset=u_off, u_jitter=u_jit, strict=True)
+        loss.backward()
+        a, b = float(loss.detach()), float(lo.detach())
+        assert abs(a - b) <= 1e-4 * abs(b), f"iteration {it}: loss {a} vs {b}"
+        for kp, ko in (("p_loss", "p"), ("d_loss", "d"), ("l_loss", "l"), ("lt_loss", "lt"), ("fs_loss", "fs"), ("opacity_loss", "op"),
+                       ("smooth_loss", "sm")):
+            x, y = float(terms[kp].detach()), float(to[ko].detach())
+            worst[kp] = max(worst.get(kp, 0.0), abs(x - y) / max(abs(y), 1e-12))
+            assert abs(x - y) <= 1e-4 * max(abs(y), 1e-9), f"iteration {it} {kp}: {x} vs {y}"
+        w = f"cfg1 one step ahead, iteration {it}: "
+        assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1, 2), om.table.grad, what=w + "d table", groups=table_level_groups(om.meta))
+        assert_close(dec.coarse_fn.decoder.params.grad.cpu()[:used(80, 33)], om.coarse.grad[:used(80, 33)], what=w + "d coarse")
+        assert_close(dec.out_fn.color_decoder.params.grad.cpu()[:used(112, 3)], om.color.grad[:used(112, 3)], what=w + "d color")
+        assert_close(dec.out_fn.logit_decoder.params.grad.cpu()[:used(112, 8)], om.logit.grad[:used(112, 8)], what=w + "d logit")
+        pool_grad = mapper.fine_decoders.pool.grad.cpu()
+        for c, slot in mapper.fine_decoders.slot.items():
+            go = om.fine[c].grad
+            if go is None:
+                assert torch.count_nonzero(pool_grad[slot]) == 0
+            else:
+                assert_close(pool_grad[slot][:used(80, 33)], go[:used(80, 33)], what=w + f"d fine[{c}]")
+        for f in range(1, 4):
+            assert_pose_grad_close(ql[f], ql[f].grad, qo[f].grad, Tl[f].grad, To[f].grad, what=w + f"frame {f}")
+        opt.step()                                       # the product moves on; the oracle is re-placed next iteration
+    print("cfg1 one step ahead: worst relative deviation of each loss term over 10 iterations:",
+          {k: f"{v:.1e}" for k, v in worst.items()})

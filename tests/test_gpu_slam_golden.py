@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import assert_close, mlp_param_groups
+from util import assert_close, mlp_param_groups, table_level_groups
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -62,7 +62,9 @@ def test_mapper_renderer_and_gradients_equal_the_reference(ci, fused_nets):
     loss.backward()
     N, S, n_class, _ = (int(v) for v in G[p + "dims"])
     used = lambda n_in, n_out: 32 * n_in + n_out * 32                         # rows beyond n_out are storage only
-    assert_close(dec.pe_fn.grid_fn.params.grad.cpu(), T(G[p + "g_table"]), what=f"{p}d table", elementwise=False)
+    # element-wise, every entry against ITS level's scale (criterion 2)
+    assert_close(dec.pe_fn.grid_fn.params.grad.cpu().reshape(-1), T(G[p + "g_table"]).reshape(-1), what=f"{p}d table",
+                 groups=table_level_groups(dec.pe_fn.grid_fn.meta))
     for name, par, n_in, n_out in (("coarse", dec.coarse_fn.decoder.params, 80, 33), ("color", dec.out_fn.color_decoder.params, 112, 3),
                                    ("logit", dec.out_fn.logit_decoder.params, 112, n_class)):
         u = used(n_in, n_out)
@@ -74,7 +76,9 @@ def test_mapper_renderer_and_gradients_equal_the_reference(ci, fused_nets):
             assert torch.count_nonzero(pool_grad[slot]) == 0, c
         else:
             assert_close(pool_grad[slot][:used(80, 33)], want_g, what=f"{p}d fine[{c}]")
-    assert_close(s["pts"].grad.cpu(), T(G[p + "g_pts"]), what=f"{p}d pts", elementwise=False)
+    # d pts: element-wise too (|a - b| <= 1e-4 |b| + 1e-4 rms of the batch's point gradients)
+    gp = s["pts"].grad.cpu().reshape(-1, 3)
+    assert_close(gp, T(G[p + "g_pts"]).reshape(-1, 3), what=f"{p}d pts")
 
 
 @pytest.mark.parametrize("ci", range(int(G["n_cases"])))
@@ -96,4 +100,7 @@ def test_tracker_renderer_and_losses_equal_the_reference(ci):
         assert abs(float(got) - w) <= 1e-4 * max(abs(w), 1e-9), (k, float(got), w)
     loss = 5.0 * pl_ + 5.0 * dl_ + 0.1 * ll_
     loss.backward()
-    assert_close(s["pts"].grad.cpu(), T(G[p + "t_g_pts"]), what=f"{p}tracker d pts", elementwise=False)
+    # criterion 1 only (max |a - b| <= 1e-4 max |b|; measured 8.8e-6): the tracker's depth term is divided by sqrt(var + 1e-10)
+    # (slams/tracking.py:90), which spreads the point gradients of one batch over four decades -- a small entry is a sum of terms
+    # a thousand times its size, and an element-wise bound relative to the entry itself measures fp32 summation order, nothing else
+    assert_close(s["pts"].grad.cpu().reshape(-1, 3), T(G[p + "t_g_pts"]).reshape(-1, 3), what=f"{p}tracker d pts", elementwise=False)
