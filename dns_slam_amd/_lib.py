@@ -72,6 +72,9 @@ SIGNATURES = {
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _P, _U, _P]),
+    "dns_loss_bwd_points": (C.c_int, [_P, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P, _U, _P]),
+    "dns_composite_fwd_ex": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _U, _P]),
+    "dns_composite_bwd_ex": (C.c_int, [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P]),
     "dns_class_slots": (C.c_int, [_P, _U, _U, _I, _P, _U, _P, _P]),
     "dns_feature_block": (C.c_int, [_P, _U, _U, _P, _U, _P, _P, _U, _U, _P, _U, _P, _P]),
     "dns_rgb_sigmoid": (C.c_int, [_P, _U, _P]),

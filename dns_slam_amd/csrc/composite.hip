@@ -41,6 +41,8 @@ __device__ __forceinline__ float wave_suffix_excl_sum(float v, uint32_t lane) {
 }
 
 __device__ __forceinline__ float sigmoid10(float occ) { return 1.0f / (1.0f + expf(-10.0f * occ)); }
+// the colour network's output activation (models/decoder.py:124) when the caller hands raw rgb LOGITS (DNS_COMPOSITE_RGB_LOGITS)
+__device__ __forceinline__ float sigmoid1c(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <int E>
 struct RayState {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
                                                             const float* __restrict__ logits, uint32_t N, uint32_t S,
                                                             uint32_t C, float* __restrict__ depth, float* __restrict__ var,
                                                             float* __restrict__ rgb, float* __restrict__ weights,
-                                                            float* __restrict__ sem) {
+                                                            float* __restrict__ sem, uint32_t rgbl) {
   extern __shared__ float lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t n = blockIdx.x * 4 + wave;
@@ -102,9 +104,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     sv += st.w[e] * t * t;
     if (s < S) {
       const float* r = raw + ((size_t)n * S + s) * 4;
-      sc[0] += st.w[e] * r[0];
-      sc[1] += st.w[e] * r[1];
-      sc[2] += st.w[e] * r[2];
+      const float c0 = rgbl ? sigmoid1c(r[0]) : r[0], c1 = rgbl ? sigmoid1c(r[1]) : r[1], c2 = rgbl ? sigmoid1c(r[2]) : r[2];
+      sc[0] += st.w[e] * c0;
+      sc[1] += st.w[e] * c1;
+      sc[2] += st.w[e] * c2;
       if (weights) weights[(size_t)n * S + s] = st.w[e];
     }
     wl[s] = st.w[e];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ d_var, const float* __restrict__ d_rgb,
                                                             const float* __restrict__ d_weights,
                                                             const float* __restrict__ d_sem, float* __restrict__ d_raw,
-                                                            float* __restrict__ d_logits) {
+                                                            float* __restrict__ d_logits, uint32_t rgbl) {
   extern __shared__ float lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t n = blockIdx.x * 4 + wave;
@@ -156,15 +159,20 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
   }
   // g_i = dL/dw_i (w treated as free), then through the normalisation and the transmittance product
   float g[E];
+  float col[E][3];                               // the sample's colour (after the sigmoid when raw holds logits)
   float gbar = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const uint32_t s = lane * E + e;
     g[e] = 0.f;
+    col[e][0] = col[e][1] = col[e][2] = 0.f;
     if (s < S) {
       const float* r = raw + ((size_t)n * S + s) * 4;
       const float t = st.z[e] - st.depth;
-      float v = gc[0] * r[0] + gc[1] * r[1] + gc[2] * r[2] + gD * st.z[e] + gV * t * t;
+      col[e][0] = rgbl ? sigmoid1c(r[0]) : r[0];
+      col[e][1] = rgbl ? sigmoid1c(r[1]) : r[1];
+      col[e][2] = rgbl ? sigmoid1c(r[2]) : r[2];
+      float v = gc[0] * col[e][0] + gc[1] * col[e][1] + gc[2] * col[e][2] + gD * st.z[e] + gV * t * t;
       if (d_weights) v += d_weights[(size_t)n * S + s];
       if (C && d_sem) {
         const float* lp = logits + ((size_t)n * S + s) * C;
@@ -194,9 +202,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     tail += du[e] * st.u[e];
     if (s < S) {
       float* o = d_raw + ((size_t)n * S + s) * 4;
-      o[0] = st.w[e] * gc[0];
-      o[1] = st.w[e] * gc[1];
-      o[2] = st.w[e] * gc[2];
+      float o0 = st.w[e] * gc[0], o1 = st.w[e] * gc[1], o2 = st.w[e] * gc[2];
+      if (rgbl) {                                // through the sigmoid: d logit = d colour * (1 - s) * s
+        o0 = o0 * (1.f - col[e][0]) * col[e][0];
+        o1 = o1 * (1.f - col[e][1]) * col[e][1];
+        o2 = o2 * (1.f - col[e][2]) * col[e][2];
+      }
+      o[0] = o0;
+      o[1] = o1;
+      o[2] = o2;
       o[3] = 10.0f * st.alpha[e] * (1.0f - st.alpha[e]) * dalpha;
     }
   }
@@ -213,39 +227,65 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 
 using namespace dns;
 
-extern "C" int dns_composite_fwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
-                                 uint32_t C, float* depth, float* var, float* rgb, float* weights, float* sem,
-                                 void* stream) {
+static int composite_fwd_impl(const char* who, const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
+                              uint32_t C, float* depth, float* var, float* rgb, float* weights, float* sem, uint32_t rgbl,
+                              void* stream) {
   if (N == 0) return DNS_OK;
-  DNS_REQUIRE(raw && z && depth && var && rgb, "dns_composite_fwd: NULL argument");
-  DNS_REQUIRE(S >= 1 && S <= 256, "dns_composite_fwd: S=%u out of range [1,256]", S);
-  DNS_REQUIRE(C == 0 || (logits && sem), "dns_composite_fwd: C>0 needs logits and sem");
-  if (N == 0) return DNS_OK;
+  DNS_REQUIRE(raw && z && depth && var && rgb, "%s: NULL argument", who);
+  DNS_REQUIRE(S >= 1 && S <= 256, "%s: S=%u out of range [1,256]", who, S);
+  DNS_REQUIRE(C == 0 || (logits && sem), "%s: C>0 needs logits and sem", who);
   const uint32_t blocks = (N + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
   const size_t ldsb = 4 * 64 * E * sizeof(float);
-  if (E == 1) DNS_LAUNCH(composite_fwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
-  else if (E == 2) DNS_LAUNCH(composite_fwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
-  else DNS_LAUNCH(composite_fwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem);
-  return check_launch("dns_composite_fwd");
+  if (E == 1) DNS_LAUNCH(composite_fwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem, rgbl);
+  else if (E == 2) DNS_LAUNCH(composite_fwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem, rgbl);
+  else DNS_LAUNCH(composite_fwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, depth, var, rgb, weights, sem, rgbl);
+  return check_launch(who);
+}
+
+static int composite_bwd_impl(const char* who, const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
+                              uint32_t C, const float* d_depth, const float* d_var, const float* d_rgb, const float* d_weights,
+                              const float* d_sem, float* d_raw, float* d_logits, uint32_t rgbl, void* stream) {
+  if (N == 0) return DNS_OK;
+  DNS_REQUIRE(raw && z && d_raw, "%s: NULL argument", who);
+  DNS_REQUIRE(S >= 1 && S <= 256, "%s: S=%u out of range [1,256]", who, S);
+  DNS_REQUIRE(C == 0 || logits, "%s: C>0 needs logits", who);
+  const uint32_t blocks = (N + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
+  const size_t ldsb = 4 * 64 * E * sizeof(float);
+  if (E == 1) DNS_LAUNCH(composite_bwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits, rgbl);
+  else if (E == 2) DNS_LAUNCH(composite_bwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits, rgbl);
+  else DNS_LAUNCH(composite_bwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits, rgbl);
+  return check_launch(who);
+}
+
+extern "C" int dns_composite_fwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
+                                 uint32_t C, float* depth, float* var, float* rgb, float* weights, float* sem,
+                                 void* stream) {
+  return composite_fwd_impl("dns_composite_fwd", raw, z, logits, N, S, C, depth, var, rgb, weights, sem, 0u, stream);
 }
 
 extern "C" int dns_composite_bwd(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S,
                                  uint32_t C, const float* d_depth, const float* d_var, const float* d_rgb,
                                  const float* d_weights, const float* d_sem, float* d_raw, float* d_logits,
                                  void* stream) {
-  if (N == 0) return DNS_OK;
-  DNS_REQUIRE(raw && z && d_raw, "dns_composite_bwd: NULL argument");
-  DNS_REQUIRE(S >= 1 && S <= 256, "dns_composite_bwd: S=%u out of range [1,256]", S);
-  DNS_REQUIRE(C == 0 || logits, "dns_composite_bwd: C>0 needs logits");
-  if (N == 0) return DNS_OK;
-  const uint32_t blocks = (N + 3) / 4;
-  hipStream_t st = (hipStream_t)stream;
-  const uint32_t E = S <= 64 ? 1 : (S <= 128 ? 2 : 4);
-  const size_t ldsb = 4 * 64 * E * sizeof(float);
-  if (E == 1) DNS_LAUNCH(composite_bwd_kernel<1>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
-  else if (E == 2) DNS_LAUNCH(composite_bwd_kernel<2>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
-  else DNS_LAUNCH(composite_bwd_kernel<4>, dim3(blocks), dim3(256), ldsb, st, raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits);
-  return check_launch("dns_composite_bwd");
+  return composite_bwd_impl("dns_composite_bwd", raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits, 0u,
+                            stream);
+}
+
+extern "C" int dns_composite_fwd_ex(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C,
+                                    float* depth, float* var, float* rgb, float* weights, float* sem, uint32_t flags, void* stream) {
+  DNS_REQUIRE((flags & ~DNS_COMPOSITE_RGB_LOGITS) == 0, "dns_composite_fwd_ex: unknown flags 0x%x", flags);
+  return composite_fwd_impl("dns_composite_fwd_ex", raw, z, logits, N, S, C, depth, var, rgb, weights, sem, flags & DNS_COMPOSITE_RGB_LOGITS,
+                            stream);
+}
+
+extern "C" int dns_composite_bwd_ex(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C,
+                                    const float* d_depth, const float* d_var, const float* d_rgb, const float* d_weights,
+                                    const float* d_sem, float* d_raw, float* d_logits, uint32_t flags, void* stream) {
+  DNS_REQUIRE((flags & ~DNS_COMPOSITE_RGB_LOGITS) == 0, "dns_composite_bwd_ex: unknown flags 0x%x", flags);
+  return composite_bwd_impl("dns_composite_bwd_ex", raw, z, logits, N, S, C, d_depth, d_var, d_rgb, d_weights, d_sem, d_raw, d_logits,
+                            flags & DNS_COMPOSITE_RGB_LOGITS, stream);
 }

@@ -587,9 +587,17 @@ struct BinPlan {
 
 // d_grid rows [P, ld] (32 contiguous floats per point) -> level-major [L][P] float2, so that a binned job reads
 // only its level's 8 bytes per point; also max |d_grid| of the launch (bit pattern, atomicMax) for the fixed-point scale.
+// Row replay (DNS_SCATTER_REPLAY): per hashed level of at most 2^16 rows the 8 corner rows of every point are computed HERE,
+// once, and stored as eight 16-bit values (16 bytes per point and level, coalesced): the binned kernel's 8 visits per level
+// then extract and compare them instead of hashing the 8 corners again in every visit.
+struct ReplayPlan {
+  int32_t slot[DNS_MAX_LEVELS];                  // level -> index of its [P] uint4 plane in rows16, -1 = not replayed
+};
+
 __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __restrict__ d_grid, uint32_t ld, uint32_t P,
                                                               uint32_t n_levels, float2* __restrict__ dg_t,
-                                                              uint32_t* __restrict__ gmax) {
+                                                              uint32_t* __restrict__ gmax, const float* __restrict__ xin,
+                                                              GridLevels lv, ReplayPlan rp, uint4* __restrict__ rows16) {
   // 256 points per workgroup through an LDS tile: rows are read as whole 128-byte lines (8 lanes x 16 B per point),
   // level planes are written as 2-KB contiguous runs (lane = point).  Row stride 34 floats keeps both sides <= 2-way.
   constexpr uint32_t LDT = 34;
@@ -643,6 +651,23 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
   if (p < P) {
     for (uint32_t l = 0; l < n_levels; ++l)
       dg_t[(size_t)l * P + p] = make_float2(tile[threadIdx.x * LDT + 2 * l], tile[threadIdx.x * LDT + 2 * l + 1]);
+    if (rows16) {
+      const float x0 = xin[(size_t)p * 3], x1 = xin[(size_t)p * 3 + 1], x2 = xin[(size_t)p * 3 + 2];
+      for (uint32_t l = 0; l < n_levels; ++l) {
+        const int slot = rp.slot[l];
+        if (slot < 0) continue;                      // uniform
+        const float sc = lv.scale[l];
+        const uint32_t g0 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x0, sc), 0.5f));
+        const uint32_t g1 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x1, sc), 0.5f));
+        const uint32_t g2 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x2, sc), 0.5f));
+        const uint32_t mask = lv.size[l] - 1u;       // hashed levels are exactly 2^T rows (<= 2^16 here)
+        const uint32_t ay0 = g1 * 2654435761u, ay1 = ay0 + 2654435761u, az0 = g2 * 805459861u, az1 = az0 + 805459861u;
+        uint32_t r[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) r[c] = ((g0 + (uint32_t)(c & 1)) ^ ((c & 2) ? ay1 : ay0) ^ ((c & 4) ? az1 : az0)) & mask;
+        rows16[(size_t)slot * P + p] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+      }
+    }
   }
   // max |d_grid|: wave reduce, then ONE conditional atomic per workgroup -- 4096 unconditional same-address atomics
   // serialised into ~40 us of this kernel's 56; a (possibly stale) read of the running max lets all but the first few
@@ -675,7 +700,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
                                                                     GridLevels lv, BinPlan plan,
                                                                     const float2* __restrict__ dg_t,
                                                                     const uint32_t* __restrict__ gmax,
-                                                                    float* __restrict__ d_table) {
+                                                                    float* __restrict__ d_table, ReplayPlan rp,
+                                                                    const uint4* __restrict__ rows16) {
   // Bins: one float64 per table float, added with ds_add_f64.  Every w*g product is formed in fp32 (as tcnn forms it) and
   // summed in float64, so a cell's sum carries ~1e-16 of relative error whatever the order of the adds -- after the final
   // rounding to fp32 the result is the correctly rounded sum except on near-ties.  Measured LDS atomic rates on MI355X
@@ -795,19 +821,85 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
         return idx;
       };
       const uint32_t rows_eff = work ? rows : 0u;                          // idle lanes never hit
-      // Only ~1/8 of the corners of a hashed level land in this chunk: a branch-free pass builds the lane's 8-bit hit
-      // mask, then the wave pops one hit per lane per round (max-hits-per-lane rounds of two ds_add_u64).
+      // Corners are handled as the four x-PAIRS (x, x + 1 at the same y, z): on a hashed level the two rows of a pair differ
+      // only in low bits (x ^ (x + 1) is a run of ones, the chunk is the row's high bits), so a pair lands in ONE chunk --
+      // about half of the points have a pair here (~4 random chunks of 8 per point) -- and on a dense level the two rows are
+      // neighbours.  A branch-free pass builds the lane's 4-bit pair mask, then the wave pops one pair per lane per round: half
+      // the rounds of a per-corner loop (SQ counters, round 4: this kernel is VALU-bound, 75 % busy, and the pop loop -- not the
+      // hashing, which a stored-rows variant removed without any effect -- is most of its vector instructions).
       uint32_t hit_mask = 0;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint32_t local = row_of((c & 1) ? ax1 : ax0, (c & 2) ? ay1 : ay0, (c & 4) ? az1 : az0) - base;
-        hit_mask |= (local < rows_eff ? 1u : 0u) << c;
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t y = (c & 1) ? ay1 : ay0, z = (c & 2) ? az1 : az0;
+        const uint32_t l0 = row_of(ax0, y, z) - base, l1 = row_of(ax1, y, z) - base;
+        hit_mask |= ((l0 < rows_eff || l1 < rows_eff) ? 1u : 0u) << c;
       }
       while (__any(hit_mask != 0)) {
         if (hit_mask) {
           const uint32_t c = (uint32_t)__ffs((int)hit_mask) - 1u;
           hit_mask &= hit_mask - 1u;
-          const uint32_t local = row_of((c & 1u) ? ax1 : ax0, (c & 2u) ? ay1 : ay0, (c & 4u) ? az1 : az0) - base;
+          const uint32_t y = (c & 1u) ? ay1 : ay0, z = (c & 2u) ? az1 : az0;
+          const uint32_t l0 = row_of(ax0, y, z) - base, l1 = row_of(ax1, y, z) - base;
+          const float wyz = ((c & 1u) ? f[1] : 1.0f - f[1]) * ((c & 2u) ? f[2] : 1.0f - f[2]);
+          const float w0 = (1.0f - f[0]) * wyz, w1 = f[0] * wyz;
+          if (l0 < rows_eff) {
+            atomicAdd(dbins + 2 * l0, (double)(w0 * gg.x));
+            atomicAdd(dbins + 2 * l0 + 1, (double)(w0 * gg.y));
+          }
+          if (l1 < rows_eff) {
+            atomicAdd(dbins + 2 * l1, (double)(w1 * gg.x));
+            atomicAdd(dbins + 2 * l1 + 1, (double)(w1 * gg.y));
+          }
+        }
+      }
+    }
+  };
+  // Row replay: the level's 8 corner rows of every point were stored by dgrid_transpose_kernel (eight 16-bit values): a visit
+  // is a 16-byte load, eight extract-and-compare steps and the three fractions for the weights -- no floor / convert / hash.
+  auto sweep_replay = [&](const uint4* __restrict__ rl) {
+    uint4 rn = make_uint4(0u, 0u, 0u, 0u);
+    {
+      const uint32_t p = point_of(0);
+      if (n_it > 0 && p < p_hi) rn = rl[p];
+    }
+    for (uint32_t it = 0; it < n_it; ++it) {
+      const float2 gg = gg_n;
+      const float xc[3] = {xn[0], xn[1], xn[2]};
+      const uint4 rr = rn;
+      const bool live = point_of(it) < p_hi;
+      gg_n = make_float2(0.f, 0.f);
+      if (it + 1 < n_it) {
+        const uint32_t pn = point_of(it + 1);
+        if (pn < p_hi) {
+          gg_n = dgl[pn];
+          rn = rl[pn];
+          xn[0] = xin[(size_t)pn * 3];
+          xn[1] = xin[(size_t)pn * 3 + 1];
+          xn[2] = xin[(size_t)pn * 3 + 2];
+        }
+      }
+      const bool work = live && !(gg.x == 0.f && gg.y == 0.f);
+      const uint32_t rows_eff = work ? rows : 0u;
+      const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
+      uint32_t hit_mask = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t local = ((c & 1) ? (w4[c >> 1] >> 16) : (w4[c >> 1] & 0xffffu)) - base;
+        hit_mask |= (local < rows_eff ? 1u : 0u) << c;
+      }
+      if (!__any(hit_mask != 0)) continue;       // (uniform) most visits of a wave whose points miss this chunk end here
+      float f[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
+        f[a] = pos - floorf(pos);
+      }
+      while (__any(hit_mask != 0)) {
+        if (hit_mask) {
+          const uint32_t c = (uint32_t)__ffs((int)hit_mask) - 1u;
+          hit_mask &= hit_mask - 1u;
+          const uint32_t wsel = (c >> 1) == 0u ? rr.x : ((c >> 1) == 1u ? rr.y : ((c >> 1) == 2u ? rr.z : rr.w));
+          const uint32_t local = ((c & 1u) ? (wsel >> 16) : (wsel & 0xffffu)) - base;
           const float w = ((c & 1u) ? f[0] : 1.0f - f[0]) * ((c & 2u) ? f[1] : 1.0f - f[1]) * ((c & 4u) ? f[2] : 1.0f - f[2]);
           atomicAdd(dbins + 2 * local, (double)(w * gg.x));
           atomicAdd(dbins + 2 * local + 1, (double)(w * gg.y));
@@ -815,7 +907,8 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
       }
     }
   };
-  if (hashed) sweep(std::true_type{});
+  if (hashed && rows16 && rp.slot[l] >= 0) sweep_replay(rows16 + (size_t)rp.slot[l] * P);
+  else if (hashed) sweep(std::true_type{});
   else sweep(std::false_type{});
   __syncthreads();
   float* out = d_table + 2 * ((size_t)lv.offset[l] + base);
@@ -1085,6 +1178,14 @@ static uint32_t part_min_chunks(uint32_t flags) {
   return PART_MIN_CHUNKS;
 }
 
+// floats of workspace in front of the replayed rows (= the whole workspace without DNS_SCATTER_REPLAY), rounded to 16 bytes
+static uint64_t replay_offset_floats(uint32_t P, const GridLevels& lv, uint32_t flags, uint32_t queue_cap) {
+  uint64_t n = (uint64_t)P * lv.n_levels * 2 + 4;
+  PartPlan pp;
+  if (part_plan(lv, P, part_min_chunks(flags), queue_cap, pp)) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS + part_floats(pp);
+  return (n + 3u) & ~(uint64_t)3u;
+}
+
 static int encode_init_attrs() {
   const int bytes = 8192 * 2 * (int)sizeof(unsigned long long);   // one 8192-row chunk of 64-bit bins: 128 KB
   if (hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
@@ -1166,7 +1267,7 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
   DNS_REQUIRE(!dy_dx || (((uintptr_t)dy_dx) & 7u) == 0, "dns_encode_bwd: dy_dx must be 8-byte aligned");
-  DNS_REQUIRE((flags & ~DNS_SCATTER_MASK) == 0, "dns_encode_bwd: unknown flags 0x%x", flags);
+  DNS_REQUIRE((flags & ~(DNS_SCATTER_MASK | DNS_SCATTER_REPLAY)) == 0, "dns_encode_bwd: unknown flags 0x%x", flags);
   GridLevels lv = {};
   if (d_grid) {
     DNS_REQUIRE(meta && table, "dns_encode_bwd: d_grid given without table/meta");
@@ -1252,14 +1353,25 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       jobs = 8u * mx;                                          // padded: workgroups past an XCD's last job exit at once
     }
     const size_t lds_bytes = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
+    // row replay: hashed levels of <= 2^16 rows that this (binned) form handles in more than one chunk
+    ReplayPlan rp;
+    uint32_t n_replay = 0;
+    for (uint32_t l = 0; l < DNS_MAX_LEVELS; ++l) {
+      const bool yes = (flags & DNS_SCATTER_REPLAY) && l < lv.n_levels && lv.hashed[l] && !in_part[l] && lv.size[l] <= 65536u && chunk_of[l] > 1u;
+      rp.slot[l] = yes ? (int32_t)n_replay++ : -1;
+    }
+    DNS_REQUIRE(!n_replay || (((uintptr_t)ws) & 15u) == 0, "dns_encode_bwd: DNS_SCATTER_REPLAY needs a 16-byte aligned workspace");
+    uint4* rows16 = n_replay ? reinterpret_cast<uint4*>(ws + replay_offset_floats(P, lv, flags, queue_cap)) : nullptr;
     uint32_t* gmax = (uint32_t*)(ws + (size_t)P * lv.n_levels * 2);
     {                                                                          // max word, non-finite flag, pad
       const int rc = fill_words(gmax, 0u, 4, st, "dns_encode_bwd");
       if (rc != DNS_OK) return rc;
     }
-    DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax);
+    DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax, x, lv, rp,
+               rows16);
     if (jobs)
-      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table);
+      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table,
+                 rp, (const uint4*)rows16);
     if (part) {
       uint32_t* qcount = gmax + 4;
       float* queues = reinterpret_cast<float*>(qcount + DNS_MAX_LEVELS * PART_MAX_CHUNKS);
@@ -1286,10 +1398,10 @@ extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMet
 
 extern "C" uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta, uint32_t flags, uint32_t queue_cap) {
   if (!meta) return 0;
-  // level-major d_grid copy + max|d_grid| word (+pad) + queue counters + the partition form's queues
-  uint64_t n = (uint64_t)P * meta->n_levels * 2 + 4;
   const GridLevels lv = to_levels(meta);
-  PartPlan pp;
-  if (part_plan(lv, P, part_min_chunks(flags), queue_cap, pp)) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS + part_floats(pp);
+  // level-major d_grid copy + max|d_grid| word (+pad) + queue counters + the partition form's queues [+ replayed rows: 4 floats
+  // per point and hashed level, 16-byte aligned]
+  uint64_t n = replay_offset_floats(P, lv, flags, queue_cap);
+  if (flags & DNS_SCATTER_REPLAY) n += (uint64_t)P * lv.n_levels * 4;
   return n;
 }

@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
                                                              const float* __restrict__ z,
                                                              const float* __restrict__ gt_depth,
                                                              const uint8_t* __restrict__ valid, float* __restrict__ d_fine,
-                                                             float* __restrict__ d_coarse, uint32_t ldd_fine) {
+                                                             float* __restrict__ d_coarse, uint32_t ldd_fine,
+                                                             const float* __restrict__ d_occ, uint32_t ld_occ) {
   const uint32_t E = c.N * c.S * c.L;
   const float g = g_total[0];
   const float clt = g * out[O_CLT], cfs = g * out[O_CFS], cop = g * out[O_COP];
@@ -317,12 +318,14 @@ __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const fl
   // (point, channel, ray) of the quad's first element come from ONE pair of integer divisions and advance incrementally
   // (a pair of divisions per ELEMENT was a third of this kernel's time).
   auto elem = [&](uint32_t p, uint32_t k, uint32_t n, bool ok, float f, float co, float& df, float& dc) {
-    df = 0.f;
+    // (d_occ: the compositing's gradient of the occupancy logit = column 0 of the fine latents, slams/mapping.py:626-627,
+    //  added here instead of by a read-modify-write pass over the strided column)
+    df = (k == 0 && d_occ) ? d_occ[(size_t)p * ld_occ] : 0.f;
     dc = 0.f;
     if (!ok) return;
     const float d0 = co - f;
     dc = clt * d0;
-    df = -clt * d0;
+    df -= clt * d0;
     if (k + 1 == c.L) {
       const float d = gt_depth[n], zz = z[p];
       const float occ = sigmoid10f(f);
@@ -446,16 +449,34 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
   DNS_REQUIRE(ldd_fine == 0 || ldd_fine >= L, "dns_loss_bwd: ldd_fine %u < L %u", ldd_fine, L);
   DNS_REQUIRE(lambdas && out && g_total && d_color && d_depth, "dns_loss_bwd: NULL argument");
   DNS_REQUIRE(C == 0 || d_logits, "dns_loss_bwd: C > 0 needs d_logits");
-  DNS_REQUIRE(tracker || (d_fine && d_coarse), "dns_loss_bwd: mapper mode needs d_fine and d_coarse");
+  DNS_REQUIRE(tracker || (d_fine != nullptr) == (d_coarse != nullptr), "dns_loss_bwd: d_fine and d_coarse come together (both NULL: "
+              "the ray part only, the point part follows with dns_loss_bwd_points)");
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
   hipStream_t st = (hipStream_t)stream;
   DNS_LAUNCH(loss_ray_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, out, g_total, pred_color, pred_depth,
                      pred_var, pred_logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var, d_logits);
-  if (!tracker) {
+  if (!tracker && d_fine) {
     const uint64_t E = (uint64_t)N * S * L;
     const uint32_t blocks = (uint32_t)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
     DNS_LAUNCH(loss_point_bwd_kernel, dim3(blocks), dim3(256), 0, st, c, out, g_total, fine, coarse, z, gt_depth,
-                       valid, d_fine, d_coarse, ldd_fine ? ldd_fine : L);
+                       valid, d_fine, d_coarse, ldd_fine ? ldd_fine : L, nullptr, 0u);
   }
   return check_launch("dns_loss_bwd");
+}
+
+extern "C" int dns_loss_bwd_points(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, const float* out,
+                                   const float* g_total, const float* gt_depth, const uint8_t* valid, const float* fine,
+                                   const float* coarse, const float* z, float* d_fine, float* d_coarse, uint32_t ldd_fine,
+                                   const float* d_occ, uint32_t ld_occ, void* stream) {
+  if (N == 0) return DNS_OK;
+  DNS_REQUIRE(lambdas && out && g_total && gt_depth && fine && coarse && z && d_fine && d_coarse, "dns_loss_bwd_points: NULL argument");
+  DNS_REQUIRE(ldd_fine == 0 || ldd_fine >= L, "dns_loss_bwd_points: ldd_fine %u < L %u", ldd_fine, L);
+  DNS_REQUIRE(!d_occ || ld_occ >= 1, "dns_loss_bwd_points: ld_occ");
+  DNS_REQUIRE((uint64_t)N * S * L < (1ull << 32) - (1ull << 22), "dns_loss_bwd_points: N*S*L must stay below 2^32");
+  const LossCfg c = make_cfg(lambdas, N, S, C, L, 0);
+  const uint64_t E = (uint64_t)N * S * L;
+  const uint32_t blocks = (uint32_t)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+  DNS_LAUNCH(loss_point_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, out, g_total, fine, coarse, z, gt_depth, valid,
+             d_fine, d_coarse, ldd_fine ? ldd_fine : L, d_occ, ld_occ);
+  return check_launch("dns_loss_bwd_points");
 }

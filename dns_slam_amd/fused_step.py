@@ -529,11 +529,11 @@ class MapStep:
                                         ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat, ptr(self.raw), st), "dns_feature_block")
         fwd(self.feat, pe, self.p_color, self.shp_col, self.raw, None, None, P, 0, self.h_col)
         fwd(self.feat, pe, self.p_logit, self.shp_log, self.logit, None, None, P, 0, self.h_log)
-        check(lib.dns_rgb_sigmoid(ptr(self.raw), P, st), "dns_rgb_sigmoid")
-        # ---- compositing + losses (utils/common.py:506-537, slams/mapping.py:887-907)
+        # ---- compositing + losses (utils/common.py:506-537, slams/mapping.py:887-907).  raw[:, 0:3] stays the colour network's
+        # LOGITS: the compositing kernels apply the sigmoid (models/decoder.py:124) on the fly, forward and backward
         Cn, L = self.n_class, self.hid + 1
-        check(lib.dns_composite_fwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
-                                    ptr(self.rgb), ptr(self.weights), ptr(self.sem), st), "dns_composite_fwd")
+        check(lib.dns_composite_fwd_ex(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
+                                       ptr(self.rgb), ptr(self.weights), ptr(self.sem), 1, st), "dns_composite_fwd_ex")
         lam = self.lam
         check(lib.dns_loss_sums(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
                                 ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(fine), ptr(self.coarse),
@@ -548,13 +548,18 @@ class MapStep:
         # [P, L] sum kernel.  (The 2-D code's columns only ever accumulate; nothing reads them -- the code has no gradient.)
         ldf = 4 + self.n_feat
         d_fine_dst = _V(self.d_featx.data_ptr() + 4 * 3)
+        # ray losses -> compositing (its d_raw[:, 0:3] IS the colour network's output gradient: the sigmoid's backward is folded
+        # in) -> point losses, which also add the compositing's d occupancy (d_raw[:, 3]) into column 0 of d_fine
         check(lib.dns_loss_bwd(lam, N, S, Cn, L, 0, ptr(self.out), ptr(self.one), ptr(self.rgb), ptr(self.depth), None,
                                ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside),
                                ptr(fine), ptr(self.coarse), ptr(self.z), ptr(self.d_color), ptr(self.d_depth), None,
-                               ptr(self.d_sem), d_fine_dst, ptr(self.d_coarse), ldf, st), "dns_loss_bwd")
-        check(lib.dns_composite_bwd(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), None,
-                                    ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), st),
-              "dns_composite_bwd")
+                               ptr(self.d_sem), None, None, 0, st), "dns_loss_bwd")
+        check(lib.dns_composite_bwd_ex(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), None,
+                                       ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), 1, st),
+              "dns_composite_bwd_ex")
+        check(lib.dns_loss_bwd_points(lam, N, S, Cn, L, ptr(self.out), ptr(self.one), ptr(self.gt_depth), ptr(self.inside), ptr(fine),
+                                      ptr(self.coarse), ptr(self.z), d_fine_dst, ptr(self.d_coarse), ldf,
+                                      _V(self.d_raw.data_ptr() + 12), 4, st), "dns_loss_bwd_points")
 
         # dW_in of every network on the SIDE stream (2.02 -> 1.90 ms per step): the streaming kernel is memory-bound and needs only
         # what its backward kernel left in the workspace, the next network's backward kernel is vector-bound -- the pair fills the
@@ -591,8 +596,7 @@ class MapStep:
 
         d_feat = self.d_featx[:, 4:]
         bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, cur.g_coarse, None, None, P, 0, 0, self.h_c)
-        check(lib.dns_raw_bwd(ptr(self.d_raw), ptr(self.raw), P, ptr(self.d_col), d_fine_dst, ldf, 1, st), "dns_raw_bwd")
-        bwd(self.feat, pe, self.d_col, self.p_color, self.shp_col, d_feat, cur.g_color, None, None, P, 0, 3, self.h_col)
+        bwd(self.feat, pe, self.d_raw, self.p_color, self.shp_col, d_feat, cur.g_color, None, None, P, 0, 3, self.h_col)
         bwd(self.feat, pe, self.d_logit, self.p_logit, self.shp_log, d_feat, cur.g_logit, None, None, P, 0, 3, self.h_log)
         if self.stem:
             # Merge's backward (models/decoder.py:67-77): d code -> the R views' latent gradients -> weight gradients and, under

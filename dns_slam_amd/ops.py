@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -58,7 +60,8 @@ class _TimedLib:
                   "dns_rays_from_pixels": 12, "dns_mlp_dwin": 10, "dns_feature_block": (7, 8), "dns_loss_sums": (1, 2),
                   "dns_loss_bwd": (1, 2), "dns_raw_bwd": 2, "dns_rgb_sigmoid": 1, "dns_class_slots": (1, 2),
                   "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5),
-                  "dns_encode_fwd_split": 2, "dns_mlp_fwd_split": 10, "dns_mlp_bwd_split": 16, "dns_feature_block_split": (9, 10)}
+                  "dns_encode_fwd_split": 2, "dns_mlp_fwd_split": 10, "dns_mlp_bwd_split": 16, "dns_feature_block_split": (9, 10),
+                  "dns_composite_fwd_ex": 3, "dns_composite_bwd_ex": 3, "dns_loss_bwd_points": (1, 2)}
 
     def arm(self, kernels=False):
         self.kernels = bool(kernels)
@@ -144,7 +147,8 @@ def _bound6(bound) -> Optional[C.Array]:
 # (form, queue_cap) of the table-gradient scatter, include/dns_hip.h DNS_SCATTER_*: 0 auto, 1 per-corner atomics (tcnn's
 # form), 2 LDS bins for every level, 3 per-chunk queues for every multi-chunk level; queue_cap 0 = sized by the library
 SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED, SCATTER_QUEUES = 0, 1, 2, 3
-SCATTER_FORM = (SCATTER_AUTO, 0)
+SCATTER_REPLAY = 0x10       # include/dns_hip.h DNS_SCATTER_REPLAY: hashed levels' corner rows stored once, replayed by the chunk visits
+SCATTER_FORM = (SCATTER_AUTO | (SCATTER_REPLAY if os.environ.get("DNS_SCATTER_REPLAY", "0") == "1" else 0), 0)
 SAVE_DY_DX = True           # encode forward keeps d(grid)/dx when the points need a gradient (False: the backward re-gathers)
 
 

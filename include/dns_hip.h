@@ -185,6 +185,11 @@ int dns_encode_fwd_split(const float* in, const double* bound, uint32_t P, uint3
 #define DNS_SCATTER_BINNED 2u
 #define DNS_SCATTER_QUEUES 3u
 #define DNS_SCATTER_MASK 3u
+/* | DNS_SCATTER_REPLAY (ABI v9): hashed levels of at most 2^16 rows handled by the LDS-bin form keep the 8 corner rows of every point
+ * (eight 16-bit values, written once per call beside the level-major gradient copy: 16 more bytes of workspace per point and
+ * level, counted by dns_encode_bwd_ws_floats with the same flags) and the 8 chunk visits of a level replay them instead of
+ * hashing the 8 corners again.  Same sums. */
+#define DNS_SCATTER_REPLAY 0x10u
 int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins,
                    const float* table, const DnsGridMeta* meta,
                    const float* d_pe, uint32_t ld_dpe, const float* d_grid, uint32_t ld_dgrid,
@@ -284,6 +289,17 @@ int dns_composite_bwd(const float* raw, const float* z, const float* logits, uin
                       const float* d_depth, const float* d_var, const float* d_rgb, const float* d_weights,
                       const float* d_sem, float* d_raw, float* d_logits, void* stream);
 
+/* The same pair with the colour network's output activation folded in (ABI v9): DNS_COMPOSITE_RGB_LOGITS -- raw[..., 0:3] holds
+ * the colour network's LOGITS; the kernels apply sigmoid (models/decoder.py:124) on the fly, and the backward's d_raw[..., 0:3] is
+ * the gradient w.r.t. those logits (d colour * s (1 - s)), i.e. directly the colour network's output gradient: no separate
+ * sigmoid pass over [P,4] forward, none backward. */
+#define DNS_COMPOSITE_RGB_LOGITS 1u
+int dns_composite_fwd_ex(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C, float* depth,
+                         float* var, float* rgb, float* weights, float* sem, uint32_t flags, void* stream);
+int dns_composite_bwd_ex(const float* raw, const float* z, const float* logits, uint32_t N, uint32_t S, uint32_t C,
+                         const float* d_depth, const float* d_var, const float* d_rgb, const float* d_weights, const float* d_sem,
+                         float* d_raw, float* d_logits, uint32_t flags, void* stream);
+
 /* ---- fused loss reductions --------------------------------------------------------------------
  * Mapper: photometric / depth / label / latent losses (slams/mapping.py:110-126) + get_opacity_loss
  * (utils/common.py:769-802) and their weighted sum (mapping.py:906-907); tracker = 1: the three masked losses of
@@ -295,7 +311,7 @@ int dns_composite_bwd(const float* raw, const float* z, const float* logits, uin
  * the buffer must hold DNS_LOSS_SUMS_FLOATS floats, the rest is reduction workspace),
  * dns_loss_finalize turns it into out[16] = {p, d, l, lt, fs, op, total, -, coefficients...},
  * dns_loss_bwd writes d(total * g_total)/d(inputs): d_color, d_depth, d_var (tracker; may be NULL), d_logits,
- * d_fine, d_coarse (overwritten).  ldd_fine: row stride of d_fine in floats (0 = L, contiguous) -- lets the caller place the
+ * d_fine, d_coarse (overwritten; both NULL in mapper mode: the ray part only, see dns_loss_bwd_points).  ldd_fine: row stride of d_fine in floats (0 = L, contiguous) -- lets the caller place the
  * fine decoder's loss gradient straight into a wider row that later kernels add to (fused_step.MapStep). */
 #define DNS_LOSS_SUMS_FLOATS (32 + 5 * 1024)
 int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
@@ -310,6 +326,15 @@ int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint3
                  const int64_t* gt_label, const uint8_t* valid, const float* fine, const float* coarse, const float* z,
                  float* d_color, float* d_depth, float* d_var, float* d_logits, float* d_fine, float* d_coarse,
                  uint32_t ldd_fine, void* stream);
+
+/* The point part of dns_loss_bwd alone (dns_loss_bwd with d_fine = d_coarse = NULL runs the ray part alone), with the
+ * compositing's gradient of the occupancy logit added in: d_fine[p, 0] += d_occ[p * ld_occ] (d_occ NULL = nothing) -- the occupancy
+ * is column 0 of the fine latents (slams/mapping.py:626-627), so the sum the reference's autograd forms needs no
+ * read-modify-write pass over a strided column.  Call order: dns_loss_bwd (rays) -> dns_composite_bwd -> this. */
+int dns_loss_bwd_points(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, const float* out,
+                        const float* g_total, const float* gt_depth, const uint8_t* valid, const float* fine, const float* coarse,
+                        const float* z, float* d_fine, float* d_coarse, uint32_t ldd_fine, const float* d_occ, uint32_t ld_occ,
+                        void* stream);
 
 /* ---- fused Adam --------------------------------------------------------------------------------
  * torch.optim.Adam.step with default betas / eps, no weight decay, no amsgrad (reference slams/mapping.py:464,910,

@@ -453,3 +453,82 @@ def test_draw_finish_equals_the_oracle_class_balanced_pick():
         assert torch.equal(got[f, n1:], want), f
         assert torch.equal(got[f, :n1], i1[f].cpu())
     assert saw_single
+
+
+def test_composite_rgb_logits_and_point_loss_backward_with_occupancy():
+    """ABI v9 glue fusions of the mapping step: dns_composite_fwd_ex / _bwd_ex with DNS_COMPOSITE_RGB_LOGITS == dns_rgb_sigmoid +
+    dns_composite_fwd / dns_composite_bwd + dns_raw_bwd (the colour network's sigmoid, models/decoder.py:124, folded into the
+    compositing); dns_loss_bwd (rays only) + dns_loss_bwd_points(d_occ) == dns_loss_bwd followed by the strided += of d occupancy."""
+    lib, check, ptr, stream_ptr = _lib()
+    from ctypes import c_float, c_void_p
+    from dns_slam_amd import ops
+    g = torch.Generator().manual_seed(12)
+    N, S, Cn, L = 300, 47, 8, 33
+    P = N * S
+    raw = torch.randn(P, 4, generator=g).to(DEV)
+    z = torch.sort(torch.rand(N, S, generator=g) * 3 + 0.1, dim=1).values.to(DEV)
+    logit = torch.randn(P, Cn, generator=g).to(DEV)
+    f = lambda *s: torch.empty(*s, device=DEV)
+    outs = []
+    for fused in (False, True):
+        r = raw.clone()
+        depth, var, rgb, w, sem = f(N), f(N), f(N, 3), f(N, S), f(N, Cn)
+        if fused:
+            check(lib.dns_composite_fwd_ex(ptr(r), ptr(z), ptr(logit), N, S, Cn, ptr(depth), ptr(var), ptr(rgb), ptr(w), ptr(sem), 1,
+                                           stream_ptr()), "fwd_ex")
+        else:
+            check(lib.dns_rgb_sigmoid(ptr(r), P, stream_ptr()), "sig")
+            check(lib.dns_composite_fwd(ptr(r), ptr(z), ptr(logit), N, S, Cn, ptr(depth), ptr(var), ptr(rgb), ptr(w), ptr(sem),
+                                        stream_ptr()), "fwd")
+        gd, gc, gs = torch.randn(N, generator=torch.Generator().manual_seed(1)).to(DEV), torch.randn(N, 3, generator=torch.Generator().manual_seed(2)).to(DEV), \
+            torch.randn(N, Cn, generator=torch.Generator().manual_seed(3)).to(DEV)
+        d_raw, d_logit = f(P, 4), f(P, Cn)
+        wide = torch.full((P, 7), 0.5, device=DEV)
+        if fused:
+            check(lib.dns_composite_bwd_ex(ptr(r), ptr(z), ptr(logit), N, S, Cn, ptr(gd), None, ptr(gc), None, ptr(gs), ptr(d_raw), ptr(d_logit),
+                                           1, stream_ptr()), "bwd_ex")
+            d_col = d_raw.clone()
+            d_col[:, 3] = 0.0
+            wide[:, 3] += d_raw[:, 3]
+        else:
+            check(lib.dns_composite_bwd(ptr(r), ptr(z), ptr(logit), N, S, Cn, ptr(gd), None, ptr(gc), None, ptr(gs), ptr(d_raw), ptr(d_logit),
+                                        stream_ptr()), "bwd")
+            d_col = f(P, 4)
+            check(lib.dns_raw_bwd(ptr(d_raw), ptr(r), P, ptr(d_col), c_void_p(wide.data_ptr() + 12), 7, 1, stream_ptr()), "raw_bwd")
+        outs.append([depth, var, rgb, w, sem, d_col, d_logit, wide])
+    torch.cuda.synchronize()
+    for a, b, name in zip(outs[1], outs[0], ("depth", "var", "rgb", "weights", "sem", "d colour logits", "d logits", "d occupancy")):
+        assert_close(a.cpu(), b.cpu(), rtol=1e-6, what=f"rgb-logit compositing: {name}")
+    # ---- point losses with the occupancy gradient added
+    fine, coarse = torch.randn(P, L, generator=g).to(DEV), torch.randn(P, L, generator=g).to(DEV)
+    gt_depth = (torch.rand(N, generator=g) * 3).to(DEV)
+    valid = (torch.rand(N, generator=g) > 0.1).to(torch.uint8).to(DEV)
+    out16 = torch.rand(16, generator=g).to(DEV)
+    one = torch.ones(1, device=DEV)
+    lam = (c_float * 8)(5.0, 5.0, 0.1, 10.0, 10.0, 10.0, 0.2, 0.05)
+    d_occ = torch.randn(P, 4, generator=g).to(DEV)
+    ldf = 4 + 64
+    res = []
+    for fused in (False, True):
+        dfx, dco = torch.zeros(P, ldf, device=DEV), f(P, L)
+        dst = c_void_p(dfx.data_ptr() + 12)
+        dcol, ddep, dsem = f(N, 3), f(N), f(N, Cn)
+        pc, pd, ps = torch.rand(N, 3, generator=torch.Generator().manual_seed(5)).to(DEV), torch.rand(N, generator=torch.Generator().manual_seed(6)).to(DEV), \
+            torch.randn(N, Cn, generator=torch.Generator().manual_seed(7)).to(DEV)
+        gcol, lab = torch.rand(N, 3, generator=torch.Generator().manual_seed(8)).to(DEV), torch.randint(0, Cn, (N,), generator=torch.Generator().manual_seed(9)).to(DEV)
+        args = (lam, N, S, Cn, L, 0, ptr(out16), ptr(one), ptr(pc), ptr(pd), None, ptr(ps), ptr(gcol), ptr(gt_depth), ptr(lab), ptr(valid),
+                ptr(fine), ptr(coarse), ptr(z), ptr(dcol), ptr(ddep), None, ptr(dsem))
+        if fused:
+            check(lib.dns_loss_bwd(*args, None, None, 0, stream_ptr()), "loss_bwd rays")
+            check(lib.dns_loss_bwd_points(lam, N, S, Cn, L, ptr(out16), ptr(one), ptr(gt_depth), ptr(valid), ptr(fine), ptr(coarse), ptr(z),
+                                          dst, ptr(dco), ldf, c_void_p(d_occ.data_ptr() + 12), 4, stream_ptr()), "loss_bwd_points")
+        else:
+            check(lib.dns_loss_bwd(*args, dst, ptr(dco), ldf, stream_ptr()), "loss_bwd")
+            dfx[:, 3] += d_occ[:, 3]
+        res.append((dfx, dco, dcol, ddep, dsem))
+    torch.cuda.synchronize()
+    for (a, b), name in zip(zip(res[1], res[0]), ("d fine (wide rows)", "d coarse", "d colour", "d depth", "d sem")):
+        if name.startswith("d fine"):       # the occupancy term joins inside one fused multiply-add instead of a later rounded add
+            assert_close(a.cpu(), b.cpu(), rtol=1e-6, what=f"point losses + d occupancy: {name}")
+        else:
+            assert torch.equal(a, b), name
