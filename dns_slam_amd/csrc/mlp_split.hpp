@@ -774,6 +774,7 @@ struct BwdArgs {
   const unsigned char* prep;                 // prepared images of the backward kernel (NULL: build them from params)
   uint32_t prep_stride;                      // bytes per weight set
   XsIn xs;                                   // split-row input (xs.s1.rows != NULL: x / seg are unused)
+  uint32_t n_waves;                          // waves per workgroup the launcher planned the grid for (4, or 8: frozen-scene form)
 #ifdef DNS_BWD_TRACE
   unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
 #endif
