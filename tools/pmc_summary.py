@@ -21,8 +21,13 @@ ENTRY = {  # C-ABI entry point -> kernels it launches
     "dns_group_slots": ["group_hist_kernel", "group_scan_kernel", "group_scatter_kernel"],
     "dns_class_slots": ["class_slots_kernel"], "dns_feature_block": ["feature_block_kernel"], "dns_rgb_sigmoid": ["rgb_sigmoid_kernel"],
     "dns_raw_bwd": ["raw_bwd_kernel"], "dns_lattice_points": ["lattice_points_kernel"],
+    # ABI v9 (round 4)
+    "dns_encode_fwd_split": ["encode_fwd_split_kernel"], "dns_feature_block_split": ["feature_block_split_kernel"],
+    "dns_mlp_dwin": ["mlp_dwin_kernel"], "dns_feature_gather_frames": ["feature_gather_frames_kernel"],
+    "dns_merge_dy": ["merge_dy_kernel"], "dns_add_ref_sum": ["add_ref_sum_kernel"], "dns_refer_poses": ["refer_poses_kernel"],
+    "dns_draw_finish": ["draw_finish_kernel"], "dns_loss_finalize": ["loss_finalize_kernel"],
 }
-GATHER = ("encode_fwd_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel")
+GATHER = ("encode_fwd_kernel", "encode_fwd_split_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel", "feature_gather_frames_kernel")
 
 
 def load(d):
