@@ -98,16 +98,16 @@ int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
                          uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
                          float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, const sp::XsIn* xs,
-                         hipStream_t st);
+                         hipStream_t st, uint32_t n_in_w = 0);
 int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
                          uint32_t lddy, const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons,
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
-                         bool with_dwin, const float* h_saved, const sp::XsIn* xs, hipStream_t st);
+                         bool with_dwin, const float* h_saved, const sp::XsIn* xs, hipStream_t st, uint32_t n_in_w = 0);
 int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                     uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
-                    const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st);
+                    const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st, uint32_t n_in_w = 0);
 // prepared weight images (mlp_split.hip): bytes per weight set (forward part / both parts), and the launch of the two builders
 uint32_t mlp_prepared_fwd_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl);
 uint32_t mlp_prepared_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl);

@@ -21,6 +21,15 @@ extern "C" uint64_t dns_mlp_bwd_ws_floats(uint32_t n_slots, uint32_t n_neurons, 
   return (uint64_t)n_slots * n_neurons;      // dH_1, slot-major: the operand of the dW_in kernel
 }
 
+// DNS_MLP_LIVE_IN(n): input columns [n, n_in) are identically zero -- the kernels run as an n-input network on the SAME parameter
+// tensor (W_in keeps its row stride n_in).  Returns the live width (n_in when the field is 0) or 0 on a bad value.
+static uint32_t live_in(uint32_t flags, uint32_t n_in, uint32_t n_in1, bool two) {
+  const uint32_t n = (flags >> 16) & 0xffu;
+  if (n == 0) return n_in;
+  if (n > n_in || (n % 8) != 0 || (two && n <= n_in1)) return 0;
+  return n;
+}
+
 static int check_segments(const char* who, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in) {
   if (!x2) return DNS_OK;
   DNS_REQUIRE(n_in1 >= 4 && n_in1 < n_in && (n_in1 % 4) == 0, "%s: first input segment must hold a multiple of 4 columns in (0, n_in)", who);
@@ -35,25 +44,28 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
                            const int32_t* tile_group, uint32_t param_stride, float* h_save, uint32_t flags, void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && params && y, "dns_mlp_fwd: NULL argument");
-  DNS_REQUIRE((flags & ~(DNS_MLP_FP16 | DNS_MLP_PREPARED)) == 0, "dns_mlp_fwd: unknown flags 0x%x", flags);
+  DNS_REQUIRE((flags & ~(DNS_MLP_FP16 | DNS_MLP_PREPARED | 0xff0000u)) == 0, "dns_mlp_fwd: unknown flags 0x%x", flags);
   const bool prepared = (flags & DNS_MLP_PREPARED) != 0;
   DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_fwd: prepared images must be 16-byte aligned");
   DNS_REQUIRE(!h_save || (((uintptr_t)h_save) % 16) == 0, "dns_mlp_fwd: h_save must be 16-byte aligned");
+  const uint32_t n_live = live_in(flags, n_in, n_in1, x2 != nullptr);
+  DNS_REQUIRE(n_live != 0 && (n_live == n_in || !prepared), "dns_mlp_fwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in], not with "
+              "DNS_MLP_PREPARED)");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
   DNS_REQUIRE(ldy >= n_out, "dns_mlp_fwd: ldy < n_out");
   {
-    const int rc = check_segments("dns_mlp_fwd", x2, ldx2, n_in1, n_in);
+    const int rc = check_segments("dns_mlp_fwd", x2, ldx2, n_in1, n_live);
     if (rc != DNS_OK) return rc;
   }
   const int rc = ensure_ready((hipStream_t)stream, "dns_mlp_fwd");
   if (rc != DNS_OK) return rc;
   // DNS_MLP_PREPARED: `params` is what dns_mlp_prepare wrote (the forward images come first in every weight set's block)
   const unsigned char* prep = prepared ? reinterpret_cast<const unsigned char*>(params) : nullptr;
-  return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_in, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
+  return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_live, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
                               row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, prep,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), nullptr, (hipStream_t)stream);
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), nullptr, (hipStream_t)stream, n_in);
 }
 
 extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
@@ -64,8 +76,11 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                            void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params, "dns_mlp_bwd: NULL argument");
-  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN | (int)DNS_MLP_DX_FIRST)) == 0,
+  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN | (int)DNS_MLP_DX_FIRST | 0xff0000)) == 0,
               "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  const uint32_t n_live = live_in((uint32_t)accumulate_dx, n_in, n_in1, x2 != nullptr);
+  DNS_REQUIRE(n_live != 0 && (n_live == n_in || (!(accumulate_dx & (int)DNS_MLP_PREPARED) && !h_saved)),
+              "dns_mlp_bwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in], not with DNS_MLP_PREPARED / h_saved)");
   const bool dx_first = (accumulate_dx & (int)DNS_MLP_DX_FIRST) != 0;
   DNS_REQUIRE(!dx_first || x2, "dns_mlp_bwd: DNS_MLP_DX_FIRST needs a two-segment input");
   const bool prepared = (accumulate_dx & (int)DNS_MLP_PREPARED) != 0;
@@ -76,23 +91,24 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   DNS_REQUIRE(!d_params || (ws && (((uintptr_t)ws) % 16) == 0), "dns_mlp_bwd: d_params needs a 16-byte aligned workspace ws");
   DNS_REQUIRE(!h_saved || (((uintptr_t)h_saved) % 16) == 0, "dns_mlp_bwd: h_saved must be 16-byte aligned");
   {
-    const int rc = check_segments("dns_mlp_bwd", x2, ldx2, n_in1, n_in);
+    const int rc = check_segments("dns_mlp_bwd", x2, ldx2, n_in1, n_live);
     if (rc != DNS_OK) return rc;
   }
-  if (!x2) n_in1 = n_in;
+  if (!x2) n_in1 = n_live;
   DNS_REQUIRE(!x2 || !d_x || d_x2 || dx_first, "dns_mlp_bwd: d_x2 is required with a two-segment input when d_x is asked for");
   if (d_x) DNS_REQUIRE(lddx >= n_in1 && ((lddx % 4) != 0 || (((uintptr_t)d_x) % 16) == 0), "dns_mlp_bwd: d_x alignment / lddx");
-  if (d_x && x2 && !dx_first) DNS_REQUIRE(lddx2 >= n_in - n_in1, "dns_mlp_bwd: lddx2 < n_in - n_in1");
+  if (d_x && x2 && !dx_first) DNS_REQUIRE(lddx2 >= n_live - n_in1, "dns_mlp_bwd: lddx2 < live columns of the second segment");
   if (dx_first) d_x2 = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int rc = ensure_ready(st, "dns_mlp_bwd");
   if (rc != DNS_OK) return rc;
-  return launch_mlp_bwd_split(x, ldx, x2, ldx2, n_in1, dy, lddy, params, n_in, n_out, n_neurons, n_hidden_layers, d_x, lddx,
+  return launch_mlp_bwd_split(x, ldx, x2, ldx2, n_in1, dy, lddy, params, n_live, n_out, n_neurons, n_hidden_layers, d_x, lddx,
                               d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride, accumulate_dx & 1,
                               (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
                               prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
                                        : nullptr,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, nullptr, st);
+                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, nullptr, st,
+                              n_in);
 }
 
 extern "C" int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in,
@@ -100,20 +116,22 @@ extern "C" int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint3
                             const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && d_params && ws, "dns_mlp_dwin: NULL argument");
-  DNS_REQUIRE((flags & ~DNS_MLP_FP16) == 0, "dns_mlp_dwin: unknown flags 0x%x", flags);
+  DNS_REQUIRE((flags & ~(DNS_MLP_FP16 | 0xff0000u)) == 0, "dns_mlp_dwin: unknown flags 0x%x", flags);
+  const uint32_t n_live = live_in(flags, n_in, n_in1, x2 != nullptr);
+  DNS_REQUIRE(n_live != 0, "dns_mlp_dwin: bad DNS_MLP_LIVE_IN value");
   DNS_REQUIRE(shape_ok(n_in, 1, n_neurons, n_hidden_layers), "dns_mlp_dwin: unsupported shape in=%u neurons=%u layers=%u", n_in,
               n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)ws) % 16) == 0, "dns_mlp_dwin: x / ws must be 16-byte aligned with ldx %% 4 == 0");
   {
-    const int rc = check_segments("dns_mlp_dwin", x2, ldx2, n_in1, n_in);
+    const int rc = check_segments("dns_mlp_dwin", x2, ldx2, n_in1, n_live);
     if (rc != DNS_OK) return rc;
   }
-  if (!x2) n_in1 = n_in;
+  if (!x2) n_in1 = n_live;
   hipStream_t st = (hipStream_t)stream;
   const int rc = ensure_ready(st, "dns_mlp_dwin");
   if (rc != DNS_OK) return rc;
-  return launch_mlp_dwin(x, ldx, x2, ldx2, n_in1, n_in, n_neurons, n_hidden_layers, d_params, ws, n_slots, row_index, tile_group,
-                         param_stride, (flags & DNS_MLP_FP16) != 0, st);
+  return launch_mlp_dwin(x, ldx, x2, ldx2, n_in1, n_live, n_neurons, n_hidden_layers, d_params, ws, n_slots, row_index, tile_group,
+                         param_stride, (flags & DNS_MLP_FP16) != 0, st, n_in);
 }
 
 extern "C" uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers) {

@@ -23,6 +23,7 @@ struct FwdArgs {
   const unsigned char* prep;                 // prepared images (NULL: build them from params)
   uint32_t prep_stride;                      // bytes per weight set
   XsIn xs;                                   // split-row input (XS kernels; x / seg unused then)
+  uint32_t n_in_w;                           // storage width of W_in's rows (= n_in, or larger with DNS_MLP_LIVE_IN)
 };
 
 // XS: the input arrives in the split-row format (split_rows.hpp) and goes from memory straight into the B operand
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
           const unsigned char* src = a.prep + (size_t)grp * a.prep_stride;
           images_copy_in(lds, src, L::misc(n_in, n_out), src + L::misc(n_in, n_out), wexp);
         }
-        if (!a.prep) build_fwd_images<NN, NL>(lds, a.params + (size_t)grp * a.param_stride, n_in, n_out);
+        if (!a.prep) build_fwd_images<NN, NL>(lds, a.params + (size_t)grp * a.param_stride, n_in, n_out, a.n_in_w);
       }
       cur_group = grp;
       __syncthreads();
@@ -199,7 +200,7 @@ struct DwinArgs {
   const float* x;
   uint32_t ldx;
   XSeg seg;
-  uint32_t n_in;
+  uint32_t n_in, n_in_w;                     // live input columns; row stride of dW_in (>= n_in)
   float* d_params;                           // dW_in block of the group = d_params + group * param_stride
   uint32_t n_slots;
   const int32_t* row_index;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dwin_kernel(DwinArgs a) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < IT; ++j)
-          flush_tile(acc[i][j], dW + (size_t)(32 * i) * n_in + 32 * j, n_in, 32u, n_in > 32u * j ? n_in - 32u * j : 0u, stg_base, wave, lane);
+          flush_tile(acc[i][j], dW + (size_t)(32 * i) * a.n_in_w + 32 * j, a.n_in_w, 32u, n_in > 32u * j ? n_in - 32u * j : 0u, stg_base, wave, lane);
     }
     run0 = run1;
   }
@@ -315,9 +316,10 @@ int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy,
                          uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride,
                          float* h_save, bool fp16_single, const unsigned char* prep, uint32_t prep_stride, const sp::XsIn* xs,
-                         hipStream_t st) {
+                         hipStream_t st, uint32_t n_in_w) {
   using namespace sp;
   FwdArgs a;
+  a.n_in_w = n_in_w ? n_in_w : n_in;
   a.xs = xs ? *xs : XsIn{};
   a.prep = prep; a.prep_stride = prep_stride;
   a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.params = params; a.n_in = n_in; a.n_out = n_out;
@@ -350,9 +352,10 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
                          uint32_t n_hidden_layers, float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params,
                          float* ws, uint32_t n_slots, const int32_t* row_index, const int32_t* tile_group,
                          uint32_t param_stride, int acc1, int acc2, bool fp16_single, const unsigned char* prep, uint32_t prep_stride,
-                         bool with_dwin, const float* h_saved, const sp::XsIn* xs, hipStream_t st) {
+                         bool with_dwin, const float* h_saved, const sp::XsIn* xs, hipStream_t st, uint32_t n_in_w) {
   using namespace sp;
   BwdArgs a;
+  a.n_in_w = n_in_w ? n_in_w : n_in;
   a.xs = xs ? *xs : XsIn{};
   a.h_saved = h_saved;
   a.prep = prep; a.prep_stride = prep_stride;
@@ -382,18 +385,18 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
   if (rc != DNS_OK || !d_params || !with_dwin) return rc;
   // dW_in = dH_1^T X from the workspace the first kernel wrote
   return launch_mlp_dwin(x, ldx, x2, ldx2, n_in1, n_in, n_neurons, n_hidden_layers, d_params, ws, n_slots, row_index, tile_group,
-                         param_stride, fp16_single, st);
+                         param_stride, fp16_single, st, n_in_w);
 }
 
 // the streaming weight-gradient kernel of the first layer on its own (dns_mlp_dwin; the second half of dns_mlp_bwd)
 int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                     uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
-                    const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st) {
+                    const int32_t* tile_group, uint32_t param_stride, bool fp16_single, hipStream_t st, uint32_t n_in_w) {
   using namespace sp;
   (void)n_hidden_layers;
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   DwinArgs d;
-  d.dh1 = ws; d.x = x; d.ldx = ldx; d.seg = {x2, ldx2, x2 ? n_in1 : n_in}; d.n_in = n_in; d.d_params = d_params; d.n_slots = n_slots;
+  d.dh1 = ws; d.x = x; d.ldx = ldx; d.seg = {x2, ldx2, x2 ? n_in1 : n_in}; d.n_in = n_in; d.n_in_w = n_in_w ? n_in_w : n_in; d.d_params = d_params; d.n_slots = n_slots;
   d.row_index = row_index; d.tile_group = tile_group; d.param_stride = param_stride;
   uint32_t tpb2 = (n_btiles + 511u) / 512u;      // two workgroups per CU
   if (tpb2 < 1) tpb2 = 1;

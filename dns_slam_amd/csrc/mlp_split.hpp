@@ -141,10 +141,13 @@ struct ImgQuads {
   float4 v[MAXQ];
 };
 
+// ld: the matrix's row stride in memory (>= C; ld > C: only the first C columns of every row are the matrix -- DNS_MLP_LIVE_IN,
+// a first layer whose trailing input columns are identically zero)
 template <int MAXQ>
-__device__ __forceinline__ float image_load(ImgQuads<MAXQ>& q, const float* __restrict__ M, uint32_t R, uint32_t C) {
-  const uint32_t nq = R * (C >> 2);
-  const bool vec = (((uintptr_t)M) & 15u) == 0;
+__device__ __forceinline__ float image_load(ImgQuads<MAXQ>& q, const float* __restrict__ M, uint32_t R, uint32_t C, uint32_t ld = 0) {
+  if (ld == 0) ld = C;
+  const uint32_t qpr = C >> 2, nq = R * qpr;
+  const bool vec = ((((uintptr_t)M) & 15u) == 0) && ((ld & 3u) == 0);
   float m = 0.f;
   bool bad = false;
 #pragma unroll
@@ -152,7 +155,8 @@ __device__ __forceinline__ float image_load(ImgQuads<MAXQ>& q, const float* __re
     const uint32_t e = threadIdx.x + j * blockDim.x;
     q.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < nq) {
-      const float* src = M + (size_t)e * 4u;
+      const uint32_t rr = e / qpr;
+      const float* src = M + (size_t)rr * ld + (size_t)(e - rr * qpr) * 4u;
       if (vec) q.v[j] = *reinterpret_cast<const float4*>(src);
       else q.v[j] = make_float4(src[0], src[1], src[2], src[3]);
     }
@@ -729,7 +733,9 @@ struct FwdLds {
 
 // the forward kernel's prologue: the three weight matrices of one weight set -> scaled f16 hi/lo operand images in LDS
 template <int NN, int NL>
-__device__ __forceinline__ void build_fwd_images(unsigned char* lds, const float* __restrict__ pw, uint32_t n_in, uint32_t n_out) {
+__device__ __forceinline__ void build_fwd_images(unsigned char* lds, const float* __restrict__ pw, uint32_t n_in, uint32_t n_out,
+                                                 uint32_t n_in_w = 0) {
+  if (n_in_w == 0) n_in_w = n_in;                                 // storage width of W_in's rows (> n_in: DNS_MLP_LIVE_IN)
   using L = FwdLds<NN, NL>;
   constexpr int NT = NN / 32;
   const uint32_t ns0 = L::ns0(n_in), mt = L::mt(n_out);
@@ -738,11 +744,11 @@ __device__ __forceinline__ void build_fwd_images(unsigned char* lds, const float
   _Float16* img_out = reinterpret_cast<_Float16*>(lds + L::img_out(n_in));
   int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
   float* red = reinterpret_cast<float*>(lds + L::misc(n_in, n_out) + 64);
-  const float* wh = pw + NN * n_in;
+  const float* wh = pw + NN * n_in_w;
   const float* wout = wh + (NL - 1) * NN * NN;
   ImgQuads<8> q_in;                                              // 64 x 128 / 4 / 256 threads
   ImgQuads<4> q_h, q_out;
-  const float m_in = image_load(q_in, pw, NN, n_in);
+  const float m_in = image_load(q_in, pw, NN, n_in, n_in_w);
   const float m_h = (NL == 2) ? image_load(q_h, wh, NN, NN) : 0.f;
   const float m_out = image_load(q_out, wout, n_out, NN);
   lds_zero16(lds, L::misc(n_in, n_out));
@@ -775,6 +781,7 @@ struct BwdArgs {
   uint32_t prep_stride;                      // bytes per weight set
   XsIn xs;                                   // split-row input (xs.s1.rows != NULL: x / seg are unused)
   uint32_t n_waves;                          // waves per workgroup the launcher planned the grid for (4, or 8: frozen-scene form)
+  uint32_t n_in_w;                           // storage width of W_in's rows (= n_in, or larger with DNS_MLP_LIVE_IN)
 #ifdef DNS_BWD_TRACE
   unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
 #endif

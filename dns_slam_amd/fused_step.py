@@ -87,10 +87,19 @@ class MapStep:
         shp = lambda n: (n.n_input_dims, n.n_output_dims, n.n_neurons, n.n_hidden_layers)
         self.shp_c, self.shp_col, self.shp_log = (shp(n) for n in nets)
         self.shp_f = (self.pe_dim + self.grid_dim, self.hid + 1, pool.nn_, pool.nl)
-        self.n_feat = self.hid + (self.hid if (features is None or self.stem) else self.features.shape[-1])
-        if not (self.pe_dim % 4 == 0 and self.pe_dim <= 64 and self.n_feat <= 64 and self.n_feat % 4 == 0
-                and self.shp_col[0] == self.pe_dim + self.n_feat):
+        # width of the colour / logit networks' second input segment: (fine latents | 2-D code).  WITHOUT a code (features None:
+        # the reference multiplies a zero code through, slams/mapping.py:553-557) the code columns are identically zero: the
+        # block is only the latents and the networks run with DNS_MLP_LIVE_IN -- their zero input columns are neither stored,
+        # read nor multiplied (K 112 -> 80 in the first layer, no dX / dW_in work for them)
+        code_dim = self.hid if self.stem else (0 if features is None else self.features.shape[-1])
+        n_feat_full = self.shp_col[0] - self.pe_dim
+        self.n_feat = self.hid + code_dim
+        if not (self.pe_dim % 4 == 0 and self.pe_dim <= 64 and n_feat_full <= 64 and self.n_feat % 4 == 0
+                and (self.n_feat == n_feat_full or code_dim == 0) and self.shp_log[0] == self.shp_col[0]):
             raise ValueError("MapStep: network shapes outside the two-segment input form (ops.render_nets has the same limits)")
+        self.live = ops.MLP_LIVE_IN(self.pe_dim + self.n_feat) if self.n_feat < n_feat_full else 0
+        if self.live and keep_hidden:                  # (the saved-activation backward takes full-width rows)
+            self.n_feat, self.live = n_feat_full, 0
         self.n_class = self.shp_log[1]
 
         # ---- poses: one [K,4] / [K,3] pair is the parameter; frame 0 stays fixed when K > 1 (slams/mapping.py:447-455)
@@ -174,6 +183,8 @@ class MapStep:
         if split_rows is None:
             split_rows = os.environ.get("DNS_SPLIT_ROWS", "0") == "1"
         self.sr = bool(split_rows) and ld % 16 == 0 and self.pe_dim % 16 == 0 and self.n_feat % 16 == 0 and not keep_hidden
+        if self.sr and self.live:                      # the split-row entry points take full-width rows: keep the zero code columns
+            self.n_feat, self.live = self.shp_col[0] - self.pe_dim, 0
         self.sr_planes = 1 if self.fp16 else 2           # half-width networks read the hi plane only
         self.sr_flags = 1 if self.fp16 else 0            # DNS_SPLIT_HI_ONLY
         if self.sr:
@@ -511,7 +522,8 @@ class MapStep:
                                             y.stride(0), n_slots, ptr(ri), ptr(tg), stride, fp16, st), "dns_mlp_fwd_split")
                 return
             check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
-                                  nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(hs), fp16, st), "dns_mlp_fwd")
+                                  nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(hs),
+                                  fp16 | (0 if x2 is None else self.live), st), "dns_mlp_fwd")
 
         fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0, self.h_c)
         fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
@@ -570,6 +582,7 @@ class MapStep:
 
         def bwd(x2, n_in1, dy, params, shape, d_x2, d_p, ri, tg, n_slots, stride, acc, hs):
             n_in, n_out, nn, nl = shape
+            live = 0 if x2 is None else self.live
             ws = self.ws_mlp4[nws[0]] if fork_dwin else self.ws_mlp
             nws[0] += 1
             if sr:
@@ -578,12 +591,12 @@ class MapStep:
                                             ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg), stride, acc | fp16, st), "dns_mlp_bwd_split")
                 if not fork_dwin:
                     check(lib.dns_mlp_dwin(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, n_in, nn, nl, ptr(d_p),
-                                           ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16, st), "dns_mlp_dwin")
+                                           ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16 | live, st), "dns_mlp_dwin")
             else:
                 check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
                                       ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
                                       0 if d_x2 is None else d_x2.stride(0), ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg),
-                                      stride, ptr(hs), acc | fp16 | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
+                                      stride, ptr(hs), acc | fp16 | live | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
             if fork_dwin:
                 # dW_in = dH_1^T x (memory-bound, needs only what this launch left in ws) on the side stream, beside the next
                 # network's vector-bound backward kernel
@@ -592,7 +605,7 @@ class MapStep:
                 self.side.wait_event(ev)
                 with torch.cuda.stream(self.side):
                     check(lib.dns_mlp_dwin(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, n_in, nn, nl, ptr(d_p),
-                                           ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16, side_st), "dns_mlp_dwin")
+                                           ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16 | live, side_st), "dns_mlp_dwin")
 
         d_feat = self.d_featx[:, 4:]
         bwd(None, 0, self.d_coarse, self.p_coarse, self.shp_c, None, cur.g_coarse, None, None, P, 0, 0, self.h_c)

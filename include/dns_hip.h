@@ -232,6 +232,14 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * [0, n_in1) -- is produced; d_x2 may be NULL and the products of the second segment's columns are skipped (Decoder.merge: the
  * OneBlob columns carry the pose gradient, the looked-up image code has none, models/decoder.py:70-74). */
 #define DNS_MLP_DX_FIRST 0x800u
+/* DNS_MLP_LIVE_IN(n) (bits 16-23 of the flags of dns_mlp_fwd / dns_mlp_dwin and of accumulate_dx of dns_mlp_bwd; ABI v9): input
+ * columns [n, n_in) are IDENTICALLY ZERO for every row of this call -- the reference's colour / logit networks when no 2-D feature
+ * code is attached (slams/mapping.py:553-557 multiplies a zero code: BASELINE configs 1, 2, 4, 5).  The kernels then run as an
+ * n-input network on the same parameter tensor (W_in keeps its row stride n_in): the zero columns are not read (x2 needs only
+ * n - n_in1 columns), their K-steps are skipped, no d_x / d_x2 is produced for them and their columns of dW_in receive nothing
+ * (their exact gradient is zero).  n: a multiple of 8 with n_in1 < n <= n_in.  Same results as the full-width call on rows padded
+ * with zeros up to fp32 rounding (W_in's power-of-two operand scale is taken over its live columns). */
+#define DNS_MLP_LIVE_IN(n) ((uint32_t)(n) << 16)
 int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                  uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
                  const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);

@@ -793,3 +793,60 @@ def test_mlp_dwin_alone_equals_the_backward_with_it():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert float(res[1][2][:nn * n_in].abs().max()) > 0
     assert_close(res[1][2].cpu(), res[0][2].cpu(), rtol=1e-5, elementwise=False, what="dW with dns_mlp_dwin launched separately")
+
+
+@pytest.mark.parametrize("nn,nl,n_out,two", [(64, 2, 3, True), (32, 1, 8, True), (64, 2, 33, False)])
+def test_mlp_live_input_columns_equal_zero_padded_rows(nn, nl, n_out, two):
+    """DNS_MLP_LIVE_IN(n): the trailing input columns [n, n_in) are identically zero (the reference's colour / logit networks when
+    no 2-D feature code is attached, slams/mapping.py:553-557).  The kernels run as an n-input network on the same parameter
+    tensor: against the full-width call on zero-padded rows -- forward, dX of the live columns, the dH_1 workspace, all weight
+    gradients (dW_in: zero in the dead columns) -- to fp32 rounding."""
+    import ctypes as C
+    ops = _ops()
+    from dns_slam_amd._lib import check, ptr, stream_ptr
+    lib = ops.lib
+    g = torch.Generator().manual_seed(31)
+    P = 3000
+    n_in, n1 = (112, 48) if two else (96, 0)
+    live = 80
+    count = ops.mlp_param_count(n_in, n_out, nn, nl)
+    params = (torch.randn(count, generator=g) * 0.2).to(DEV)
+    x_full = torch.randn(P, n_in, generator=g)
+    x_full[:, live:] = 0.0
+    dy = torch.randn(P, n_out, generator=g).to(DEV)
+    if two:
+        a_full = torch.zeros(P, 80)
+        a_full[:, :n1] = x_full[:, :n1]
+        b_full, b_live = x_full[:, n1:].contiguous(), x_full[:, n1:live].contiguous()
+        xa, xb_full, xb_live = a_full.to(DEV), b_full.to(DEV), b_live.to(DEV)
+    else:
+        xa, xa_live = x_full.to(DEV), x_full[:, :live].contiguous().to(DEV)
+    outs = []
+    for use_live in (False, True):
+        flag = ops.MLP_LIVE_IN(live) if use_live else 0
+        y = torch.zeros(P, n_out, device=DEV)
+        ws = torch.zeros(P * nn, device=DEV)
+        dp = torch.zeros_like(params)
+        if two:
+            xb = xb_live if use_live else xb_full
+            dxa, dxb = torch.zeros(P, 80, device=DEV), torch.zeros_like(xb)
+            check(lib.dns_mlp_fwd(ptr(xa), 80, ptr(xb), xb.shape[1], n1, ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, P, None, None, 0,
+                                  None, flag, stream_ptr()), "fwd")
+            check(lib.dns_mlp_bwd(ptr(xa), 80, ptr(xb), xb.shape[1], n1, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(dxa), 80,
+                                  ptr(dxb), xb.shape[1], ptr(dp), ptr(ws), P, None, None, 0, None, flag, stream_ptr()), "bwd")
+            res = [y, dxa[:, :n1], dxb[:, :live - n1], ws, dp]
+        else:
+            x = xa_live if use_live else xa
+            dx = torch.zeros_like(x)
+            check(lib.dns_mlp_fwd(ptr(x), x.shape[1], None, 0, 0, ptr(params), n_in, n_out, nn, nl, ptr(y), n_out, P, None, None, 0, None,
+                                  flag, stream_ptr()), "fwd")
+            check(lib.dns_mlp_bwd(ptr(x), x.shape[1], None, 0, 0, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(dx), x.shape[1],
+                                  None, 0, ptr(dp), ptr(ws), P, None, None, 0, None, flag, stream_ptr()), "bwd")
+            res = [y, dx[:, :live], ws, dp]
+        outs.append(res)
+    torch.cuda.synchronize()
+    for a, b in zip(outs[1], outs[0]):
+        assert float(b.abs().max()) > 0
+        assert_close(a.cpu(), b.cpu(), rtol=1e-5, elementwise=False, what="live input columns vs zero-padded rows")
+    w_in = outs[1][-1][:nn * n_in].reshape(nn, n_in)
+    assert float(w_in[:, live:].abs().max()) == 0.0 and float(w_in[:, :live].abs().max()) > 0
