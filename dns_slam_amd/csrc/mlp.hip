@@ -76,8 +76,10 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                            void* stream) {
   if (n_slots == 0) return DNS_OK;
   DNS_REQUIRE(x && dy && params, "dns_mlp_bwd: NULL argument");
-  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN | (int)DNS_MLP_DX_FIRST | 0xff0000)) == 0,
+  DNS_REQUIRE((accumulate_dx & ~(3 | (int)DNS_MLP_FP16 | (int)DNS_MLP_PREPARED | (int)DNS_MLP_NO_DWIN | (int)DNS_MLP_DX_FIRST | 0x7fff0000)) == 0,
               "dns_mlp_bwd: unknown accumulate_dx bits 0x%x", accumulate_dx);
+  const uint32_t dx_from = ((uint32_t)accumulate_dx >> 24) & 0x7fu;
+  DNS_REQUIRE(dx_from % 4 == 0 && dx_from < n_in, "dns_mlp_bwd: DNS_MLP_DX_FROM(%u) must be a multiple of 4 below n_in", dx_from);
   const uint32_t n_live = live_in((uint32_t)accumulate_dx, n_in, n_in1, x2 != nullptr);
   DNS_REQUIRE(n_live != 0 && (n_live == n_in || (!(accumulate_dx & (int)DNS_MLP_PREPARED) && !h_saved)),
               "dns_mlp_bwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in], not with DNS_MLP_PREPARED / h_saved)");
@@ -103,7 +105,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   const int rc = ensure_ready(st, "dns_mlp_bwd");
   if (rc != DNS_OK) return rc;
   return launch_mlp_bwd_split(x, ldx, x2, ldx2, n_in1, dy, lddy, params, n_live, n_out, n_neurons, n_hidden_layers, d_x, lddx,
-                              d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride, accumulate_dx & 1,
+                              d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride,
+                              (accumulate_dx & 1) | (int)(dx_from << 8),
                               (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
                               prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
                                        : nullptr,

@@ -364,7 +364,7 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
 #endif
   a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.dy = dy; a.lddy = lddy; a.params = params;
   a.n_in = n_in; a.n_out = n_out; a.dx = d_x; a.lddx = lddx;
-  a.dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)acc1, (uint32_t)acc2};
+  a.dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)acc1 & 1u, (uint32_t)acc2, (uint32_t)acc1 >> 8};   // (col_lo rides in acc1's upper bits)
   a.d_params = d_params; a.dh1 = d_params ? ws : nullptr;
   a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
   // Without weight gradients (the tracker's frozen scene; a network without a weight-set table) the kernel has no persistent

@@ -568,6 +568,7 @@ __device__ __forceinline__ void layer_chain(const f32x16 (&act)[NT_IN], float f,
 struct DxSeg {
   float* dx2;
   uint32_t lddx2, acc1, acc2;                // acc: read-add-write instead of overwrite
+  uint32_t col_lo;                           // input-gradient columns below this one have no consumer: not stored (DNS_MLP_DX_FROM)
 };
 
 // The values a read-add-write store of store_tile_rows_vec will add to: requested EARLY (all input-gradient tiles of a
@@ -592,7 +593,7 @@ __device__ __forceinline__ void dx_old_issue(DxOld& o, const float* __restrict__
   for (int i = 0; i < 4; ++i) {
     const int row = rows_lds[rr + 8 * i];
     o.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (acc && row >= 0 && c4 < ncols) {
+    if (acc && row >= 0 && c4 < ncols && col >= seg.col_lo) {
       const float4* p = second ? reinterpret_cast<const float4*>(seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1))
                                : reinterpret_cast<const float4*>(dst1 + (size_t)row * ld1 + col);
       o.v[i] = *p;
@@ -616,7 +617,7 @@ __device__ __forceinline__ void store_tile_rows_vec(float* __restrict__ dst1, ui
     const uint32_t r = rr + 8 * i;
     const int row = rows_lds[r];
     float4 v = *reinterpret_cast<const float4*>(stg + r * STG_LD + c4);
-    if (row >= 0 && c4 < ncols) {
+    if (row >= 0 && c4 < ncols && col0 + c4 >= seg.col_lo) {
       const uint32_t col = col0 + c4;
       const bool second = seg.dx2 != nullptr && col >= n_in1;
       float4* p = second ? reinterpret_cast<float4*>(seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1))
@@ -645,7 +646,7 @@ __device__ __forceinline__ void store_tile_rows_scalar_acc(float* __restrict__ d
     const uint32_t r = (lane >> 5) + 2 * i;
     const int row = rows_lds[r];
     float v = stg[r * STG_LD + f];
-    if (row >= 0 && f < ncols) {
+    if (row >= 0 && f < ncols && col0 + f >= seg.col_lo) {
       const uint32_t col = col0 + f;
       const bool second = seg.dx2 != nullptr && col >= n_in1;
       float* p = second ? seg.dx2 + (size_t)row * seg.lddx2 + (col - n_in1) : dst1 + (size_t)row * ld1 + col;

@@ -371,9 +371,10 @@ class MapStep:
             check(lib.dns_mlp_dwin(ptr(self.bufl), ld, None, 0, 0, n_in, nn, nl, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None,
                                    0, self.fp16, st), "dns_mlp_dwin")
         else:
+            # (the lattice points carry no pose: only the grid columns' input gradient has a consumer, the table scatter)
             check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
                                   ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, ptr(self.h_l),
-                                  self.fp16, st), "dns_mlp_bwd")
+                                  self.fp16 | (0 if self.h_l is not None else ops.MLP_DX_FROM(pe)), st), "dns_mlp_bwd")
         d_grid_l = _V(self.d_bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
                                  ptr(cur.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),

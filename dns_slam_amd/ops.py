@@ -244,6 +244,7 @@ MLP_FP16_FLAG = 0x100                      # include/dns_hip.h DNS_MLP_FP16
 MLP_PREPARED_FLAG = 0x200                  # include/dns_hip.h DNS_MLP_PREPARED
 MLP_NO_DWIN_FLAG = 0x400                   # include/dns_hip.h DNS_MLP_NO_DWIN
 MLP_DX_FIRST_FLAG = 0x800                  # include/dns_hip.h DNS_MLP_DX_FIRST
+MLP_DX_FROM = lambda c: int(c) << 24       # include/dns_hip.h DNS_MLP_DX_FROM(c): no input gradient for columns [0, c)
 MLP_LIVE_IN = lambda n: int(n) << 16       # include/dns_hip.h DNS_MLP_LIVE_IN(n): input columns [n, n_in) are identically zero
 
 

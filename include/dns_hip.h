@@ -240,6 +240,10 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * (their exact gradient is zero).  n: a multiple of 8 with n_in1 < n <= n_in.  Same results as the full-width call on rows padded
  * with zeros up to fp32 rounding (W_in's power-of-two operand scale is taken over its live columns). */
 #define DNS_MLP_LIVE_IN(n) ((uint32_t)(n) << 16)
+/* DNS_MLP_DX_FROM(c) (bits 24-30 of accumulate_dx of dns_mlp_bwd): the input gradient of columns [0, c) has no consumer -- it is
+ * neither formed (whole 32-column tiles) nor stored.  The smoothness lattice's coarse network (slams/mapping.py:129-159) needs
+ * the hash-grid columns' gradient only: its points carry no pose.  c: a multiple of 4 below n_in. */
+#define DNS_MLP_DX_FROM(c) ((uint32_t)(c) << 24)
 int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, uint32_t n_neurons,
                  uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
                  const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);

@@ -850,3 +850,27 @@ def test_mlp_live_input_columns_equal_zero_padded_rows(nn, nl, n_out, two):
         assert_close(a.cpu(), b.cpu(), rtol=1e-5, elementwise=False, what="live input columns vs zero-padded rows")
     w_in = outs[1][-1][:nn * n_in].reshape(nn, n_in)
     assert float(w_in[:, live:].abs().max()) == 0.0 and float(w_in[:, :live].abs().max()) > 0
+
+
+def test_mlp_bwd_dx_from_skips_the_leading_columns():
+    """DNS_MLP_DX_FROM(c): input-gradient columns [0, c) are neither formed nor stored (the smoothness lattice's coarse network needs
+    the grid columns only); the others, the workspace and the weight gradients are what the plain call gives."""
+    ops = _ops()
+    from dns_slam_amd._lib import check, ptr, stream_ptr
+    lib = ops.lib
+    g = torch.Generator().manual_seed(41)
+    P, n_in, n_out, nn, nl = 2500, 80, 1, 64, 2
+    params = (torch.randn(ops.mlp_param_count(n_in, n_out, nn, nl), generator=g) * 0.2).to(DEV)
+    x = torch.randn(P, n_in, generator=g).to(DEV)
+    dy = torch.randn(P, n_out, generator=g).to(DEV)
+    res = []
+    for flag in (0, ops.MLP_DX_FROM(48)):
+        dx = torch.full((P, n_in), -7.0, device=DEV)
+        ws, dp = torch.zeros(P * nn, device=DEV), torch.zeros_like(params)
+        check(lib.dns_mlp_bwd(ptr(x), n_in, None, 0, 0, ptr(dy), n_out, ptr(params), n_in, n_out, nn, nl, ptr(dx), n_in, None, 0, ptr(dp),
+                              ptr(ws), P, None, None, 0, None, flag, stream_ptr()), "bwd")
+        res.append((dx, ws, dp))
+    torch.cuda.synchronize()
+    (dx0, ws0, dp0), (dx1, ws1, dp1) = res
+    assert torch.equal(dx1[:, 48:], dx0[:, 48:]) and bool((dx1[:, :48] == -7.0).all()) and torch.equal(ws0, ws1)
+    assert_close(dp1.cpu(), dp0.cpu(), rtol=1e-5, elementwise=False, what="DX_FROM: dW")
