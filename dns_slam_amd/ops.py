@@ -48,9 +48,13 @@ class _TimedLib:
         return timed
 
     # per-call facts the roofline needs: the network shape of an MLP launch and which gradients it produces
-    _INFO = {"dns_mlp_fwd": lambda a: {"n_in": a[6], "n_out": a[7], "nn": a[8], "nl": a[9]},
-             "dns_mlp_dwin": lambda a: {"n_in": a[5], "n_out": 0, "nn": a[6], "nl": a[7]},
-             "dns_mlp_bwd": lambda a: {"n_in": a[8], "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]), "dw": bool(a[16])},
+    # (n_in = the LIVE input width: with DNS_MLP_LIVE_IN the kernels skip the identically-zero columns, and the roofline counts
+    #  the work that is done, not the multiplications by zero the reference's full-width GEMM performs)
+    _live = staticmethod(lambda n_in, flags: ((int(flags) >> 16) & 0xff) or n_in)
+    _INFO = {"dns_mlp_fwd": lambda a: {"n_in": _TimedLib._live(a[6], a[17]), "n_out": a[7], "nn": a[8], "nl": a[9]},
+             "dns_mlp_dwin": lambda a: {"n_in": _TimedLib._live(a[5], a[14]), "n_out": 0, "nn": a[6], "nl": a[7]},
+             "dns_mlp_bwd": lambda a: {"n_in": _TimedLib._live(a[8], a[23]), "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]),
+                                       "dw": bool(a[16])},
              "dns_mlp_fwd_split": lambda a: {"n_in": a[4], "n_out": a[5], "nn": a[6], "nl": a[7]},
              "dns_mlp_bwd_split": lambda a: {"n_in": a[6], "n_out": a[7], "nn": a[8], "nl": a[9], "dx": bool(a[10]), "dw": bool(a[14])}}
 
