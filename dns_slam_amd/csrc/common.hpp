@@ -13,7 +13,6 @@ void set_error(const char* fmt, ...);
 // Sticky per-device error word in pinned host memory (host.cpp): kernels that consume device counters set a bit instead of
 // storing out of bounds; poll_device_error() is a plain host read, no synchronisation.
 constexpr uint32_t DNS_DEVERR_GROUP_CURSOR = 1u;
-constexpr uint32_t DNS_DEVERR_MLP_HANDSHAKE = 2u;   // the producer / consumer backward gave up a spin wait (mlp_split_bwd.inc)
 uint32_t* device_error_word();               // device-visible pointer for kernel arguments (NULL before dns_init)
 int poll_device_error(const char* what);     // DNS_OK, or DNS_E_LAUNCH + message while the word is non-zero
 

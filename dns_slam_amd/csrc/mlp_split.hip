@@ -1,6 +1,5 @@
 // Forward kernel, dW_in kernel and the host-side launchers of the split-operand MLP (device helpers: mlp_split.hpp; the
 // backward kernel: mlp_split_bwd.inc, one translation unit per (n_neurons, n_hidden_layers)).
-#include <stdlib.h>
 #include "mlp_split.hpp"
 
 namespace dns {
@@ -372,9 +371,6 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
   // accumulators and runs with EIGHT waves per workgroup -- two per SIMD on one set of LDS weight images: 1.28-1.37x
   const bool wide = !d_params && !tile_group && !h_saved;
   a.n_waves = wide ? 8u : 4u;
-  a.ring = 1u;
-  a.err = device_error_word();
-  { static const uint32_t dbg = [] { const char* e = getenv("DNS_MLP_PC_DBG"); return e ? (uint32_t)atoi(e) : 0u; }(); a.dbg = dbg; }
   const uint32_t bt_slots = 32u * a.n_waves;
   const uint32_t n_btiles = (n_slots + bt_slots - 1u) / bt_slots;
   uint32_t tpb = (n_btiles + 255u) / 256u;       // one workgroup of 4 waves per CU, contiguous tile ranges

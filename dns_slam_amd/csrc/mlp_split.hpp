@@ -783,10 +783,6 @@ struct BwdArgs {
   XsIn xs;                                   // split-row input (xs.s1.rows != NULL: x / seg are unused)
   uint32_t n_waves;                          // waves per workgroup the launcher planned the grid for (4, or 8: frozen-scene form)
   uint32_t n_in_w;                           // storage width of W_in's rows (= n_in, or larger with DNS_MLP_LIVE_IN)
-  uint32_t ring;                             // (producer / consumer form) tile slots per pair's ring: 1 or 2
-  uint32_t* err;                             // the device error word (host-pinned), NULL before dns_init
-  uint32_t dbg;                              // measurement knobs of the producer / consumer form (DNS_MLP_PC_DBG): 1 = the consumer
-                                             // drains messages without splitting / multiplying, 2 = no messages at all
 #ifdef DNS_BWD_TRACE
   unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
 #endif
@@ -826,27 +822,20 @@ DNS_DECL_PREP(64, 2)
 
 // adds the workgroup's four copies of one 32 x 32 accumulator tile (rows = dW rows, lanes = dW columns) and issues the
 // float atomics: one 128-byte row segment per lane half per instruction
-// (wave = the accumulating wave's index 0..3; active = false: a wave of the workgroup that holds no accumulators -- the producers
-//  of the producer / consumer backward -- only takes part in the two barriers)
 __device__ __forceinline__ void flush_tile(const f32x16& a, float* __restrict__ dst, uint32_t ld, uint32_t rows_valid,
-                                           uint32_t cols_valid, float* __restrict__ stg_base, uint32_t wave, uint32_t lane,
-                                           bool active = true) {
+                                           uint32_t cols_valid, float* __restrict__ stg_base, uint32_t wave, uint32_t lane) {
   float* stg = stg_base + wave * STG_WAVE_FLOATS;
   const uint32_t j = lane & 31u, h = lane >> 5;
-  if (active) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * STG_LD + j] = a[r];
-  }
+  for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * STG_LD + j] = a[r];
   __syncthreads();
-  if (active) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t row = wave * 8u + 2u * i + h;
-      float v = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = wave * 8u + 2u * i + h;
+    float v = 0.f;
 #pragma unroll
-      for (uint32_t w = 0; w < 4u; ++w) v += stg_base[w * STG_WAVE_FLOATS + row * STG_LD + j];
-      if (row < rows_valid && j < cols_valid && v != 0.f) atomicAdd(dst + (size_t)row * ld + j, v);
-    }
+    for (uint32_t w = 0; w < 4u; ++w) v += stg_base[w * STG_WAVE_FLOATS + row * STG_LD + j];
+    if (row < rows_valid && j < cols_valid && v != 0.f) atomicAdd(dst + (size_t)row * ld + j, v);
   }
   __syncthreads();
 }
