@@ -578,6 +578,7 @@ struct BinPlan {
   uint32_t n_levels;
   uint32_t chunk_rows;                    // rows per chunk
   uint32_t strided_dense;                 // dense levels: one contiguous run of points per thread
+  uint32_t dense_runs;                    // ... whose per-cell sums are kept in registers until the cell changes
   uint32_t job_prefix[DNS_MAX_LEVELS + 1];  // prefix sum over levels of chunks[l] * slices[l]
   uint32_t group_prefix[DNS_MAX_LEVELS + 1];  // prefix sum over levels of slices[l]: a group = one (level, slice)
   uint32_t xcd_major;                     // 1: blockIdx -> (xcd = b % 8, q = b / 8), a group's chunks adjacent in q
@@ -694,6 +695,13 @@ __device__ __forceinline__ long long fixed_rn(float v) {
   const float lo_f = fmaf(-hi_f, 65536.0f, v);
   const int hi = (int)hi_f, lo = (int)rintf(lo_f);
   return ((long long)hi << 16) + (long long)lo;
+}
+
+// the same for |v| < 2^51 through the float64 adder: v + 1.5 * 2^52 has v's nearest integer (ties to even) in its low mantissa
+// bits; subtracting the constant's bit pattern leaves it as a two's-complement 64-bit integer (4 instructions instead of 11)
+__device__ __forceinline__ unsigned long long fixed_rn_f64(float v) {
+  const double d = (double)v + 6755399441055744.0;
+  return (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
 }
 
 __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* __restrict__ xin, uint32_t P,
@@ -854,6 +862,73 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
       }
     }
   };
+  // Dense levels, strided walk: a thread's consecutive points are consecutive samples of a ray (or Morton neighbours of the
+  // lattice) and stay in one cell for a while on these coarse levels, and near a camera a thousand rays share a handful of
+  // cells -- per-point atomics pile many deep on single LDS addresses (measured: the four dense levels of the 16-level grid cost
+  // 76 us of the launch).  The thread keeps the 8 corners x 2 features of its CURRENT cell in float64 registers and adds them to
+  // the bins when the cell changes: one set of atomics per run instead of per point, with few lanes active at a time.
+  auto sweep_dense_runs = [&]() {
+    const uint32_t res2 = res * res;
+    uint32_t cur = 0xffffffffu;                  // row of the current cell's corner (0, 0, 0); a live cell never has this value
+    bool in_range = false;
+    double acc[8][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c][0] = acc[c][1] = 0.0;
+    auto flush = [&]() {
+#pragma unroll
+      for (uint32_t c = 0; c < 8; ++c) {
+        uint32_t idx = cur + (c & 1u) + ((c >> 1) & 1u) * res + (c >> 2) * res2;
+        if (idx >= size) idx %= size;
+        const uint32_t local = idx - base;
+        if (local < rows) {
+          atomicAdd(dbins + 2 * local, acc[c][0]);
+          atomicAdd(dbins + 2 * local + 1, acc[c][1]);
+        }
+        acc[c][0] = acc[c][1] = 0.0;
+      }
+    };
+    for (uint32_t it = 0; it < n_it; ++it) {
+      const float2 gg = gg_n;
+      const float xc[3] = {xn[0], xn[1], xn[2]};
+      const bool live = point_of(it) < p_hi;
+      gg_n = make_float2(0.f, 0.f);
+      if (it + 1 < n_it) {
+        const uint32_t pn = point_of(it + 1);
+        if (pn < p_hi) {
+          gg_n = dgl[pn];
+          xn[0] = xin[(size_t)pn * 3];
+          xn[1] = xin[(size_t)pn * 3 + 1];
+          xn[2] = xin[(size_t)pn * 3 + 2];
+        }
+      }
+      if (!(live && !(gg.x == 0.f && gg.y == 0.f))) continue;
+      float f[3];
+      uint32_t g[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
+        const float fl = floorf(pos);
+        g[a] = (uint32_t)(int)fl;
+        f[a] = pos - fl;
+      }
+      const uint32_t r000 = g[0] + g[1] * res + g[2] * res2;
+      if (r000 != cur) {
+        if (in_range) flush();
+        cur = r000;
+        // a cell none of whose rows can lie in this chunk (no wrap-around: the last row is below the level's size) is skipped whole
+        const uint32_t last = r000 + 1u + res + res2;
+        in_range = last >= size || (last >= base && r000 < base + rows);
+      }
+      if (!in_range) continue;
+#pragma unroll
+      for (uint32_t c = 0; c < 8; ++c) {
+        const float w = ((c & 1u) ? f[0] : 1.0f - f[0]) * ((c & 2u) ? f[1] : 1.0f - f[1]) * ((c & 4u) ? f[2] : 1.0f - f[2]);
+        acc[c][0] += (double)(w * gg.x);
+        acc[c][1] += (double)(w * gg.y);
+      }
+    }
+    if (in_range) flush();
+  };
   // Row replay: the level's 8 corner rows of every point were stored by dgrid_transpose_kernel (eight 16-bit values): a visit
   // is a 16-byte load, eight extract-and-compare steps and the three fractions for the weights -- no floor / convert / hash.
   auto sweep_replay = [&](const uint4* __restrict__ rl) {
@@ -909,6 +984,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_binned_kernel(const float* 
   };
   if (hashed && rows16 && rp.slot[l] >= 0) sweep_replay(rows16 + (size_t)rp.slot[l] * P);
   else if (hashed) sweep(std::true_type{});
+  else if (strided && plan.dense_runs) sweep_dense_runs();
   else sweep(std::false_type{});
   __syncthreads();
   float* out = d_table + 2 * ((size_t)lv.offset[l] + base);
@@ -956,7 +1032,7 @@ static Bound6 make_bound(const double* bound) {
 // T = 2^16, 262 k points: 141 + 122 us against ~190 us for the same levels binned) -- so the host picks this form from
 // 16 chunks per level up.  Queues are sized for the uniform-hash expectation plus slack; what does not fit goes straight
 // to d_table with float atomics (correct, merely slow: only reachable with adversarially clustered points).
-constexpr uint32_t PART_MAX_CHUNKS = 128;      // chunks per hashed level (T <= 2^20)
+constexpr uint32_t PART_MAX_CHUNKS = 256;      // chunks per level (8192-row chunks: T <= 2^21; the lists' 4096-row chunks: T <= 2^20)
 constexpr uint32_t PART_THREADS = 256;         // points per pass-1 workgroup
 constexpr uint32_t PART_ENTRIES = PART_THREADS * 8;
 
@@ -1124,18 +1200,349 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_queue_kernel(GridLevels lv,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Multi-chunk levels, PAIR-LIST form (round 4, DNS_SCATTER_LISTS).  The binned kernel's vector work is its chunk visits (every
+// point-level is hashed and tested once per chunk of its level, ~175 vector instructions per 64-point visit of which 32 lanes'
+// worth is useful), the queue form's cost is 24 bytes of traffic per corner.  Here pass 1 hashes every point-level once and
+// appends, per x-PAIR of corners (x, x + 1 at the same y, z: one chunk on a hashed level), ONE 32-bit word {point, pair} to the
+// list of the pair's chunk -- 16 bytes per point-level instead of 192 --, and pass 2 gives every lane one list entry: it fetches
+// the entry's point (12 + 8 bytes, consecutive entries are nearly consecutive points), forms the pair's two rows and weights
+// and adds into the chunk's float64 LDS bins -- no tests, no idle lanes.  A pair whose two rows straddle a chunk boundary (dense
+// levels only) is entered in both chunks; the consumer range-checks each corner.  A full list (clustered points on a dense
+// level) sends the pair straight to d_table with float atomics.
+constexpr uint32_t LIST_THREADS = 256;           // points per pass-1 workgroup
+constexpr uint32_t LIST_TILES = 8;               // 256-point tiles per pass-1 workgroup (<= 32: one bit each; DNS_LIST_TILES)
+
+struct ListPlan {
+  uint32_t n;                                  // levels handled by the pair-list form
+  uint32_t level[DNS_MAX_LEVELS];
+  uint32_t chunks[DNS_MAX_LEVELS];
+  uint32_t qoff[DNS_MAX_LEVELS + 1];           // first list of the level (prefix sum of chunks)
+  uint32_t cap[DNS_MAX_LEVELS];                // entries per list of the level
+  uint64_t qbase[DNS_MAX_LEVELS];              // word offset of the level's first list
+  uint32_t chunk_shift;                        // log2(rows per chunk) = 13
+  uint32_t slices;                             // pass-2 workgroups per list
+  uint32_t tiles;                              // 256-point tiles per pass-1 workgroup
+};
+
+// the two rows (level-relative) and weights of x-pair c (bit 0: y + 1, bit 1: z + 1) of a point
+struct PairRows {
+  uint32_t l0, l1;
+  float w0, w1;
+};
+__device__ __forceinline__ void pair_cell(const float xc[3], float s, uint32_t g[3], float f[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float pos = __fadd_rn(__fmul_rn(xc[a], s), 0.5f);
+    const float fl = floorf(pos);
+    g[a] = (uint32_t)(int)fl;
+    f[a] = pos - fl;
+  }
+}
+__device__ __forceinline__ void pair_rows_only(const uint32_t g[3], uint32_t c, bool hashed, uint32_t res, uint32_t size,
+                                               uint32_t& l0, uint32_t& l1) {
+  const uint32_t gy = g[1] + (c & 1u), gz = g[2] + ((c >> 1) & 1u);
+  if (hashed) {                                  // uniform per level
+    const uint32_t h = (gy * 2654435761u) ^ (gz * 805459861u);
+    l0 = (g[0] ^ h) & (size - 1u);
+    l1 = ((g[0] + 1u) ^ h) & (size - 1u);
+  } else {
+    uint32_t r = g[0] + gy * res + gz * res * res;
+    if (r >= size) r %= size;
+    l0 = r;
+    r = g[0] + 1u + gy * res + gz * res * res;
+    if (r >= size) r %= size;
+    l1 = r;
+  }
+}
+__device__ __forceinline__ PairRows pair_rows(const float xc[3], float s, uint32_t c, bool hashed, uint32_t res, uint32_t size) {
+  uint32_t g[3];
+  float f[3];
+  pair_cell(xc, s, g, f);
+  PairRows r;
+  pair_rows_only(g, c, hashed, res, size, r.l0, r.l1);
+  const float wyz = ((c & 1u) ? f[1] : 1.0f - f[1]) * ((c & 2u) ? f[2] : 1.0f - f[2]);
+  r.w0 = (1.0f - f[0]) * wyz;
+  r.w1 = f[0] * wyz;
+  return r;
+}
+
+__global__ __launch_bounds__(LIST_THREADS) void hashgrid_bwd_pairlist_kernel(const float* __restrict__ xin, uint32_t P,
+                                                                              GridLevels lv, ListPlan lp,
+                                                                              const float2* __restrict__ dg_t,
+                                                                              const uint32_t* __restrict__ gmax,
+                                                                              uint32_t* __restrict__ qcount,
+                                                                              uint32_t* __restrict__ lists,
+                                                                              float* __restrict__ d_table) {
+  // A workgroup takes LIST_TILES x 256 consecutive points of one level.  Sweep A counts its entries per chunk in LDS, the first
+  // wave then reserves one run per chunk in the global lists -- ONE atomic per chunk and 2048 points: a reservation per 256 points
+  // put 4096 same-address atomics per list behind each other and took longer than everything else --, sweep B forms the chunks
+  // again (two multiplies and a few xors per pair) and writes every entry at its run's next free slot.
+  __shared__ uint32_t cnt[PART_MAX_CHUNKS], gofs[PART_MAX_CHUNKS];
+  if (!(__uint_as_float(*gmax) > 0.f) || gmax[1] != 0u) return;   // all-zero or poisoned upstream gradient: pass 2 handles both
+  const uint32_t li = blockIdx.y;
+  const uint32_t l = lp.level[li], C = lp.chunks[li], cap = lp.cap[li];
+  const float s = lv.scale[l];
+  const uint32_t size = lv.size[l], res = lv.resolution[l];
+  const bool hashed = lv.hashed[l] != 0;         // uniform
+  const float2* __restrict__ dgl = dg_t + (size_t)l * P;
+  const uint32_t p_base = blockIdx.x * (LIST_THREADS * lp.tiles) + threadIdx.x;
+  for (uint32_t i = threadIdx.x; i < C; i += LIST_THREADS) cnt[i] = 0;
+  __syncthreads();
+  uint32_t work_bits = 0;                        // bit t: the point of tile t carries a gradient
+#pragma unroll 2
+  for (uint32_t t = 0; t < lp.tiles; ++t) {
+    const uint32_t p = p_base + t * LIST_THREADS;
+    if (p >= P) break;
+    const float2 gg = dgl[p];
+    if (gg.x == 0.f && gg.y == 0.f) continue;
+    work_bits |= 1u << t;
+    const float xc[3] = {xin[(size_t)p * 3], xin[(size_t)p * 3 + 1], xin[(size_t)p * 3 + 2]};
+    uint32_t g[3];
+    float f[3];
+    pair_cell(xc, s, g, f);
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+      uint32_t l0, l1;
+      pair_rows_only(g, c, hashed, res, size, l0, l1);
+      const uint32_t c0 = l0 >> lp.chunk_shift, c1 = l1 >> lp.chunk_shift;
+      atomicAdd(&cnt[c0], 1u);
+      if (c1 != c0) atomicAdd(&cnt[c1], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < C; c += LIST_THREADS) {
+    const uint32_t v = cnt[c];
+    gofs[c] = v ? atomicAdd(&qcount[lp.qoff[li] + c], v) : 0u;
+    cnt[c] = 0;                                  // now the run's next free slot
+  }
+  __syncthreads();
+  uint32_t* __restrict__ ql = lists + lp.qbase[li];
+  float* __restrict__ tl = d_table + 2 * (size_t)lv.offset[l];
+#pragma unroll 2
+  for (uint32_t t = 0; t < lp.tiles; ++t) {
+    if (!((work_bits >> t) & 1u)) continue;
+    const uint32_t p = p_base + t * LIST_THREADS;
+    const float xc[3] = {xin[(size_t)p * 3], xin[(size_t)p * 3 + 1], xin[(size_t)p * 3 + 2]};
+    uint32_t g[3];
+    float f[3];
+    pair_cell(xc, s, g, f);
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+      uint32_t l0, l1;
+      pair_rows_only(g, c, hashed, res, size, l0, l1);
+      const uint32_t c0 = l0 >> lp.chunk_shift, c1 = l1 >> lp.chunk_shift;
+      const uint32_t at0 = gofs[c0] + atomicAdd(&cnt[c0], 1u);
+      const uint32_t at1 = c1 != c0 ? gofs[c1] + atomicAdd(&cnt[c1], 1u) : 0u;
+      const bool over0 = at0 >= cap, over1 = c1 != c0 && at1 >= cap;
+      if (!over0) ql[(size_t)c0 * cap + at0] = (p << 2) | c;
+      if (c1 != c0 && !over1) ql[(size_t)c1 * cap + at1] = (p << 2) | c;
+      if (over0 || over1) {                      // list full: the pair's corners in that chunk go straight to the table
+        const float2 gg = dgl[p];
+        const float wyz = ((c & 1u) ? f[1] : 1.0f - f[1]) * ((c & 2u) ? f[2] : 1.0f - f[2]);
+        const float w0 = (1.0f - f[0]) * wyz, w1 = f[0] * wyz;
+        if (over0) {
+          atomicAdd(tl + 2 * (size_t)l0, w0 * gg.x);
+          atomicAdd(tl + 2 * (size_t)l0 + 1, w0 * gg.y);
+        }
+        if (c1 == c0 ? over0 : over1) {
+          atomicAdd(tl + 2 * (size_t)l1, w1 * gg.x);
+          atomicAdd(tl + 2 * (size_t)l1 + 1, w1 * gg.y);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void hashgrid_bwd_pairbins_kernel(const float* __restrict__ xin, uint32_t P, GridLevels lv,
+                                                                      ListPlan lp, const float2* __restrict__ dg_t,
+                                                                      const uint32_t* __restrict__ qcount,
+                                                                      const uint32_t* __restrict__ lists,
+                                                                      const uint32_t* __restrict__ gmax,
+                                                                      float* __restrict__ d_table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
+  const float mx = __uint_as_float(*gmax);
+  const bool poisoned = gmax[1] != 0u;           // NaN / Inf upstream: NaN into the list's rows (see the binned kernel)
+  if (!(mx > 0.f) && !poisoned) return;          // all-zero upstream gradient (uniform exit)
+  // 64-bit FIXED-POINT bins (|w g| * 2^(40 - ex) < 2^40, rounded to nearest: exact, order-independent sums with 2^24 entries of
+  // headroom): this kernel is bound by the LDS atomic unit, not by its vector instructions, and ds_add_u64 issues at 11.9 cycles
+  // per wave instruction against 21.6 for ds_add_f64 -- the conversion that lost in the (vector-bound) sweep form pays here
+  int ex;
+  (void)frexpf(mx, &ex);
+  const float scale = ldexpf(1.0f, 40 - ex);
+  const double inv_scale = (double)ldexpf(1.0f, ex - 40);
+  const uint32_t qi = blockIdx.x / lp.slices, slice = blockIdx.x % lp.slices;   // list = (level, chunk)
+  uint32_t li = 0;
+  while (li + 1 < lp.n && qi >= lp.qoff[li + 1]) ++li;
+  const uint32_t ch = qi - lp.qoff[li], l = lp.level[li], cap = lp.cap[li];
+  const uint32_t row0 = ch << lp.chunk_shift;
+  const uint32_t size = lv.size[l], res = lv.resolution[l];
+  const uint32_t rows = min(1u << lp.chunk_shift, size - row0);
+  if (poisoned) {                                // uniform
+    float* out = d_table + 2 * ((size_t)lv.offset[l] + row0);
+    if (slice == 0)
+      for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
+  const uint32_t n = min(qcount[qi], cap);
+  const uint32_t lo = (uint32_t)(((uint64_t)n * slice) / lp.slices), hi = (uint32_t)(((uint64_t)n * (slice + 1)) / lp.slices);
+  if (lo >= hi) return;                          // uniform per workgroup
+  const uint32_t* __restrict__ q = lists + lp.qbase[li] + (size_t)ch * cap;
+  const float2* __restrict__ dgl = dg_t + (size_t)l * P;
+  const float s = lv.scale[l];
+  const bool hashed = lv.hashed[l] != 0;         // uniform
+  // The loop is a chain of dependent memory round trips (entry -> point -> bins) on few waves per SIMD (one 128-KB workgroup per
+  // CU): every thread keeps U entries of a trip in flight together, two stages deep -- the entries of trip t + 2 and the points of
+  // trip t + 1 are requested while trip t computes.
+  constexpr uint32_t U = 4;
+  // Lane <-> entry.  A list is in point order; on a DENSE level consecutive samples of a ray share a cell, hence a pair's two rows,
+  // and with consecutive entries on consecutive lanes a wave's atomics pile several deep on one address: there lane j of wave w
+  // takes entry j * n_waves + w of every round of blockDim.x entries (neighbouring lanes n_waves entries apart; the workgroup's
+  // waves share the lines they read).  Hashed levels keep the coalesced order (measured 20 % faster there).
+  const uint32_t nt = blockDim.x;
+  const uint32_t i0 = lo + (hashed ? threadIdx.x : (threadIdx.x & 63u) * (nt >> 6) + (threadIdx.x >> 6));
+  uint32_t e_n[U], e_nn[U];
+  float xn[U][3];
+  float2 gn[U];
+#pragma unroll
+  for (uint32_t u = 0; u < U; ++u) e_n[u] = (i0 + u * nt < hi) ? q[i0 + u * nt] : 0u;
+#pragma unroll
+  for (uint32_t u = 0; u < U; ++u) e_nn[u] = (i0 + (U + u) * nt < hi) ? q[i0 + (U + u) * nt] : 0u;
+#pragma unroll
+  for (uint32_t u = 0; u < U; ++u) {
+    const uint32_t pn = e_n[u] >> 2;             // 0 past the end: a valid point, never used
+    xn[u][0] = xin[(size_t)pn * 3];
+    xn[u][1] = xin[(size_t)pn * 3 + 1];
+    xn[u][2] = xin[(size_t)pn * 3 + 2];
+    gn[u] = dgl[pn];
+  }
+  // the bins are cleared while the first entries and points are on their way
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) bins[i] = 0ull;
+  __syncthreads();
+  for (uint32_t i = i0; i < hi; i += U * nt) {
+    uint32_t e[U];
+    float xc[U][3];
+    float2 gg[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      e[u] = e_n[u];
+      xc[u][0] = xn[u][0];
+      xc[u][1] = xn[u][1];
+      xc[u][2] = xn[u][2];
+      gg[u] = gn[u];
+      e_n[u] = e_nn[u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t pn = e_n[u] >> 2;
+      xn[u][0] = xin[(size_t)pn * 3];
+      xn[u][1] = xin[(size_t)pn * 3 + 1];
+      xn[u][2] = xin[(size_t)pn * 3 + 2];
+      gn[u] = dgl[pn];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) e_nn[u] = (i + (2u * U + u) * nt < hi) ? q[i + (2u * U + u) * nt] : 0u;
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      if (i + u * nt >= hi) break;
+      const PairRows r = hashed ? pair_rows(xc[u], s, e[u] & 3u, true, res, size) : pair_rows(xc[u], s, e[u] & 3u, false, res, size);
+      const uint32_t a0 = r.l0 - row0, a1 = r.l1 - row0;
+      if (a0 < rows) {
+        atomicAdd(bins + 2 * a0, fixed_rn_f64(r.w0 * gg[u].x * scale));
+        atomicAdd(bins + 2 * a0 + 1, fixed_rn_f64(r.w0 * gg[u].y * scale));
+      }
+      if (a1 < rows) {
+        atomicAdd(bins + 2 * a1, fixed_rn_f64(r.w1 * gg[u].x * scale));
+        atomicAdd(bins + 2 * a1 + 1, fixed_rn_f64(r.w1 * gg[u].y * scale));
+      }
+    }
+  }
+  __syncthreads();
+  float* out = d_table + 2 * ((size_t)lv.offset[l] + row0);
+  for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) {
+    const long long v = (long long)bins[i];
+    if (v != 0) atomicAdd(out + i, (float)((double)v * inv_scale));
+  }
+}
+
+static bool list_dense() {
+  static const bool v = [] { const char* e = getenv("DNS_LIST_DENSE"); return e && e[0] == '1'; }();
+  return v;
+}
+
+// Lists: 4 pairs per point-level spread over the level's chunks.  Hashed levels get the uniform-hash expectation + 1/8 slack,
+// dense levels (spatially clustered points) four times the expectation; what does not fit takes the atomics fallback.
+static uint32_t list_chunk_shift() {
+  static const uint32_t v = [] { const char* e = getenv("DNS_LIST_SHIFT"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 10 && n <= 13 ? n : 12); }();
+  return v;
+}
+
+static uint32_t list_threads(uint32_t shift) {
+  static const uint32_t v = [] { const char* e = getenv("DNS_LIST_THREADS"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 64 && n <= 1024 && n % 64 == 0 ? n : 0); }();
+  return v ? v : 1024u >> (13u - shift);
+}
+
+static bool list_plan(const GridLevels& lv, uint32_t P, uint32_t queue_cap, uint32_t target_jobs, ListPlan& lp) {
+  lp.n = 0;
+  lp.chunk_shift = list_chunk_shift();
+  uint32_t queues = 0;
+  uint64_t words = 0;
+  if (P >= (1u << 30)) return false;             // {point, pair} in 32 bits
+  for (uint32_t l = 0; l < lv.n_levels; ++l) {
+    const uint32_t chunks = (lv.size[l] + (1u << lp.chunk_shift) - 1u) >> lp.chunk_shift;
+    if (lv.size[l] <= 8192u || chunks > PART_MAX_CHUNKS) continue;   // one-chunk levels stay with the sweep
+    if (lv.hashed[l] && (lv.size[l] & (lv.size[l] - 1u))) continue;
+    if (!lv.hashed[l] && !list_dense()) continue;
+    const uint64_t expect = ((uint64_t)P * 4u + chunks - 1) / chunks;
+    uint64_t cap = (lv.hashed[l] ? expect + expect / 8u : 4u * expect) + 4096u;
+    if (cap > (uint64_t)P * 8u) cap = (uint64_t)P * 8u;          // a level emits at most 8 entries per point
+    if (queue_cap) cap = queue_cap;                               // caller-chosen capacity (tests: the overflow fallback)
+    cap = (cap + 3u) & ~3ull;
+    if (cap > 0x7FFFFFFFull) return false;
+    const uint32_t i = lp.n++;
+    lp.level[i] = l;
+    lp.chunks[i] = chunks;
+    lp.qoff[i] = queues;
+    lp.cap[i] = (uint32_t)cap;
+    lp.qbase[i] = words;
+    queues += chunks;
+    words += (uint64_t)chunks * cap;
+  }
+  lp.qoff[lp.n] = queues;
+  for (uint32_t i = lp.n; i < DNS_MAX_LEVELS; ++i) {
+    lp.level[i] = 0;
+    lp.chunks[i] = 0;
+    lp.cap[i] = 0;
+    lp.qbase[i] = words;
+    lp.qoff[i + 1] = queues;
+  }
+  if (!lp.n) return false;
+  lp.slices = (target_jobs + queues - 1) / queues;
+  if (lp.slices < 1) lp.slices = 1;
+  static const uint32_t tiles_env = [] { const char* e = getenv("DNS_LIST_TILES"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1 && n <= 32 ? n : 0); }();
+  lp.tiles = tiles_env ? tiles_env : LIST_TILES;
+  return true;
+}
+
+static uint64_t list_words(const ListPlan& lp) {
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < lp.n; ++i) w += (uint64_t)lp.chunks[i] * lp.cap[i];
+  return w;
+}
+
 // Levels with at least PART_MIN_CHUNKS chunks go through the partition form; hashed levels get the uniform-hash
 // expectation + 1/8 slack per queue, dense levels (spatially clustered points) twice the expectation.
 constexpr uint32_t PART_MIN_CHUNKS = 16;
 
-static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, uint32_t queue_cap, PartPlan& pp) {
+static bool part_plan(const GridLevels& lv, uint32_t P, uint32_t min_chunks, uint32_t queue_cap, PartPlan& pp,
+                      const bool* skip = nullptr) {
   pp.n = 0;
   pp.chunk_shift = 13;
   uint32_t queues = 0;
   uint64_t floats = 0;
   for (uint32_t l = 0; l < lv.n_levels; ++l) {
     const uint32_t chunks = (lv.size[l] + 8191u) >> 13;
-    if (chunks < min_chunks || chunks > PART_MAX_CHUNKS) continue;
+    if (chunks < min_chunks || chunks > PART_MAX_CHUNKS || (skip && skip[l])) continue;
     if (lv.hashed[l] && (lv.size[l] & (lv.size[l] - 1u))) continue;
     const uint64_t expect = ((uint64_t)P * 8u + chunks - 1) / chunks;
     uint64_t cap = (lv.hashed[l] ? expect + expect / 8u : 2u * expect) + 4096u;
@@ -1178,18 +1585,68 @@ static uint32_t part_min_chunks(uint32_t flags) {
   return PART_MIN_CHUNKS;
 }
 
-// floats of workspace in front of the replayed rows (= the whole workspace without DNS_SCATTER_REPLAY), rounded to 16 bytes
-static uint64_t replay_offset_floats(uint32_t P, const GridLevels& lv, uint32_t flags, uint32_t queue_cap) {
-  uint64_t n = (uint64_t)P * lv.n_levels * 2 + 4;
+// workgroups of the sweep form (DNS_BIN_JOBS overrides, for measurement): ~1280 when it carries the hashed levels too (above),
+// one round of the chip when only the dense levels are left to it (every job zeroes and flushes a whole chunk)
+static uint32_t bin_target_jobs(bool lists) {
+  static const uint32_t v = [] { const char* e = getenv("DNS_BIN_JOBS"); const long n = e ? atol(e) : 0; return (uint32_t)(n > 0 && n < 65536 ? n : 0); }();
+  return v ? v : (lists ? 512u : 1280u);
+}
+
+static uint32_t bin_threads() {
+  static const uint32_t v = [] { const char* e = getenv("DNS_BIN_THREADS"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 64 && n <= 1024 && n % 64 == 0 ? n : 1024); }();
+  return v;
+}
+
+// pass-2 workgroups of the pair-list form (DNS_LIST_JOBS overrides, for measurement)
+static uint32_t list_target_jobs() {
+  static const uint32_t v = [] {
+    const char* e = getenv("DNS_LIST_JOBS");
+    const long n = e ? atol(e) : 0;
+    return (uint32_t)(n > 0 && n < 65536 ? n : 1536);
+  }();
+  return v;
+}
+
+// Workspace of the table scatter, in floats: [level-major gradient copy | max word, non-finite flag, pad | queue counters + queues
+// of the partition form | list counters + lists of the pair-list form | replayed rows (16-byte aligned)]
+struct ScatterWs {
+  bool part, lists;
   PartPlan pp;
-  if (part_plan(lv, P, part_min_chunks(flags), queue_cap, pp)) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS + part_floats(pp);
-  return (n + 3u) & ~(uint64_t)3u;
+  ListPlan lp;
+  bool in_part[DNS_MAX_LEVELS], in_list[DNS_MAX_LEVELS];
+  uint64_t gmax, qcount, queues, lcount, lwords, replay, total;
+};
+static ScatterWs scatter_ws(uint32_t P, const GridLevels& lv, uint32_t flags, uint32_t queue_cap) {
+  ScatterWs w = {};
+  w.lists = ((flags & DNS_SCATTER_LISTS) || (flags & DNS_SCATTER_MASK) == DNS_SCATTER_AUTO) && list_plan(lv, P, queue_cap, list_target_jobs(), w.lp);
+  if (w.lists)
+    for (uint32_t i = 0; i < w.lp.n; ++i) w.in_list[w.lp.level[i]] = true;
+  w.part = part_plan(lv, P, part_min_chunks(flags), queue_cap, w.pp, w.in_list);
+  if (w.part)
+    for (uint32_t i = 0; i < w.pp.n; ++i) w.in_part[w.pp.level[i]] = true;
+  uint64_t n = (uint64_t)P * lv.n_levels * 2;
+  w.gmax = n;
+  n += 4;
+  w.qcount = n;
+  if (w.part) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS;
+  w.queues = n;
+  if (w.part) n += part_floats(w.pp);
+  w.lcount = n;
+  if (w.lists) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS;
+  w.lwords = n;
+  if (w.lists) n += list_words(w.lp);
+  n = (n + 3u) & ~(uint64_t)3u;
+  w.replay = n;
+  if (flags & DNS_SCATTER_REPLAY) n += (uint64_t)P * lv.n_levels * 4;
+  w.total = n;
+  return w;
 }
 
 static int encode_init_attrs() {
   const int bytes = 8192 * 2 * (int)sizeof(unsigned long long);   // one 8192-row chunk of 64-bit bins: 128 KB
   if (hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-      hipFuncSetAttribute((const void*)hashgrid_bwd_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+      hipFuncSetAttribute((const void*)hashgrid_bwd_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+      hipFuncSetAttribute((const void*)hashgrid_bwd_pairbins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
     set_error("dns_init: hipFuncSetAttribute failed for the hash-grid scatter kernels");
     return DNS_E_LAUNCH;
   }
@@ -1267,7 +1724,7 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
   if (P == 0) return DNS_OK;
   DNS_REQUIRE(x != nullptr, "dns_encode_bwd: x is NULL");
   DNS_REQUIRE(!dy_dx || (((uintptr_t)dy_dx) & 7u) == 0, "dns_encode_bwd: dy_dx must be 8-byte aligned");
-  DNS_REQUIRE((flags & ~(DNS_SCATTER_MASK | DNS_SCATTER_REPLAY)) == 0, "dns_encode_bwd: unknown flags 0x%x", flags);
+  DNS_REQUIRE((flags & ~(DNS_SCATTER_MASK | DNS_SCATTER_REPLAY | DNS_SCATTER_LISTS)) == 0, "dns_encode_bwd: unknown flags 0x%x", flags);
   GridLevels lv = {};
   if (d_grid) {
     DNS_REQUIRE(meta && table, "dns_encode_bwd: d_grid given without table/meta");
@@ -1306,12 +1763,15 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     plan.chunk_rows = 8192u;
     plan.xcd_major = 1u;
     plan.strided_dense = 1u;
-    // levels of large tables: partition form (DNS_SCATTER_QUEUES sends every multi-chunk level there, _BINNED none)
-    PartPlan pp;
-    const bool part = part_plan(lv, P, part_min_chunks(flags), queue_cap, pp);
-    bool in_part[DNS_MAX_LEVELS] = {};
-    if (part)
-      for (uint32_t i = 0; i < pp.n; ++i) in_part[pp.level[i]] = true;
+    static const bool no_runs = [] { const char* e = getenv("DNS_DENSE_RUNS"); return e && e[0] == '0'; }();
+    plan.dense_runs = no_runs ? 0u : 1u;
+    // multi-chunk levels: pair lists (DNS_SCATTER_LISTS), else the partition form for levels of large tables
+    // (DNS_SCATTER_QUEUES sends every multi-chunk level there, _BINNED none)
+    const ScatterWs W = scatter_ws(P, lv, flags, queue_cap);
+    const PartPlan& pp = W.pp;
+    const bool part = W.part;
+    bool in_part[DNS_MAX_LEVELS];
+    for (uint32_t l = 0; l < DNS_MAX_LEVELS; ++l) in_part[l] = W.in_part[l] || W.in_list[l];
     uint32_t total_chunks = 0, chunk_of[DNS_MAX_LEVELS];
     for (uint32_t l = 0; l < lv.n_levels; ++l) {
       chunk_of[l] = in_part[l] ? 0u : (lv.size[l] + plan.chunk_rows - 1) / plan.chunk_rows;
@@ -1325,9 +1785,9 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     uint32_t weight = 0;
     for (uint32_t l = 0; l < lv.n_levels; ++l) weight += chunk_of[l] * (lv.hashed[l] ? 1u : (chunk_of[l] == 1 ? 4u : 2u));
     if (weight == 0) weight = 1;
-    uint32_t ns = (1280u + weight - 1) / weight;
+    uint32_t ns = (bin_target_jobs(W.lists) + weight - 1) / weight;
     if (ns < 1) ns = 1;
-    const uint32_t max_ns = (P + 1023) / 1024;                 // at least ~one point per thread
+    const uint32_t max_ns = (P + bin_threads() - 1) / bin_threads();   // at least ~one point per thread
     if (ns > max_ns) ns = max_ns ? max_ns : 1;
     uint32_t jobs = 0, groups = 0;
     uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1361,8 +1821,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       rp.slot[l] = yes ? (int32_t)n_replay++ : -1;
     }
     DNS_REQUIRE(!n_replay || (((uintptr_t)ws) & 15u) == 0, "dns_encode_bwd: DNS_SCATTER_REPLAY needs a 16-byte aligned workspace");
-    uint4* rows16 = n_replay ? reinterpret_cast<uint4*>(ws + replay_offset_floats(P, lv, flags, queue_cap)) : nullptr;
-    uint32_t* gmax = (uint32_t*)(ws + (size_t)P * lv.n_levels * 2);
+    uint4* rows16 = n_replay ? reinterpret_cast<uint4*>(ws + W.replay) : nullptr;
+    uint32_t* gmax = (uint32_t*)(ws + W.gmax);
     {                                                                          // max word, non-finite flag, pad
       const int rc = fill_words(gmax, 0u, 4, st, "dns_encode_bwd");
       if (rc != DNS_OK) return rc;
@@ -1370,11 +1830,25 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax, x, lv, rp,
                rows16);
     if (jobs)
-      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(1024), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table,
+      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(bin_threads()), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table,
                  rp, (const uint4*)rows16);
+    if (W.lists) {
+      const ListPlan& lp = W.lp;
+      uint32_t* lcount = reinterpret_cast<uint32_t*>(ws + W.lcount);
+      uint32_t* lists = reinterpret_cast<uint32_t*>(ws + W.lwords);
+      {
+        const int rc = fill_words(lcount, 0u, lp.qoff[lp.n], st, "dns_encode_bwd");
+        if (rc != DNS_OK) return rc;
+      }
+      DNS_LAUNCH(hashgrid_bwd_pairlist_kernel, dim3((P + LIST_THREADS * lp.tiles - 1) / (LIST_THREADS * lp.tiles), lp.n), dim3(LIST_THREADS), 0,
+                 st, x, P, lv, lp, (const float2*)ws, gmax, lcount, lists, d_table);
+      DNS_LAUNCH(hashgrid_bwd_pairbins_kernel, dim3(lp.qoff[lp.n] * lp.slices), dim3(list_threads(lp.chunk_shift)),
+                 lds_bytes >> (13u - lp.chunk_shift), st, x, P, lv, lp,
+                 (const float2*)ws, lcount, lists, gmax, d_table);
+    }
     if (part) {
-      uint32_t* qcount = gmax + 4;
-      float* queues = reinterpret_cast<float*>(qcount + DNS_MAX_LEVELS * PART_MAX_CHUNKS);
+      uint32_t* qcount = reinterpret_cast<uint32_t*>(ws + W.qcount);
+      float* queues = ws + W.queues;
       {
         const int rc = fill_words(qcount, 0u, pp.qoff[pp.n], st, "dns_encode_bwd");
         if (rc != DNS_OK) return rc;
@@ -1399,9 +1873,5 @@ extern "C" int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMet
 extern "C" uint64_t dns_encode_bwd_ws_floats(uint32_t P, const DnsGridMeta* meta, uint32_t flags, uint32_t queue_cap) {
   if (!meta) return 0;
   const GridLevels lv = to_levels(meta);
-  // level-major d_grid copy + max|d_grid| word (+pad) + queue counters + the partition form's queues [+ replayed rows: 4 floats
-  // per point and hashed level, 16-byte aligned]
-  uint64_t n = replay_offset_floats(P, lv, flags, queue_cap);
-  if (flags & DNS_SCATTER_REPLAY) n += (uint64_t)P * lv.n_levels * 4;
-  return n;
+  return scatter_ws(P, lv, flags, queue_cap).total;
 }

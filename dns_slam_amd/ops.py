@@ -148,11 +148,14 @@ def _bound6(bound) -> Optional[C.Array]:
 
 
 # ----------------------------------------------------------------------------- encoding
-# (form, queue_cap) of the table-gradient scatter, include/dns_hip.h DNS_SCATTER_*: 0 auto, 1 per-corner atomics (tcnn's
-# form), 2 LDS bins for every level, 3 per-chunk queues for every multi-chunk level; queue_cap 0 = sized by the library
+# (form, queue_cap) of the table-gradient scatter, include/dns_hip.h DNS_SCATTER_*: 0 auto (pair lists for the hashed levels, LDS
+# sweep / queues for the dense ones), 1 per-corner atomics (tcnn's form), 2 LDS sweep for every level, 3 per-chunk queues for
+# every multi-chunk level; queue_cap 0 = sized by the library
 SCATTER_AUTO, SCATTER_ATOMIC, SCATTER_BINNED, SCATTER_QUEUES = 0, 1, 2, 3
 SCATTER_REPLAY = 0x10       # include/dns_hip.h DNS_SCATTER_REPLAY: hashed levels' corner rows stored once, replayed by the chunk visits
-SCATTER_FORM = (SCATTER_AUTO | (SCATTER_REPLAY if os.environ.get("DNS_SCATTER_REPLAY", "0") == "1" else 0), 0)
+SCATTER_LISTS = 0x20        # include/dns_hip.h DNS_SCATTER_LISTS (implied by auto): hashed levels through per-chunk lists of {point, corner pair} words
+SCATTER_FORM = (SCATTER_AUTO | (SCATTER_REPLAY if os.environ.get("DNS_SCATTER_REPLAY", "0") == "1" else 0)
+                | (SCATTER_LISTS if os.environ.get("DNS_SCATTER_LISTS", "0") == "1" else 0), 0)
 SAVE_DY_DX = True           # encode forward keeps d(grid)/dx when the points need a gradient (False: the backward re-gathers)
 
 

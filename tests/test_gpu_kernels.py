@@ -49,11 +49,15 @@ def test_hashgrid_rows_bit_exact(hash_size, res):
     (16, 592, 3000, "b", None),       # LDS bins forced for every level
     (16, 592, 5000, "r", None),       # binned + row replay: the hashed levels' corner rows stored once, replayed by the 8 chunk visits
     (14, 200, 2000, "r", None),       # ... T = 2^14: two chunks per hashed level
+    (16, 592, 5000, "l", None),       # pair lists: every multi-chunk level (3 dense + 12 hashed) hashed once, {point, pair} words per chunk
+    (16, 592, 3000, "l", 64),         # ... with 64-entry lists: most pairs take the overflow fallback (float atomics)
+    (20, 231, 4000, "l", None),       # ... T = 2^20: up to 128 chunks per level, large dense levels (pairs that straddle chunks)
+    (14, 200, 2000, "l", None),
 ])
 def test_encode_forward_backward(hash_size, res, P, scatter, cap, monkeypatch):
     ops = _ops()
     form = {None: ops.SCATTER_AUTO, "q": ops.SCATTER_QUEUES, "a": ops.SCATTER_ATOMIC, "b": ops.SCATTER_BINNED,
-            "r": ops.SCATTER_AUTO | ops.SCATTER_REPLAY}[scatter]
+            "r": ops.SCATTER_AUTO | ops.SCATTER_REPLAY, "l": ops.SCATTER_AUTO | ops.SCATTER_LISTS}[scatter]
     monkeypatch.setattr(ops, "SCATTER_FORM", (form, cap or 0))      # dns_encode_bwd flags / queue_cap
     om, pm = tr.grid_meta(hash_size, res), ops.GridMeta(hash_size, res)
     g = torch.Generator().manual_seed(1)
@@ -157,7 +161,7 @@ def test_encode_world_normalisation_fp64():
     assert torch.equal(ops.hashgrid_rows(x_p, pm).cpu(), rows_o)
 
 
-@pytest.mark.parametrize("scatter", ["auto", "atomic", "queues"])
+@pytest.mark.parametrize("scatter", ["auto", "atomic", "queues", "lists"])
 @pytest.mark.parametrize("poison", [float("nan"), float("inf")])
 def test_table_gradient_propagates_non_finite(scatter, poison, monkeypatch):
     """A NaN / Inf in the upstream grid gradient must reach d_table in every scatter form: the 64-bit LDS bins of the queue form (fixed point) cannot
@@ -165,7 +169,7 @@ def test_table_gradient_propagates_non_finite(scatter, poison, monkeypatch):
     it and the binned / queue kernels write NaN into their rows (csrc/encode.hip), as tcnn's float atomics would."""
     ops = _ops()
     pm = ops.GridMeta(16, 592)
-    form = {"auto": ops.SCATTER_AUTO, "atomic": ops.SCATTER_ATOMIC, "queues": ops.SCATTER_QUEUES}[scatter]
+    form = {"auto": ops.SCATTER_AUTO, "atomic": ops.SCATTER_ATOMIC, "queues": ops.SCATTER_QUEUES, "lists": ops.SCATTER_LISTS}[scatter]
     monkeypatch.setattr(ops, "SCATTER_FORM", (form, 0))
     g = torch.Generator().manual_seed(5)
     P = 3000
@@ -180,6 +184,37 @@ def test_table_gradient_propagates_non_finite(scatter, poison, monkeypatch):
     y = ops.encode(x, table, pm, None, 16, False, True)
     (y * gy).sum().backward()
     assert not bool(torch.isfinite(table.grad).all()), f"{scatter}: a {poison} upstream gradient left d_table finite"
+
+
+@pytest.mark.parametrize("hash_size,res,P", [(16, 592, 262144), (20, 592, 100000)])
+def test_pair_list_scatter_equals_the_binned_scatter_on_ray_points(hash_size, res, P, monkeypatch):
+    """The pair-list form (DNS_SCATTER_LISTS) against the LDS-bin sweep on a step-sized batch of RAY samples (clustered on the dense
+    levels: their lists fill unevenly and pairs straddle chunk boundaries) with a tenth of the gradients exactly zero (those points
+    enter no list): both forms sum the same fp32 products in float64 bins, so every table entry agrees to the last-place noise of
+    the final float atomics (1e-6 of the level's largest entry)."""
+    ops = _ops()
+    pm = ops.GridMeta(hash_size, res)
+    g = torch.Generator().manual_seed(11)
+    o = torch.rand(P // 64, 1, 3, generator=g) * 0.3 + 0.35
+    d = torch.randn(P // 64, 1, 3, generator=g) * 0.3
+    t = torch.linspace(0, 1, 64)[None, :, None]
+    x = (o + d * t).reshape(-1, 3).clamp(0, 1).to(DEV)
+    gy = torch.randn(x.shape[0], 32, generator=g)
+    gy[torch.rand(x.shape[0], generator=g) < 0.1] = 0.0
+    gy = gy.to(DEV)
+    grads = []
+    for form in (ops.SCATTER_BINNED, ops.SCATTER_LISTS):
+        monkeypatch.setattr(ops, "SCATTER_FORM", (form, 0))
+        table = torch.rand(pm.total_rows * 2, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+        y = ops.encode(x, table, pm, None, 16, False, True)
+        y.backward(gy)
+        grads.append(table.grad.reshape(-1, 2).clone())
+    off = 0
+    for l in range(pm.c.n_levels):
+        n = pm.c.size[l]
+        a, b = grads[0][off:off + n], grads[1][off:off + n]
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), f"level {l}: {float((a - b).abs().max())} vs max {float(a.abs().max())}"
+        off += n
 
 
 def test_encode_known_answers():
