@@ -76,8 +76,16 @@ def kernel_cost(entry, kernel, units, info, wl):
         return ("hbm", units * (16 * 3 * 8 + 80 * 4 + 12 + 12))            # the forward's dy_dx + the gradient row + x in, d_x out
     if k == "dgrid_transpose_kernel":
         return ("hbm", units * 2 * 32 * 4)                                 # [P,32] gradient read, level-major copy written
+    # table scatter, per point and level: RMW of 8 cells of 8 B + the level's 8 B of gradient (+ the point, 12 B, per kernel).  Pair
+    # lists (the hashed levels): pass 1 reads point + gradient twice and writes four 4-byte entries, pass 2 reads them back
+    L = (info or {}).get("n_levels", 16)
+    n_list = (info or {}).get("list_levels", 0)
     if k in ("hashgrid_bwd_binned_kernel", "hashgrid_bwd_queue_kernel"):
-        return ("hbm", units * (2 * 16 * 8 * 2 * 4 + 12 + 32 * 4))         # RMW of the same 128 cells + the point + its gradient
+        return ("hbm", units * ((L - n_list) * (2 * 8 * 8 + 8) + 12))
+    if k == "hashgrid_bwd_pairbins_kernel":
+        return ("hbm", units * n_list * (2 * 8 * 8 + 4 * (4 + 12 + 8)))
+    if k == "hashgrid_bwd_pairlist_kernel":
+        return ("hbm", units * n_list * (2 * (12 + 8) + 16))
     if k in ("composite_fwd_kernel", "composite_bwd_kernel"):
         return ("hbm", units * S * (4 + 1 + 8) * 4 * (2 if k == "composite_bwd_kernel" else 1))   # raw + z + logits (and their gradients)
     if k == "mlp_fwd_kernel":

@@ -1607,8 +1607,8 @@ static uint32_t list_target_jobs() {
   return v;
 }
 
-// Workspace of the table scatter, in floats: [level-major gradient copy | max word, non-finite flag, pad | queue counters + queues
-// of the partition form | list counters + lists of the pair-list form | replayed rows (16-byte aligned)]
+// Workspace of the table scatter, in floats: [level-major gradient copy | max word, non-finite flag, pad | list counters | queue
+// counters + queues of the partition form | lists of the pair-list form | replayed rows (16-byte aligned)]
 struct ScatterWs {
   bool part, lists;
   PartPlan pp;
@@ -1627,12 +1627,12 @@ static ScatterWs scatter_ws(uint32_t P, const GridLevels& lv, uint32_t flags, ui
   uint64_t n = (uint64_t)P * lv.n_levels * 2;
   w.gmax = n;
   n += 4;
+  w.lcount = n;                                  // directly behind the max words: one fill clears both
+  if (w.lists) n += w.lp.qoff[w.lp.n];
   w.qcount = n;
   if (w.part) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS;
   w.queues = n;
   if (w.part) n += part_floats(w.pp);
-  w.lcount = n;
-  if (w.lists) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS;
   w.lwords = n;
   if (w.lists) n += list_words(w.lp);
   n = (n + 3u) & ~(uint64_t)3u;
@@ -1760,7 +1760,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
   if (binned) {
     BinPlan plan;
     plan.n_levels = lv.n_levels;
-    plan.chunk_rows = 8192u;
+    static const uint32_t rows_env = [] { const char* e = getenv("DNS_BIN_ROWS"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1024 && n <= 8192 ? n : 0); }();
+    plan.chunk_rows = rows_env ? rows_env : 8192u;
     plan.xcd_major = 1u;
     plan.strided_dense = 1u;
     static const bool no_runs = [] { const char* e = getenv("DNS_DENSE_RUNS"); return e && e[0] == '0'; }();
@@ -1812,7 +1813,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       for (int i = 0; i < 8; ++i) mx = per_xcd[i] > mx ? per_xcd[i] : mx;
       jobs = 8u * mx;                                          // padded: workgroups past an XCD's last job exit at once
     }
-    const size_t lds_bytes = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
+    const size_t lds_bytes = (size_t)8192u * 2 * sizeof(unsigned long long);          // queue / list kernels: 8192-row chunks
+    const size_t bin_lds = (size_t)plan.chunk_rows * 2 * sizeof(unsigned long long);
     // row replay: hashed levels of <= 2^16 rows that this (binned) form handles in more than one chunk
     ReplayPlan rp;
     uint32_t n_replay = 0;
@@ -1824,22 +1826,18 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     uint4* rows16 = n_replay ? reinterpret_cast<uint4*>(ws + W.replay) : nullptr;
     uint32_t* gmax = (uint32_t*)(ws + W.gmax);
     {                                                                          // max word, non-finite flag, pad
-      const int rc = fill_words(gmax, 0u, 4, st, "dns_encode_bwd");
+      const int rc = fill_words(gmax, 0u, 4 + (W.lists ? W.lp.qoff[W.lp.n] : 0u), st, "dns_encode_bwd");
       if (rc != DNS_OK) return rc;
     }
     DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax, x, lv, rp,
                rows16);
     if (jobs)
-      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(bin_threads()), lds_bytes, st, x, P, lv, plan, (const float2*)ws, gmax, d_table,
+      DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(bin_threads()), bin_lds, st, x, P, lv, plan, (const float2*)ws, gmax, d_table,
                  rp, (const uint4*)rows16);
     if (W.lists) {
       const ListPlan& lp = W.lp;
       uint32_t* lcount = reinterpret_cast<uint32_t*>(ws + W.lcount);
       uint32_t* lists = reinterpret_cast<uint32_t*>(ws + W.lwords);
-      {
-        const int rc = fill_words(lcount, 0u, lp.qoff[lp.n], st, "dns_encode_bwd");
-        if (rc != DNS_OK) return rc;
-      }
       DNS_LAUNCH(hashgrid_bwd_pairlist_kernel, dim3((P + LIST_THREADS * lp.tiles - 1) / (LIST_THREADS * lp.tiles), lp.n), dim3(LIST_THREADS), 0,
                  st, x, P, lv, lp, (const float2*)ws, gmax, lcount, lists, d_table);
       DNS_LAUNCH(hashgrid_bwd_pairbins_kernel, dim3(lp.qoff[lp.n] * lp.slices), dim3(list_threads(lp.chunk_shift)),

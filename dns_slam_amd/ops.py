@@ -51,7 +51,17 @@ class _TimedLib:
     # (n_in = the LIVE input width: with DNS_MLP_LIVE_IN the kernels skip the identically-zero columns, and the roofline counts
     #  the work that is done, not the multiplications by zero the reference's full-width GEMM performs)
     _live = staticmethod(lambda n_in, flags: ((int(flags) >> 16) & 0xff) or n_in)
-    _INFO = {"dns_mlp_fwd": lambda a: {"n_in": _TimedLib._live(a[6], a[17]), "n_out": a[7], "nn": a[8], "nl": a[9]},
+    @staticmethod
+    def _grid_info(meta_ref):
+        """levels of a grid and how many of them the scatter sends through pair lists (hashed, more than one 8192-row chunk)"""
+        m = getattr(meta_ref, "_obj", None)
+        if m is None:
+            return None
+        L = int(m.n_levels)
+        return {"n_levels": L, "list_levels": sum(1 for l in range(L) if m.hashed[l] and 8192 < m.size[l] <= (1 << 20))}
+
+    _INFO = {"dns_encode_bwd": lambda a: _TimedLib._grid_info(a[5]),
+             "dns_mlp_fwd": lambda a: {"n_in": _TimedLib._live(a[6], a[17]), "n_out": a[7], "nn": a[8], "nl": a[9]},
              "dns_mlp_dwin": lambda a: {"n_in": _TimedLib._live(a[5], a[14]), "n_out": 0, "nn": a[6], "nl": a[7]},
              "dns_mlp_bwd": lambda a: {"n_in": _TimedLib._live(a[8], a[23]), "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]),
                                        "dw": bool(a[16])},

@@ -13,7 +13,8 @@ fetch_dir, write_dir, workload, tag = sys.argv[1:5]
 n_steps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 ENTRY = {  # C-ABI entry point -> kernels it launches
     "dns_mlp_fwd": ["mlp_fwd_kernel"], "dns_mlp_bwd": ["mlp_bwd_kernel", "mlp_dwin_kernel"],
-    "dns_encode_fwd": ["encode_fwd_kernel"], "dns_encode_bwd": ["encode_bwd_kernel", "dgrid_transpose_kernel", "hashgrid_bwd_binned_kernel"],
+    "dns_encode_fwd": ["encode_fwd_kernel"], "dns_encode_bwd": ["encode_bwd_kernel", "dgrid_transpose_kernel", "hashgrid_bwd_binned_kernel", "hashgrid_bwd_pairlist_kernel",
+                                                                "hashgrid_bwd_pairbins_kernel", "hashgrid_bwd_partition_kernel", "hashgrid_bwd_queue_kernel"],
     "dns_composite_fwd": ["composite_fwd_kernel"], "dns_composite_bwd": ["composite_bwd_kernel"],
     "dns_loss_sums": ["loss_ray_sums_kernel", "loss_point_sums_kernel"], "dns_loss_bwd": ["loss_ray_bwd_kernel", "loss_point_bwd_kernel"],
     "dns_raygen_sample": ["depth_max_kernel", "raygen_sample_kernel"], "dns_raygen_bwd": ["raygen_bwd_reduce_kernel", "raygen_bwd_pose_kernel"],
@@ -27,7 +28,8 @@ ENTRY = {  # C-ABI entry point -> kernels it launches
     "dns_merge_dy": ["merge_dy_kernel"], "dns_add_ref_sum": ["add_ref_sum_kernel"], "dns_refer_poses": ["refer_poses_kernel"],
     "dns_draw_finish": ["draw_finish_kernel"], "dns_loss_finalize": ["loss_finalize_kernel"],
 }
-GATHER = ("encode_fwd_kernel", "encode_fwd_split_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel", "feature_gather_frames_kernel")
+GATHER = ("encode_fwd_kernel", "encode_fwd_split_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel", "feature_gather_frames_kernel",
+          "hashgrid_bwd_pairbins_kernel", "hashgrid_bwd_pairlist_kernel")
 
 
 def load(d):
