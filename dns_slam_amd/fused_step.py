@@ -820,15 +820,13 @@ class TrackStep:
         # cost more than the per-workgroup rebuild (measured on one box: 2.105 without, 2.111 with the images but no
         # re-preparation, 2.133 with both; stand-alone the prepared launches are 1-3 us (forward) and 4-7 us (backward) faster).
         self.PREP = ops.MLP_PREPARED_FLAG
-        self.w = []
         nets_w = [(self.p_coarse, self.shp_c), (self.p_color, self.shp_col), (self.p_logit, self.shp_log)]
         if self.stem:
             nets_w.append((self.p_merge, self.shp_m))
-        for p_, shp_ in nets_w:
-            w = f(int(raw_lib.dns_mlp_prepared_floats(*shp_)))
-            check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w),
-                                          _V(torch.cuda.current_stream().cuda_stream)), "dns_mlp_prepare")
-            self.w.append(w)
+        self._nets_w = nets_w
+        self.w = [f(int(raw_lib.dns_mlp_prepared_floats(*shp_))) for _, shp_ in nets_w]
+        self._prepare_weights()
+        self.g = None                                      # the captured iteration (run(graph=True)), kept across reset()
         self.w_coarse, self.w_color, self.w_logit = self.w[:3]
         self.w_merge = self.w[3] if self.stem else None
         self.lam = (C.c_float * 8)(t.lambda_p, t.lambda_d, t.lambda_l, 0.0, 0.0, 0.0, 0.0, 1.0)
@@ -942,18 +940,66 @@ class TrackStep:
               "dns_adam_step")
         self.steps += 1
 
+    @staticmethod
+    def signature(tracker, features, refer_frames):
+        """Everything a captured iteration has baked in besides the contents of its buffers: shapes, the constants passed by value
+        (loss weights, learning rates, intrinsics, border) and the ADDRESSES of the scene's parameters.  ``Tracker.track_frame``
+        keeps one TrackStep per signature and only ``reset``s it from frame to frame."""
+        t, dec = tracker, tracker.decoder
+        nets = [dec.pe_fn.grid_fn.params, dec.coarse_fn.decoder.params, dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params]
+        fs = None if features is None else tuple(features.shape)
+        if features is not None and features.dim() == 5:
+            nets.append(dec.merge.decoder.params)
+            fs = fs + (tuple(refer_frames["est_w2c"].shape),)
+        return (int(t.n_pixels), 0 if t.t_uniform is None else t.t_uniform.numel(), t.n_surface_ray, t.H, t.W, t.border, fs,
+                float(t.lambda_p), float(t.lambda_d), float(t.lambda_l), float(t.cam_lr), bool(t.seperate_LR),
+                float(t.fx), float(t.fy), float(t.cx), float(t.cy), tuple(float(v) for v in torch.as_tensor(t.bound).reshape(-1)),
+                tuple((p.data_ptr(), p.numel()) for p in nets))
+
+    @torch.no_grad()
+    def reset(self, cur_frames, est_c2w, features=None, refer_frames=None):
+        """The next frame on the SAME buffers (and the same captured graph): new images, initial pose, 2-D code / stem maps and
+        reference poses are copied into place, the Adam moments and the keep-best state start over (slams/tracking.py:108-126:
+        a new optimiser per frame) and the frozen networks' operand images are rebuilt from the current weights."""
+        t, dev = self.t, self.dev
+        for k, v in (("color", cur_frames["gt_color"]), ("depth", cur_frames["gt_depth"]), ("label", cur_frames["gt_label"])):
+            self.prep[k].copy_(v.to(dev).float()[None])
+        if self.stem:
+            self.feat_maps.copy_(features.detach().to(dev).float()[0].permute(0, 2, 3, 1))
+            w2c = refer_frames["est_w2c"].clone().detach().to(dev).float()
+            self.w2c.copy_(w2c.reshape(self.R, 16))
+            self.origin.copy_(torch.inverse(w2c)[:, :3, 3])
+        elif self.features is not None:
+            self.features.copy_(features.to(dev).float())
+        self.Q.copy_(get_quad_from_c2w(est_c2w).detach().to(dev).float().reshape(1, 4))
+        self.T.copy_(est_c2w[:3, 3].detach().to(dev).float().reshape(1, 3))
+        self.M.zero_()
+        self.V.zero_()
+        self.adam_state.zero_()
+        self.best_loss.fill_(float("inf"))
+        self.best_cam.copy_(torch.cat((self.Q.reshape(-1), self.T.reshape(-1))))
+        self._prepare_weights()
+        self.steps = 0
+
+    def _prepare_weights(self):
+        st = _V(torch.cuda.current_stream().cuda_stream)
+        for (p_, shp_), w in zip(self._nets_w, self.w):
+            check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w), st), "dns_mlp_prepare")
+
     def run(self, n_iters, graph=True):
         """n_iters iterations -> (best camera tensor [7] = (quat | T), best loss).  ``graph``: capture one iteration into a
-        hipGraph and replay it (tracking is 30-50 latency-bound iterations per frame)."""
+        hipGraph and replay it (tracking is 30-50 latency-bound iterations per frame); the capture is kept, so a TrackStep that
+        is ``reset`` for the next frame replays without capturing again."""
         if not graph:
             for _ in range(n_iters):
                 self.step()
             return self.best_cam, self.best_loss[0]
-        from ._lib import ensure_init
-        ensure_init()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):                          # records one iteration; nothing executes during capture
-            self.step()
+        if self.g is None:
+            from ._lib import ensure_init
+            ensure_init()
+            self.g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g):                 # records one iteration; nothing executes during capture
+                self.step()
         for _ in range(n_iters):
-            g.replay()
+            self.g.replay()
         return self.best_cam, self.best_loss[0]

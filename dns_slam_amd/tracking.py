@@ -166,9 +166,19 @@ class Tracker:
             # the same loop as a fixed launch sequence over preallocated buffers (no autograd graph; draws on the device
             # generator like static_shapes); graph=True replays one captured iteration.  `fused` / `graph_warmup` do not apply
             # (Adam is the library's own kernel, a capture needs no warm-up); there is no torch optimizer object afterwards
+            # ONE TrackStep per tracker and signature (shapes, constants, parameter addresses): its ~30 buffers, the prepared
+            # weight images' storage and the captured graph are reused from frame to frame; only the frame's data, the pose and
+            # the optimiser state are reset (a fresh TrackStep per frame cost a capture and ~30 allocations per frame)
             from .fused_step import TrackStep
-            ts = TrackStep(self, cur_frames, est_c2w, features=features, refer_frames=refer_frames)
+            key = TrackStep.signature(self, features, refer_frames)
+            ts = getattr(self, "_track_step", None)
+            if ts is not None and getattr(self, "_track_step_key", None) == key:
+                ts.reset(cur_frames, est_c2w, features=features, refer_frames=refer_frames)
+            else:
+                ts = TrackStep(self, cur_frames, est_c2w, features=features, refer_frames=refer_frames)
+                self._track_step, self._track_step_key = ts, key
             cam, best = ts.run(n_iters, graph=graph)
+            cam, best = cam.clone(), best.clone()          # the TrackStep's own buffers are overwritten by the next frame
             self.last_track_step = ts
             self.last_optimizer = None
             return cam, best

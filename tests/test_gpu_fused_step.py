@@ -260,6 +260,49 @@ def test_track_step_equals_the_tracker_loop(code):
     assert float((out["autograd"][0][4:] - c2w[:3, 3]).abs().max()) > 0        # the pose did move
 
 
+def test_track_step_is_reused_across_frames():
+    """``Tracker.track_frame(use_track_step)`` keeps ONE TrackStep (buffers, prepared-weight storage, captured graph) and resets it
+    per frame: the second frame of a cached, graph-replaying tracker must give what a FRESH tracker gives for that frame from
+    the same generator state -- other images, other initial pose, and scene weights that changed in between (the prepared
+    operand images must be rebuilt) --, and the graph must not have been captured twice."""
+    from dns_slam_amd.tracking import Tracker
+    cfg, bound, cam, frames, dec, mapper = _setup(64, 2, n_pixels=400)
+    cfg["tracking"]["n_pixels"] = 256
+    curs = [{"gt_color": frames["gt_color"][k], "gt_depth": frames["gt_depth"][k], "gt_label": frames["gt_label"][k]} for k in (1, 2)]
+    c2ws = []
+    for k in (1, 2):
+        c = frames["est_c2w"][k].clone()
+        c[:3, 3] += torch.tensor([0.02, -0.01, 0.015], dtype=c.dtype) * k
+        c2ws.append(c)
+
+    def perturb():
+        with torch.no_grad():
+            dec.coarse_fn.decoder.params.mul_(1.01)
+
+    cached = Tracker(cfg, dec, bound, cam, device=DEV)
+    cached.border, cached.use_track_step = 5, True
+    torch.manual_seed(3)
+    torch.cuda.manual_seed(3)
+    cached.track_frame(curs[0], c2ws[0], n_iters=10, graph=True)
+    first = cached.last_track_step
+    g_first = first.g
+    perturb()
+    torch.cuda.manual_seed(7)
+    cam_c, best_c = cached.track_frame(curs[1], c2ws[1], n_iters=20, graph=True)
+    assert cached.last_track_step is first and first.g is g_first
+    fresh = Tracker(cfg, dec, bound, cam, device=DEV)
+    fresh.border, fresh.use_track_step = 5, True
+    torch.cuda.manual_seed(7)
+    cam_f, best_f = fresh.track_frame(curs[1], c2ws[1], n_iters=20, graph=True)
+    torch.cuda.synchronize()
+    assert abs(float(best_c) - float(best_f)) <= 1e-5 * abs(float(best_f)), (float(best_c), float(best_f))
+    assert float((cam_c - cam_f).abs().max()) <= 2e-5
+    # a different signature (another ray count) builds a new TrackStep
+    cached.n_pixels = 128
+    cached.track_frame(curs[1], c2ws[1], n_iters=2, graph=False)
+    assert cached.last_track_step is not first
+
+
 def test_tracker_glue_kernels():
     lib, check, ptr, stream_ptr = _lib()
     g = torch.Generator().manual_seed(8)
