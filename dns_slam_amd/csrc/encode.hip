@@ -595,23 +595,26 @@ struct ReplayPlan {
   int32_t slot[DNS_MAX_LEVELS];                  // level -> index of its [P] uint4 plane in rows16, -1 = not replayed
 };
 
+constexpr uint32_t DG_TILES = 2;                 // 256-point tiles per workgroup of the transpose
 __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __restrict__ d_grid, uint32_t ld, uint32_t P,
                                                               uint32_t n_levels, float2* __restrict__ dg_t,
                                                               uint32_t* __restrict__ gmax, const float* __restrict__ xin,
-                                                              GridLevels lv, ReplayPlan rp, uint4* __restrict__ rows16) {
+                                                              GridLevels lv, ReplayPlan rp, uint4* __restrict__ rows16,
+                                                              uint32_t n_tiles) {
   // 256 points per workgroup through an LDS tile: rows are read as whole 128-byte lines (8 lanes x 16 B per point),
   // level planes are written as 2-KB contiguous runs (lane = point).  Row stride 34 floats keeps both sides <= 2-way.
+  // A workgroup takes DG_TILES consecutive tiles: the NEXT tile's rows are requested before this tile goes through LDS and out, so
+  // the read stream of one tile overlaps the write stream of the one before (one tile per workgroup ran the two phases of the
+  // whole grid in lock-step: 26 us for 67 MB).
   constexpr uint32_t LDT = 34;
   __shared__ float tile[256 * LDT];
-  const uint32_t p0 = blockIdx.x * 256u;
   const uint32_t nf = n_levels * 2;                  // floats per row (<= 32 with the supported 16 levels)
   const bool vec = ((ld & 3u) == 0) && ((((uintptr_t)d_grid) & 15u) == 0) && ((nf & 3u) == 0);
   float m = 0.f;
   bool bad = false;                                  // a NaN / Inf in the upstream gradient
-  if (vec) {
-    // all eight 16-byte loads of a thread are requested before the first is used (clamped addresses, no branch between
-    // them: a guarded load per trip made every trip wait its own memory round trip)
-    float4 v[8];
+  // all eight 16-byte loads of a thread are requested before the first is used (clamped addresses, no branch between
+  // them: a guarded load per trip made every trip wait its own memory round trip)
+  auto issue = [&](uint32_t p0, float4 (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t e = threadIdx.x + 256u * i;
@@ -619,56 +622,69 @@ __global__ __launch_bounds__(256) void dgrid_transpose_kernel(const float* __res
       const uint32_t pc = min(p0 + r, P - 1u), qc = min(4u * q, nf - 4u);
       v[i] = *reinterpret_cast<const float4*>(d_grid + (size_t)pc * ld + qc);
     }
+  };
+  float4 v[8], vn[8];
+  const uint32_t tile0 = blockIdx.x * n_tiles;
+  if (vec && tile0 * 256u < P) issue(tile0 * 256u, v);
+  for (uint32_t t = 0; t < n_tiles; ++t) {
+    const uint32_t p0 = (tile0 + t) * 256u;
+    if (p0 >= P) break;                              // uniform
+    if (vec) {
+      if (t + 1 < n_tiles && p0 + 256u < P) issue(p0 + 256u, vn);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t e = threadIdx.x + 256u * i;
-      const uint32_t r = e >> 3, q = e & 7u;
-      if (!(p0 + r < P && 4u * q < nf)) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      float* d = tile + r * LDT + 4 * q;
-      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
-      bad = bad || !(fabsf(v[i].x) < INFINITY) || !(fabsf(v[i].y) < INFINITY) || !(fabsf(v[i].z) < INFINITY) || !(fabsf(v[i].w) < INFINITY);
-    }
-  } else {
-    for (uint32_t e = threadIdx.x; e < 256u * 8u; e += 256u) {
-      const uint32_t r = e >> 3, q = e & 7u;
-      const uint32_t p = p0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < P && 4 * q < nf) {
-        const float* src = d_grid + (size_t)p * ld + 4 * q;
-        v.x = src[0];
-        if (4 * q + 1 < nf) v.y = src[1];
-        if (4 * q + 2 < nf) v.z = src[2];
-        if (4 * q + 3 < nf) v.w = src[3];
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t e = threadIdx.x + 256u * i;
+        const uint32_t r = e >> 3, q = e & 7u;
+        if (!(p0 + r < P && 4u * q < nf)) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = tile + r * LDT + 4 * q;
+        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+        bad = bad || !(fabsf(v[i].x) < INFINITY) || !(fabsf(v[i].y) < INFINITY) || !(fabsf(v[i].z) < INFINITY) || !(fabsf(v[i].w) < INFINITY);
       }
-      float* d = tile + r * LDT + 4 * q;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-      bad = bad || !(fabsf(v.x) < INFINITY) || !(fabsf(v.y) < INFINITY) || !(fabsf(v.z) < INFINITY) || !(fabsf(v.w) < INFINITY);
-    }
-  }
-  __syncthreads();
-  const uint32_t p = p0 + threadIdx.x;
-  if (p < P) {
-    for (uint32_t l = 0; l < n_levels; ++l)
-      dg_t[(size_t)l * P + p] = make_float2(tile[threadIdx.x * LDT + 2 * l], tile[threadIdx.x * LDT + 2 * l + 1]);
-    if (rows16) {
-      const float x0 = xin[(size_t)p * 3], x1 = xin[(size_t)p * 3 + 1], x2 = xin[(size_t)p * 3 + 2];
-      for (uint32_t l = 0; l < n_levels; ++l) {
-        const int slot = rp.slot[l];
-        if (slot < 0) continue;                      // uniform
-        const float sc = lv.scale[l];
-        const uint32_t g0 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x0, sc), 0.5f));
-        const uint32_t g1 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x1, sc), 0.5f));
-        const uint32_t g2 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x2, sc), 0.5f));
-        const uint32_t mask = lv.size[l] - 1u;       // hashed levels are exactly 2^T rows (<= 2^16 here)
-        const uint32_t ay0 = g1 * 2654435761u, ay1 = ay0 + 2654435761u, az0 = g2 * 805459861u, az1 = az0 + 805459861u;
-        uint32_t r[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) r[c] = ((g0 + (uint32_t)(c & 1)) ^ ((c & 2) ? ay1 : ay0) ^ ((c & 4) ? az1 : az0)) & mask;
-        rows16[(size_t)slot * P + p] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+      for (int i = 0; i < 8; ++i) v[i] = vn[i];
+    } else {
+      for (uint32_t e = threadIdx.x; e < 256u * 8u; e += 256u) {
+        const uint32_t r = e >> 3, q = e & 7u;
+        const uint32_t p = p0 + r;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < P && 4 * q < nf) {
+          const float* src = d_grid + (size_t)p * ld + 4 * q;
+          w.x = src[0];
+          if (4 * q + 1 < nf) w.y = src[1];
+          if (4 * q + 2 < nf) w.z = src[2];
+          if (4 * q + 3 < nf) w.w = src[3];
+        }
+        float* d = tile + r * LDT + 4 * q;
+        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+        bad = bad || !(fabsf(w.x) < INFINITY) || !(fabsf(w.y) < INFINITY) || !(fabsf(w.z) < INFINITY) || !(fabsf(w.w) < INFINITY);
       }
     }
+    __syncthreads();
+    const uint32_t p = p0 + threadIdx.x;
+    if (p < P) {
+      for (uint32_t l = 0; l < n_levels; ++l)
+        dg_t[(size_t)l * P + p] = make_float2(tile[threadIdx.x * LDT + 2 * l], tile[threadIdx.x * LDT + 2 * l + 1]);
+      if (rows16) {
+        const float x0 = xin[(size_t)p * 3], x1 = xin[(size_t)p * 3 + 1], x2 = xin[(size_t)p * 3 + 2];
+        for (uint32_t l = 0; l < n_levels; ++l) {
+          const int slot = rp.slot[l];
+          if (slot < 0) continue;                      // uniform
+          const float sc = lv.scale[l];
+          const uint32_t g0 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x0, sc), 0.5f));
+          const uint32_t g1 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x1, sc), 0.5f));
+          const uint32_t g2 = (uint32_t)(int)floorf(__fadd_rn(__fmul_rn(x2, sc), 0.5f));
+          const uint32_t mask = lv.size[l] - 1u;       // hashed levels are exactly 2^T rows (<= 2^16 here)
+          const uint32_t ay0 = g1 * 2654435761u, ay1 = ay0 + 2654435761u, az0 = g2 * 805459861u, az1 = az0 + 805459861u;
+          uint32_t r[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) r[c] = ((g0 + (uint32_t)(c & 1)) ^ ((c & 2) ? ay1 : ay0) ^ ((c & 4) ? az1 : az0)) & mask;
+          rows16[(size_t)slot * P + p] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+        }
+      }
+    }
+    __syncthreads();                                   // the tile is overwritten by the next trip
   }
   // max |d_grid|: wave reduce, then ONE conditional atomic per workgroup -- 4096 unconditional same-address atomics
   // serialised into ~40 us of this kernel's 56; a (possibly stale) read of the running max lets all but the first few
@@ -1829,8 +1845,9 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       const int rc = fill_words(gmax, 0u, 4 + (W.lists ? W.lp.qoff[W.lp.n] : 0u), st, "dns_encode_bwd");
       if (rc != DNS_OK) return rc;
     }
-    DNS_LAUNCH(dgrid_transpose_kernel, dim3(blocks), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax, x, lv, rp,
-               rows16);
+    static const uint32_t dg_tiles = [] { const char* e = getenv("DNS_DG_TILES"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1 && n <= 64 ? n : DG_TILES); }();
+    DNS_LAUNCH(dgrid_transpose_kernel, dim3((blocks + dg_tiles - 1) / dg_tiles), dim3(256), 0, st, d_grid, ld_dgrid, P, lv.n_levels, (float2*)ws, gmax, x, lv, rp,
+               rows16, dg_tiles);
     if (jobs)
       DNS_LAUNCH(hashgrid_bwd_binned_kernel, dim3(jobs), dim3(bin_threads()), bin_lds, st, x, P, lv, plan, (const float2*)ws, gmax, d_table,
                  rp, (const uint4*)rows16);
