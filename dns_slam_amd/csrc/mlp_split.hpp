@@ -96,9 +96,12 @@ __device__ __forceinline__ Frag3 split8_bf3(const float (&v)[8]) {
 }
 
 // PREC == 1 (tcnn's half-precision mode): two parts (16 bits, at least fp16's 11) and three products
+#ifndef DNS_WGRAD_PRODUCTS
+#define DNS_WGRAD_PRODUCTS 6
+#endif
 template <int PREC>
 __device__ __forceinline__ f32x16 mma_pt(const Frag3& a, const Frag3& b, f32x16 acc) {
-  if (PREC == 3) {
+  if (PREC == 3 && DNS_WGRAD_PRODUCTS == 6) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
