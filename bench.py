@@ -83,7 +83,7 @@ def kernel_cost(entry, kernel, units, info, wl):
     if k in ("hashgrid_bwd_binned_kernel", "hashgrid_bwd_queue_kernel"):
         return ("hbm", units * ((L - n_list) * (2 * 8 * 8 + 8) + 12))
     if k == "hashgrid_bwd_pairbins_kernel":
-        return ("hbm", units * n_list * (2 * 8 * 8 + 4 * (4 + 12 + 8)))
+        return ("hbm", units * (n_list * (2 * 8 * 8 + 8 + 4 * 4) + 12))     # the RMW (SURVEY 8d prices it as memory traffic) + gradient + entries
     if k == "hashgrid_bwd_pairlist_kernel":
         return ("hbm", units * n_list * (2 * (12 + 8) + 16))
     if k in ("composite_fwd_kernel", "composite_bwd_kernel"):
