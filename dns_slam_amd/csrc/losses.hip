@@ -20,7 +20,7 @@ namespace dns {
 // sums[] layout
 enum { S_P = 0, S_D, S_L, S_LT, S_FS, S_OP, S_NV, S_ND, S_NFRONT, S_NOMASK, S_COUNT = 16,
        S_PARTIALS = 32, S_MAX_BLOCKS = 1024 };   // workspace behind the 16 results: DNS_LOSS_SUMS_FLOATS
-constexpr uint32_t LOSS_POINT_BLOCKS = 512;   // x 256 threads x 4 quads per trip; <= S_MAX_BLOCKS (5 partial sums each)
+constexpr uint32_t LOSS_POINT_BLOCKS = 1024;  // x 256 threads x 4 quads per trip; <= S_MAX_BLOCKS (5 partial sums each)
 // out[] layout: terms p,d,l,lt,fs,op, total ; coefficients
 enum { O_P = 0, O_D, O_L, O_LT, O_FS, O_OP, O_TOTAL, O_CP = 8, O_CD, O_CL, O_CLT, O_CFS, O_COP };
 
@@ -46,32 +46,30 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 __device__ __forceinline__ bool ray_valid(const uint8_t* valid, uint32_t n) { return valid ? valid[n] != 0 : true; }
 
-__global__ __launch_bounds__(256) void loss_ray_sums_kernel(LossCfg c, const float* __restrict__ pred_color,
-                                                            const float* __restrict__ pred_depth,
-                                                            const float* __restrict__ pred_var,
-                                                            const float* __restrict__ logits,
-                                                            const float* __restrict__ gt_color,
-                                                            const float* __restrict__ gt_depth,
-                                                            const int64_t* __restrict__ gt_label,
-                                                            const uint8_t* __restrict__ valid, float* __restrict__ sums,
-                                                            uint32_t n_partials) {
-  __shared__ float sh[4];
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  float sp = 0.f, sd = 0.f, sl = 0.f, nv = 0.f, nd = 0.f;
+struct RayTerms {
+  float sp, sd, sl, nv, nd;
+};
+// one ray's numerators and counts (slams/mapping.py:110-126, slams/tracking.py:85-96)
+__device__ __forceinline__ RayTerms ray_terms(const LossCfg& c, uint32_t n, const float* __restrict__ pred_color,
+                                              const float* __restrict__ pred_depth, const float* __restrict__ pred_var,
+                                              const float* __restrict__ logits, const float* __restrict__ gt_color,
+                                              const float* __restrict__ gt_depth, const int64_t* __restrict__ gt_label,
+                                              const uint8_t* __restrict__ valid) {
+  RayTerms r = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (n < c.N && ray_valid(valid, n)) {
-    nv = 1.f;
+    r.nv = 1.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const float e = gt_color[(size_t)n * 3 + k] - pred_color[(size_t)n * 3 + k];
-      sp += e * e;
+      r.sp += e * e;
     }
     const float gd = gt_depth[n];
     if (c.tracker) {
-      sd = fabsf(gd - pred_depth[n]) / sqrtf(pred_var[n] + 1e-10f);
-      nd = 1.f;
+      r.sd = fabsf(gd - pred_depth[n]) / sqrtf(pred_var[n] + 1e-10f);
+      r.nd = 1.f;
     } else if (gd > 0.f) {
-      sd = fabsf(gd - pred_depth[n]);
-      nd = 1.f;
+      r.sd = fabsf(gd - pred_depth[n]);
+      r.nd = 1.f;
     }
     if (c.C) {
       const float* lg = logits + (size_t)n * c.C;
@@ -81,9 +79,25 @@ __global__ __launch_bounds__(256) void loss_ray_sums_kernel(LossCfg c, const flo
       for (uint32_t k = 0; k < c.C; ++k) se += expf(lg[k] - mx);
       const int64_t lab = gt_label[n];
       const float ll = (lab >= 0 && lab < (int64_t)c.C) ? lg[lab] : 0.f;
-      sl = (mx + logf(se)) - ll;
+      r.sl = (mx + logf(se)) - ll;
     }
   }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void loss_ray_sums_kernel(LossCfg c, const float* __restrict__ pred_color,
+                                                            const float* __restrict__ pred_depth,
+                                                            const float* __restrict__ pred_var,
+                                                            const float* __restrict__ logits,
+                                                            const float* __restrict__ gt_color,
+                                                            const float* __restrict__ gt_depth,
+                                                            const int64_t* __restrict__ gt_label,
+                                                            const uint8_t* __restrict__ valid, float* __restrict__ sums,
+                                                            uint32_t n_partials) {
+  __shared__ float sh[16];
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  const RayTerms rt = ray_terms(c, n, pred_color, pred_depth, pred_var, logits, gt_color, gt_depth, gt_label, valid);
+  const float sp = rt.sp, sd = rt.sd, sl = rt.sl, nv = rt.nv, nd = rt.nd;
   float t;
   t = block_sum(sp, sh); if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + S_P, t);
   t = block_sum(sd, sh); if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + S_D, t);
@@ -227,8 +241,8 @@ __global__ __launch_bounds__(256) void loss_point_sums_kernel(LossCfg c, const f
   }
 }
 
-__global__ void loss_finalize_kernel(LossCfg c, const float* __restrict__ sums, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// sums -> the loss terms and the per-element gradient coefficients (one thread)
+__device__ __forceinline__ void finalize_terms(const LossCfg& c, const float* sums, float* out) {
   const float nv = sums[S_NV], nd = sums[S_ND];
   const float np = nv * (float)c.S;                      // points of valid rays
   const float p = sums[S_P] / (3.f * nv);
@@ -251,21 +265,19 @@ __global__ void loss_finalize_kernel(LossCfg c, const float* __restrict__ sums, 
   out[O_COP] = c.tracker ? 0.f : flag * c.lambda_op * 2.f / np;
 }
 
-__global__ __launch_bounds__(256) void loss_ray_bwd_kernel(LossCfg c, const float* __restrict__ out,
-                                                           const float* __restrict__ g_total,
-                                                           const float* __restrict__ pred_color,
-                                                           const float* __restrict__ pred_depth,
-                                                           const float* __restrict__ pred_var,
-                                                           const float* __restrict__ logits,
-                                                           const float* __restrict__ gt_color,
-                                                           const float* __restrict__ gt_depth,
-                                                           const int64_t* __restrict__ gt_label,
-                                                           const uint8_t* __restrict__ valid, float* __restrict__ d_color,
-                                                           float* __restrict__ d_depth, float* __restrict__ d_var,
-                                                           float* __restrict__ d_logits) {
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= c.N) return;
-  const float g = g_total[0];
+__global__ void loss_finalize_kernel(LossCfg c, const float* __restrict__ sums, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  finalize_terms(c, sums, out);
+}
+
+// one ray's gradients of the three ray terms
+__device__ __forceinline__ void ray_bwd_one(const LossCfg& c, const float* out, float g, uint32_t n,
+                                            const float* __restrict__ pred_color, const float* __restrict__ pred_depth,
+                                            const float* __restrict__ pred_var, const float* __restrict__ logits,
+                                            const float* __restrict__ gt_color, const float* __restrict__ gt_depth,
+                                            const int64_t* __restrict__ gt_label, const uint8_t* __restrict__ valid,
+                                            float* __restrict__ d_color, float* __restrict__ d_depth, float* __restrict__ d_var,
+                                            float* __restrict__ d_logits) {
   const bool ok = ray_valid(valid, n);
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -300,6 +312,81 @@ __global__ __launch_bounds__(256) void loss_ray_bwd_kernel(LossCfg c, const floa
       for (uint32_t k = 0; k < c.C; ++k) dl[k] = cl * (expf(lg[k] - mx) / se - ((int64_t)k == lab ? 1.f : 0.f));
     }
   }
+}
+
+__global__ __launch_bounds__(256) void loss_ray_bwd_kernel(LossCfg c, const float* __restrict__ out,
+                                                           const float* __restrict__ g_total,
+                                                           const float* __restrict__ pred_color,
+                                                           const float* __restrict__ pred_depth,
+                                                           const float* __restrict__ pred_var,
+                                                           const float* __restrict__ logits,
+                                                           const float* __restrict__ gt_color,
+                                                           const float* __restrict__ gt_depth,
+                                                           const int64_t* __restrict__ gt_label,
+                                                           const uint8_t* __restrict__ valid, float* __restrict__ d_color,
+                                                           float* __restrict__ d_depth, float* __restrict__ d_var,
+                                                           float* __restrict__ d_logits) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= c.N) return;
+  ray_bwd_one(c, out, g_total[0], n, pred_color, pred_depth, pred_var, logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth,
+              d_var, d_logits);
+}
+
+// Rays' sums + finalize + rays' backward as ONE single-workgroup launch (dns_loss_rays): the three are a few microseconds of
+// work each behind a launch each -- on the mapper's critical chain, and four of the tracker's ~33 launches per iteration (its
+// 16-word clear included).  Valid when nothing has to happen between the sums and the coefficients (no all-reduce).
+// 1024 threads walk the rays twice; the sums are exact per-thread partials reduced in a fixed order (no atomics).
+__global__ __launch_bounds__(1024) void loss_rays_fused_kernel(LossCfg c, const float* __restrict__ pred_color,
+                                                               const float* __restrict__ pred_depth,
+                                                               const float* __restrict__ pred_var,
+                                                               const float* __restrict__ logits,
+                                                               const float* __restrict__ gt_color,
+                                                               const float* __restrict__ gt_depth,
+                                                               const int64_t* __restrict__ gt_label,
+                                                               const uint8_t* __restrict__ valid, float* __restrict__ sums,
+                                                               uint32_t n_partials, float* __restrict__ out,
+                                                               const float* __restrict__ g_total, float* __restrict__ d_color,
+                                                               float* __restrict__ d_depth, float* __restrict__ d_var,
+                                                               float* __restrict__ d_logits) {
+  __shared__ float sh[16];
+  __shared__ float s_sums[S_COUNT], s_out[16];
+  RayTerms a = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (uint32_t n = threadIdx.x; n < c.N; n += blockDim.x) {
+    const RayTerms r = ray_terms(c, n, pred_color, pred_depth, pred_var, logits, gt_color, gt_depth, gt_label, valid);
+    a.sp += r.sp; a.sd += r.sd; a.sl += r.sl; a.nv += r.nv; a.nd += r.nd;
+  }
+  if (threadIdx.x < S_COUNT) s_sums[threadIdx.x] = 0.f;
+  const float rv[5] = {a.sp, a.sd, a.sl, a.nv, a.nd};
+  const int rd[5] = {S_P, S_D, S_L, S_NV, S_ND};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float t = block_sum(rv[i], sh);
+    if (threadIdx.x == 0) s_sums[rd[i]] = t;
+  }
+  if (n_partials) {                                  // the point pass's parked partial sums (loss_point_sums_kernel, launched before)
+    const float* partial = sums + S_PARTIALS;
+    const int dst[5] = {S_LT, S_FS, S_OP, S_NFRONT, S_NOMASK};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float v = 0.f;
+      for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) v += partial[b * 5u + i];
+      const float t = block_sum(v, sh);
+      if (threadIdx.x == 0) s_sums[dst[i]] = t;
+    }
+  }
+  if (threadIdx.x == 0) {
+    finalize_terms(c, s_sums, s_out);
+    s_out[7] = 0.f; s_out[14] = 0.f; s_out[15] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    sums[threadIdx.x] = s_sums[threadIdx.x];
+    out[threadIdx.x] = s_out[threadIdx.x];
+  }
+  const float g = g_total[0];
+  for (uint32_t n = threadIdx.x; n < c.N; n += blockDim.x)
+    ray_bwd_one(c, s_out, g, n, pred_color, pred_depth, pred_var, logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var,
+                d_logits);
 }
 
 __global__ __launch_bounds__(256) void loss_point_bwd_kernel(LossCfg c, const float* __restrict__ out,
@@ -422,13 +509,40 @@ extern "C" int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint3
   if (!tracker) {
     const uint64_t E = (uint64_t)N * S * L;
     // few, fat workgroups: each parks 5 partial sums that workgroup 0 of the ray kernel (launched next) adds up
-    const uint32_t cap = LOSS_POINT_BLOCKS;
+    static const uint32_t cap_env = [] { const char* e = getenv("DNS_LOSS_BLOCKS"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1 && n <= (long)S_MAX_BLOCKS ? n : 0); }();
+    const uint32_t cap = cap_env ? cap_env : LOSS_POINT_BLOCKS;
     blocks = (uint32_t)((E + 255) / 256 < cap ? (E + 255) / 256 : cap);
     DNS_LAUNCH(loss_point_sums_kernel, dim3(blocks), dim3(256), 0, st, c, fine, coarse, z, gt_depth, valid, sums);
   }
   DNS_LAUNCH(loss_ray_sums_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, pred_color, pred_depth, pred_var,
                      pred_logits, gt_color, gt_depth, gt_label, valid, sums, blocks);
   return check_launch("dns_loss_sums");
+}
+
+extern "C" int dns_loss_rays(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
+                             const float* pred_color, const float* pred_depth, const float* pred_var, const float* pred_logits,
+                             const float* gt_color, const float* gt_depth, const int64_t* gt_label, const uint8_t* valid,
+                             const float* fine, const float* coarse, const float* z, float* sums, float* out, const float* g_total,
+                             float* d_color, float* d_depth, float* d_var, float* d_logits, void* stream) {
+  DNS_REQUIRE(lambdas && sums && out && g_total, "dns_loss_rays: NULL argument");
+  DNS_REQUIRE(N >= 1 && N <= (1u << 20), "dns_loss_rays: N %u outside [1, 2^20] (use dns_loss_sums / _finalize / _bwd)", N);
+  DNS_REQUIRE(pred_color && pred_depth && gt_color && gt_depth && d_color && d_depth, "dns_loss_rays: NULL ray tensor");
+  DNS_REQUIRE(C == 0 || (pred_logits && gt_label && d_logits), "dns_loss_rays: C > 0 needs logits, labels and d_logits");
+  DNS_REQUIRE(!tracker || pred_var, "dns_loss_rays: tracker mode needs pred_var");
+  DNS_REQUIRE(tracker || (fine && coarse && z && L >= 1 && S >= 1), "dns_loss_rays: mapper mode needs fine, coarse, z");
+  DNS_REQUIRE(tracker || (uint64_t)N * S * L < (1ull << 32) - (1ull << 22), "dns_loss_rays: N*S*L must stay below 2^32");
+  const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t blocks = 0;
+  if (!tracker) {
+    const uint64_t E = (uint64_t)N * S * L;
+    const uint32_t cap = LOSS_POINT_BLOCKS;
+    blocks = (uint32_t)((E + 255) / 256 < cap ? (E + 255) / 256 : cap);
+    DNS_LAUNCH(loss_point_sums_kernel, dim3(blocks), dim3(256), 0, st, c, fine, coarse, z, gt_depth, valid, sums);
+  }
+  DNS_LAUNCH(loss_rays_fused_kernel, dim3(1), dim3(1024), 0, st, c, pred_color, pred_depth, pred_var, pred_logits, gt_color, gt_depth,
+             gt_label, valid, sums, blocks, out, g_total, d_color, d_depth, d_var, d_logits);
+  return check_launch("dns_loss_rays");
 }
 
 extern "C" int dns_loss_finalize(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,

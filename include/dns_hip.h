@@ -335,6 +335,15 @@ int dns_composite_bwd_ex(const float* raw, const float* z, const float* logits, 
  * d_fine, d_coarse (overwritten; both NULL in mapper mode: the ray part only, see dns_loss_bwd_points).  ldd_fine: row stride of d_fine in floats (0 = L, contiguous) -- lets the caller place the
  * fine decoder's loss gradient straight into a wider row that later kernels add to (fused_step.MapStep). */
 #define DNS_LOSS_SUMS_FLOATS (32 + 5 * 1024)
+/* dns_loss_rays (ABI v10) = dns_loss_sums + dns_loss_finalize + the RAY part of dns_loss_bwd where nothing has to happen between the
+ * sums and the coefficients (one rank, no all-reduce): the point pass's partial sums (mapper) and ONE single-workgroup kernel that
+ * walks the rays, reduces in a fixed order (no atomics: sums[0..15] are reproducible), finalises out[16] and writes d_color,
+ * d_depth, d_var (tracker; may be NULL), d_logits.  1 <= N <= 2^20.  The mapper's point gradients follow with dns_loss_bwd_points. */
+int dns_loss_rays(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
+                  const float* pred_color, const float* pred_depth, const float* pred_var, const float* pred_logits,
+                  const float* gt_color, const float* gt_depth, const int64_t* gt_label, const uint8_t* valid,
+                  const float* fine, const float* coarse, const float* z, float* sums, float* out, const float* g_total,
+                  float* d_color, float* d_depth, float* d_var, float* d_logits, void* stream);
 int dns_loss_sums(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
                   const float* pred_color, const float* pred_depth, const float* pred_var, const float* pred_logits,
                   const float* gt_color, const float* gt_depth, const int64_t* gt_label, const uint8_t* valid,

@@ -260,6 +260,56 @@ def test_track_step_equals_the_tracker_loop(code):
     assert float((out["autograd"][0][4:] - c2w[:3, 3]).abs().max()) > 0        # the pose did move
 
 
+@pytest.mark.parametrize("tracker", [0, 1])
+@pytest.mark.parametrize("N", [300, 4096, 5000])
+def test_loss_rays_single_launch_equals_the_three_calls(tracker, N):
+    """dns_loss_rays (ABI v10: the point pass's partial sums + ONE single-workgroup kernel for the rays' sums, the finalize and the
+    rays' backward) against dns_loss_sums -> dns_loss_finalize -> dns_loss_bwd(rays): the same per-ray arithmetic (shared device
+    functions), the sums differ only in the order of the fp32 adds (fixed-order tree instead of float atomics): 16 sums and
+    16 outputs to 2e-6, gradients to 2e-6 of their scale (they carry the coefficients).  Mapper (with the point terms) and
+    tracker mode, some rays invalid, N below / at / above a multiple of the workgroup."""
+    lib, check, ptr, stream_ptr = _lib()
+    from ctypes import c_float
+    from dns_slam_amd import ops
+    g = torch.Generator().manual_seed(20 + N + tracker)
+    S, Cn, L = (1, 8, 1) if tracker else (24, 8, 33)
+    P = N * S
+    pc, pd = torch.rand(N, 3, generator=g).to(DEV), (torch.rand(N, generator=g) * 3).to(DEV)
+    pv, ps = (torch.rand(N, generator=g) + 0.01).to(DEV), torch.randn(N, Cn, generator=g).to(DEV)
+    gc, gd = torch.rand(N, 3, generator=g).to(DEV), (torch.rand(N, generator=g) * 3).to(DEV)
+    gd[::7] = 0.0
+    lab = torch.randint(0, Cn, (N,), generator=g).to(DEV)
+    valid = (torch.rand(N, generator=g) > 0.1).to(torch.uint8).to(DEV)
+    fine, coarse = torch.randn(P, L, generator=g).to(DEV), torch.randn(P, L, generator=g).to(DEV)
+    z = torch.sort(torch.rand(N, S, generator=g) * 3 + 0.1, dim=1).values.to(DEV)
+    one = torch.full((1,), 0.7, device=DEV)
+    lam = (c_float * 8)(5.0, 5.0, 0.1, 0.0 if tracker else 10.0, 0.0 if tracker else 10.0, 0.0 if tracker else 10.0, 0.2, 0.05)
+    f = lambda *s_: torch.full(s_, float("nan"), device=DEV)
+    pts = (None, None, None) if tracker else (ptr(fine), ptr(coarse), ptr(z))
+    var = ptr(pv) if tracker else None
+    res = []
+    for fused in (False, True):
+        sums, out = f(ops.LOSS_SUMS_FLOATS), f(16)
+        dcol, ddep, dvar, dsem = f(N, 3), f(N), f(N), f(N, Cn)
+        dv = ptr(dvar) if tracker else None
+        if fused:
+            check(lib.dns_loss_rays(lam, N, S, Cn, L, tracker, ptr(pc), ptr(pd), var, ptr(ps), ptr(gc), ptr(gd), ptr(lab), ptr(valid), *pts,
+                                    ptr(sums), ptr(out), ptr(one), ptr(dcol), ptr(ddep), dv, ptr(dsem), stream_ptr()), "loss_rays")
+        else:
+            check(lib.dns_loss_sums(lam, N, S, Cn, L, tracker, ptr(pc), ptr(pd), var, ptr(ps), ptr(gc), ptr(gd), ptr(lab), ptr(valid), *pts,
+                                    ptr(sums), stream_ptr()), "loss_sums")
+            check(lib.dns_loss_finalize(lam, N, S, Cn, L, tracker, ptr(sums), ptr(out), stream_ptr()), "loss_finalize")
+            check(lib.dns_loss_bwd(lam, N, S, Cn, L, tracker, ptr(out), ptr(one), ptr(pc), ptr(pd), var, ptr(ps), ptr(gc), ptr(gd), ptr(lab),
+                                   ptr(valid), *pts, ptr(dcol), ptr(ddep), dv, ptr(dsem), None, None, 0, stream_ptr()), "loss_bwd")
+        torch.cuda.synchronize()
+        used = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13]
+        res.append((sums[:10].cpu(), out[used].cpu(), dcol.cpu(), ddep.cpu(), (dvar if tracker else ddep).cpu(), dsem.cpu()))
+    for a, b, name in zip(res[1], res[0], ("sums", "out", "d colour", "d depth", "d var", "d logits")):
+        assert torch.isfinite(b).all(), name
+        assert_close(a, b, rtol=2e-6, what=f"dns_loss_rays ({'tracker' if tracker else 'mapper'}, N={N}): {name}", elementwise=False)
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12, name
+
+
 def test_track_step_is_reused_across_frames():
     """``Tracker.track_frame(use_track_step)`` keeps ONE TrackStep (buffers, prepared-weight storage, captured graph) and resets it
     per frame: the second frame of a cached, graph-replaying tracker must give what a FRESH tracker gives for that frame from

@@ -27,6 +27,7 @@ ENTRY = {  # C-ABI entry point -> kernels it launches
     "dns_mlp_dwin": ["mlp_dwin_kernel"], "dns_feature_gather_frames": ["feature_gather_frames_kernel"],
     "dns_merge_dy": ["merge_dy_kernel"], "dns_add_ref_sum": ["add_ref_sum_kernel"], "dns_refer_poses": ["refer_poses_kernel"],
     "dns_draw_finish": ["draw_finish_kernel"], "dns_loss_finalize": ["loss_finalize_kernel"],
+    "dns_loss_rays": ["loss_point_sums_kernel", "loss_rays_fused_kernel"],
 }
 GATHER = ("encode_fwd_kernel", "encode_fwd_split_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel", "feature_gather_frames_kernel",
           "hashgrid_bwd_pairbins_kernel", "hashgrid_bwd_pairlist_kernel")
