@@ -70,6 +70,7 @@ SIGNATURES = {
     "dns_feature_block_split": (C.c_int, [_P, _U, _U, _P, _U, _U, _U, _P, _P, _U, _U, _P, _U, _P, _U, _P, _U, _P, _P]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_loss_rays": (C.c_int, [_P, _U, _U, _U, _U, _I] + [_P] * 19),
+    "dns_loss_finalize_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I] + [_P] * 16),
     "dns_loss_finalize": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P]),
     "dns_loss_bwd": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _P, _U, _P]),

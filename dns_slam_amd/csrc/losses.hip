@@ -325,7 +325,21 @@ __global__ __launch_bounds__(256) void loss_ray_bwd_kernel(LossCfg c, const floa
                                                            const int64_t* __restrict__ gt_label,
                                                            const uint8_t* __restrict__ valid, float* __restrict__ d_color,
                                                            float* __restrict__ d_depth, float* __restrict__ d_var,
-                                                           float* __restrict__ d_logits) {
+                                                           float* __restrict__ d_logits, const float* __restrict__ sums,
+                                                           float* __restrict__ out_w) {
+  // sums != NULL (dns_loss_finalize_bwd): the finalize runs HERE -- every workgroup turns the 16 sums into the terms and
+  // coefficients for itself (thirty flops), workgroup 0 also writes them to out_w for the kernels that follow; the one-thread
+  // finalize launch in front of this kernel is gone from the iteration's critical chain
+  __shared__ float s_out[16];
+  if (sums) {
+    if (threadIdx.x == 0) {
+      finalize_terms(c, sums, s_out);
+      s_out[7] = 0.f; s_out[14] = 0.f; s_out[15] = 0.f;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 16) out_w[threadIdx.x] = s_out[threadIdx.x];
+    out = s_out;
+  }
   const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= c.N) return;
   ray_bwd_one(c, out, g_total[0], n, pred_color, pred_depth, pred_var, logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth,
@@ -568,7 +582,8 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
   const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
   hipStream_t st = (hipStream_t)stream;
   DNS_LAUNCH(loss_ray_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, c, out, g_total, pred_color, pred_depth,
-                     pred_var, pred_logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var, d_logits);
+                     pred_var, pred_logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var, d_logits, (const float*)nullptr,
+                     (float*)nullptr);
   if (!tracker && d_fine) {
     const uint64_t E = (uint64_t)N * S * L;
     const uint32_t blocks = (uint32_t)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
@@ -576,6 +591,21 @@ extern "C" int dns_loss_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32
                        valid, d_fine, d_coarse, ldd_fine ? ldd_fine : L, nullptr, 0u);
   }
   return check_launch("dns_loss_bwd");
+}
+
+extern "C" int dns_loss_finalize_bwd(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, int tracker,
+                                     const float* sums, float* out, const float* g_total, const float* pred_color,
+                                     const float* pred_depth, const float* pred_var, const float* pred_logits, const float* gt_color,
+                                     const float* gt_depth, const int64_t* gt_label, const uint8_t* valid, float* d_color,
+                                     float* d_depth, float* d_var, float* d_logits, void* stream) {
+  DNS_REQUIRE(N >= 1, "dns_loss_finalize_bwd: N must be >= 1 (dns_loss_finalize handles the empty batch)");
+  DNS_REQUIRE(lambdas && sums && out && g_total && d_color && d_depth, "dns_loss_finalize_bwd: NULL argument");
+  DNS_REQUIRE(C == 0 || d_logits, "dns_loss_finalize_bwd: C > 0 needs d_logits");
+  const LossCfg c = make_cfg(lambdas, N, S, C, L, tracker);
+  DNS_LAUNCH(loss_ray_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, (const float*)nullptr, g_total,
+             pred_color, pred_depth, pred_var, pred_logits, gt_color, gt_depth, gt_label, valid, d_color, d_depth, d_var, d_logits, sums,
+             out);
+  return check_launch("dns_loss_finalize_bwd");
 }
 
 extern "C" int dns_loss_bwd_points(const float* lambdas, uint32_t N, uint32_t S, uint32_t C, uint32_t L, const float* out,

@@ -28,6 +28,7 @@ all-reduce) under the hash-grid scatter, and the rest after the two streams have
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -548,17 +549,14 @@ class MapStep:
         check(lib.dns_composite_fwd_ex(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.depth), ptr(self.var),
                                        ptr(self.rgb), ptr(self.weights), ptr(self.sem), 1, st), "dns_composite_fwd_ex")
         lam = self.lam
-        if self.dist_on:                                   # the 16 sums are all-reduced between the sums and the coefficients
-            check(lib.dns_loss_sums(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
-                                    ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(fine), ptr(self.coarse),
-                                    ptr(self.z), ptr(self.sums_ws), st), "dns_loss_sums")
+        # (dns_loss_rays -- the rays' sums, the finalize and the rays' backward as ONE single-workgroup launch -- is what the
+        #  tracker's 512 rays use; at 4096 rays one workgroup takes 63 us where the three launches take 22: measured, not used here)
+        check(lib.dns_loss_sums(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
+                                ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(fine), ptr(self.coarse),
+                                ptr(self.z), ptr(self.sums_ws), st), "dns_loss_sums")
+        if self.dist_on:
             m.dist.allreduce_sums(self.sums_ws[:16])
-            check(lib.dns_loss_finalize(lam, N, S, Cn, L, 0, ptr(self.sums_ws), ptr(self.out), st), "dns_loss_finalize")
-        else:                                              # one rank: rays' sums + finalize + rays' backward in one launch
-            check(lib.dns_loss_rays(lam, N, S, Cn, L, 0, ptr(self.rgb), ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color),
-                                    ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside), ptr(fine), ptr(self.coarse),
-                                    ptr(self.z), ptr(self.sums_ws), ptr(self.out), ptr(self.one), ptr(self.d_color),
-                                    ptr(self.d_depth), None, ptr(self.d_sem), st), "dns_loss_rays")
+        # (the finalize runs inside the rays' backward kernel below: dns_loss_finalize_bwd)
 
         # ---- backward.  d_featx [P, 4 + n_feat]: column 3 = d occupancy, columns 4.. = the feature-block gradient of the colour /
         # logit networks, so columns 3 .. 3 + L are the fine network's output gradient in one strided view.  The losses write
@@ -568,11 +566,10 @@ class MapStep:
         d_fine_dst = _V(self.d_featx.data_ptr() + 4 * 3)
         # ray losses -> compositing (its d_raw[:, 0:3] IS the colour network's output gradient: the sigmoid's backward is folded
         # in) -> point losses, which also add the compositing's d occupancy (d_raw[:, 3]) into column 0 of d_fine
-        if self.dist_on:
-            check(lib.dns_loss_bwd(lam, N, S, Cn, L, 0, ptr(self.out), ptr(self.one), ptr(self.rgb), ptr(self.depth), None,
-                                   ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth), ptr(self.gt_label), ptr(self.inside),
-                                   ptr(fine), ptr(self.coarse), ptr(self.z), ptr(self.d_color), ptr(self.d_depth), None,
-                                   ptr(self.d_sem), None, None, 0, st), "dns_loss_bwd")
+        check(lib.dns_loss_finalize_bwd(lam, N, S, Cn, L, 0, ptr(self.sums_ws), ptr(self.out), ptr(self.one), ptr(self.rgb),
+                                        ptr(self.depth), None, ptr(self.sem), ptr(self.gt_color), ptr(self.gt_depth),
+                                        ptr(self.gt_label), ptr(self.inside), ptr(self.d_color), ptr(self.d_depth), None,
+                                        ptr(self.d_sem), st), "dns_loss_finalize_bwd")
         check(lib.dns_composite_bwd_ex(ptr(self.raw), ptr(self.z), ptr(self.logit), N, S, Cn, ptr(self.d_depth), None,
                                        ptr(self.d_color), None, ptr(self.d_sem), ptr(self.d_raw), ptr(self.d_logit), 1, st),
               "dns_composite_bwd_ex")

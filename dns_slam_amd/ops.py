@@ -72,7 +72,7 @@ class _TimedLib:
     _UNITS_ARG = {"dns_encode_fwd": 2, "dns_encode_bwd": 2, "dns_mlp_fwd": 12, "dns_mlp_bwd": 18,
                   "dns_composite_fwd": 3, "dns_composite_bwd": 3, "dns_raygen_sample": (14, 15), "dns_raygen_bwd": (7, 8),
                   "dns_rays_from_pixels": 12, "dns_mlp_dwin": 10, "dns_feature_block": (7, 8), "dns_loss_sums": (1, 2),
-                  "dns_loss_bwd": (1, 2), "dns_loss_rays": (1, 2), "dns_raw_bwd": 2, "dns_rgb_sigmoid": 1, "dns_class_slots": (1, 2),
+                  "dns_loss_bwd": (1, 2), "dns_loss_rays": (1, 2), "dns_loss_finalize_bwd": (1, 2), "dns_raw_bwd": 2, "dns_rgb_sigmoid": 1, "dns_class_slots": (1, 2),
                   "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5),
                   "dns_encode_fwd_split": 2, "dns_mlp_fwd_split": 10, "dns_mlp_bwd_split": 16, "dns_feature_block_split": (9, 10),
                   "dns_composite_fwd_ex": 3, "dns_composite_bwd_ex": 3, "dns_loss_bwd_points": (1, 2)}

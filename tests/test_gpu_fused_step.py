@@ -304,6 +304,24 @@ def test_loss_rays_single_launch_equals_the_three_calls(tracker, N):
         torch.cuda.synchronize()
         used = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13]
         res.append((sums[:10].cpu(), out[used].cpu(), dcol.cpu(), ddep.cpu(), (dvar if tracker else ddep).cpu(), dsem.cpu()))
+    # dns_loss_finalize_bwd: the finalize inside the rays' backward kernel, from the SAME sums -> bit-identical to the two launches
+    sums, out = f(ops.LOSS_SUMS_FLOATS), f(16)
+    dcol, ddep, dvar, dsem = f(N, 3), f(N), f(N), f(N, Cn)
+    dv = ptr(dvar) if tracker else None
+    check(lib.dns_loss_sums(lam, N, S, Cn, L, tracker, ptr(pc), ptr(pd), var, ptr(ps), ptr(gc), ptr(gd), ptr(lab), ptr(valid), *pts,
+                            ptr(sums), stream_ptr()), "loss_sums")
+    ref_out, ref = f(16), [f(N, 3), f(N), f(N), f(N, Cn)]
+    check(lib.dns_loss_finalize(lam, N, S, Cn, L, tracker, ptr(sums), ptr(ref_out), stream_ptr()), "loss_finalize")
+    check(lib.dns_loss_bwd(lam, N, S, Cn, L, tracker, ptr(ref_out), ptr(one), ptr(pc), ptr(pd), var, ptr(ps), ptr(gc), ptr(gd), ptr(lab),
+                           ptr(valid), *pts, ptr(ref[0]), ptr(ref[1]), ptr(ref[2]) if tracker else None, ptr(ref[3]), None, None, 0,
+                           stream_ptr()), "loss_bwd")
+    check(lib.dns_loss_finalize_bwd(lam, N, S, Cn, L, tracker, ptr(sums), ptr(out), ptr(one), ptr(pc), ptr(pd), var, ptr(ps), ptr(gc),
+                                    ptr(gd), ptr(lab), ptr(valid), ptr(dcol), ptr(ddep), dv, ptr(dsem), stream_ptr()), "loss_finalize_bwd")
+    torch.cuda.synchronize()
+    used_t = torch.tensor([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13])
+    assert torch.equal(out.cpu()[used_t], ref_out.cpu()[used_t])
+    assert torch.equal(dcol, ref[0]) and torch.equal(ddep, ref[1]) and torch.equal(dsem, ref[3])
+    assert not tracker or torch.equal(dvar, ref[2])
     for a, b, name in zip(res[1], res[0], ("sums", "out", "d colour", "d depth", "d var", "d logits")):
         assert torch.isfinite(b).all(), name
         assert_close(a, b, rtol=2e-6, what=f"dns_loss_rays ({'tracker' if tracker else 'mapper'}, N={N}): {name}", elementwise=False)
