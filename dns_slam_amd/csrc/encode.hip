@@ -1237,8 +1237,18 @@ struct ListPlan {
   uint32_t cap[DNS_MAX_LEVELS];                // entries per list of the level
   uint64_t qbase[DNS_MAX_LEVELS];              // word offset of the level's first list
   uint32_t chunk_shift;                        // log2(rows per chunk) = 13
-  uint32_t slices;                             // pass-2 workgroups per list
+  uint32_t slices;                             // pass-2 workgroups per list (static slicing: hashed levels only)
   uint32_t tiles;                              // 256-point tiles per pass-1 workgroup
+  // Dense levels (round 4, second half): their lists fill by where the rays are, so (a) they are sized EXACTLY -- a counting
+  // sweep, a scan kernel that places each chunk's list inside the level's region (at most 8 entries per point), a writing sweep --
+  // and (b) pass 2 cuts every list into jobs of `target` entries from the actual counts (`balanced`: the scan kernel's job
+  // prefix, searched in LDS) instead of a fixed number of slices per list.
+  uint32_t dense[DNS_MAX_LEVELS];              // 1: exact-size lists; qbase = the level's region, cap = its size (8 P)
+  uint32_t n_dense;
+  uint32_t dense_idx[DNS_MAX_LEVELS];          // list-level indices of the dense levels (grid.y of the writing sweep)
+  uint32_t balanced;                           // 1: jobs from the scan kernel
+  uint32_t target;                             // entries per balanced job
+  uint32_t max_jobs;                           // upper bound of the balanced job count (grid of pass 2)
 };
 
 // the two rows (level-relative) and weights of x-pair c (bit 0: y + 1, bit 1: z + 1) of a point
@@ -1289,15 +1299,20 @@ __global__ __launch_bounds__(LIST_THREADS) void hashgrid_bwd_pairlist_kernel(con
                                                                               const uint32_t* __restrict__ gmax,
                                                                               uint32_t* __restrict__ qcount,
                                                                               uint32_t* __restrict__ lists,
-                                                                              float* __restrict__ d_table) {
+                                                                              float* __restrict__ d_table, uint32_t mode,
+                                                                              const uint32_t* __restrict__ lbase) {
+  // mode 0: every list level; a hashed level is counted, reserved and written here, a DENSE level is only counted (qcount = the
+  // lists' sizes).  mode 1: the dense levels' writing sweep (blockIdx.y indexes lp.dense_idx; qcount = the lists' cursors, lbase =
+  // where the scan kernel placed each list inside its level's region).
   // A workgroup takes LIST_TILES x 256 consecutive points of one level.  Sweep A counts its entries per chunk in LDS, the first
   // wave then reserves one run per chunk in the global lists -- ONE atomic per chunk and 2048 points: a reservation per 256 points
   // put 4096 same-address atomics per list behind each other and took longer than everything else --, sweep B forms the chunks
   // again (two multiplies and a few xors per pair) and writes every entry at its run's next free slot.
   __shared__ uint32_t cnt[PART_MAX_CHUNKS], gofs[PART_MAX_CHUNKS];
   if (!(__uint_as_float(*gmax) > 0.f) || gmax[1] != 0u) return;   // all-zero or poisoned upstream gradient: pass 2 handles both
-  const uint32_t li = blockIdx.y;
+  const uint32_t li = mode ? lp.dense_idx[blockIdx.y] : blockIdx.y;
   const uint32_t l = lp.level[li], C = lp.chunks[li], cap = lp.cap[li];
+  const bool exact = lp.dense[li] != 0;          // uniform
   const float s = lv.scale[l];
   const uint32_t size = lv.size[l], res = lv.resolution[l];
   const bool hashed = lv.hashed[l] != 0;         // uniform
@@ -1330,8 +1345,10 @@ __global__ __launch_bounds__(LIST_THREADS) void hashgrid_bwd_pairlist_kernel(con
   for (uint32_t c = threadIdx.x; c < C; c += LIST_THREADS) {
     const uint32_t v = cnt[c];
     gofs[c] = v ? atomicAdd(&qcount[lp.qoff[li] + c], v) : 0u;
+    if (mode) gofs[c] += lbase[lp.qoff[li] + c];  // exact lists: slot inside the level's region
     cnt[c] = 0;                                  // now the run's next free slot
   }
+  if (exact && !mode) return;                    // (uniform) dense level, counting launch: nothing is written yet
   __syncthreads();
   uint32_t* __restrict__ ql = lists + lp.qbase[li];
   float* __restrict__ tl = d_table + 2 * (size_t)lv.offset[l];
@@ -1350,6 +1367,11 @@ __global__ __launch_bounds__(LIST_THREADS) void hashgrid_bwd_pairlist_kernel(con
       const uint32_t c0 = l0 >> lp.chunk_shift, c1 = l1 >> lp.chunk_shift;
       const uint32_t at0 = gofs[c0] + atomicAdd(&cnt[c0], 1u);
       const uint32_t at1 = c1 != c0 ? gofs[c1] + atomicAdd(&cnt[c1], 1u) : 0u;
+      if (exact) {                               // every entry has its place
+        ql[at0] = (p << 2) | c;
+        if (c1 != c0) ql[at1] = (p << 2) | c;
+        continue;
+      }
       const bool over0 = at0 >= cap, over1 = c1 != c0 && at1 >= cap;
       if (!over0) ql[(size_t)c0 * cap + at0] = (p << 2) | c;
       if (c1 != c0 && !over1) ql[(size_t)c1 * cap + at1] = (p << 2) | c;
@@ -1370,12 +1392,89 @@ __global__ __launch_bounds__(LIST_THREADS) void hashgrid_bwd_pairlist_kernel(con
   }
 }
 
+// Exclusive prefix sums over the lists (one workgroup, <= 8192 lists): where each dense list starts inside its level's region,
+// and how many jobs of `target` entries precede each list (jobstart[n_lists] = all of them).
+__global__ __launch_bounds__(1024) void hashgrid_bwd_pairscan_kernel(ListPlan lp, const uint32_t* __restrict__ qcount,
+                                                                      uint32_t* __restrict__ lbase, uint32_t* __restrict__ jobstart) {
+  __shared__ uint32_t s_n[8192], s_wave[16];
+  // the plan's per-level arrays in LDS (a per-thread index into the kernel-argument struct would go through scratch memory), the
+  // level of every list in one byte, the counts read once
+  __shared__ uint32_t s_qoff[DNS_MAX_LEVELS + 1], s_cap[DNS_MAX_LEVELS], s_dense[DNS_MAX_LEVELS];
+  __shared__ uint8_t s_lvl[8192];
+  const uint32_t n_lists = lp.qoff[lp.n];
+  if (threadIdx.x <= DNS_MAX_LEVELS) s_qoff[threadIdx.x] = lp.qoff[threadIdx.x < DNS_MAX_LEVELS ? threadIdx.x : DNS_MAX_LEVELS];
+  if (threadIdx.x < DNS_MAX_LEVELS) {
+    s_cap[threadIdx.x] = lp.cap[threadIdx.x];
+    s_dense[threadIdx.x] = lp.dense[threadIdx.x];
+  }
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < n_lists; q += blockDim.x) {
+    uint32_t li = 0;
+    while (li + 1 < lp.n && q >= s_qoff[li + 1]) ++li;
+    s_lvl[q] = (uint8_t)li;
+    s_n[q] = s_dense[li] ? qcount[q] : min(qcount[q], s_cap[li]);
+  }
+  __syncthreads();
+  constexpr uint32_t PER = 8;                    // lists per thread
+  const uint32_t t0 = threadIdx.x * PER;
+  auto level_of = [&](uint32_t q) { return (uint32_t)s_lvl[q]; };
+  uint32_t cnt[PER];
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) cnt[k] = t0 + k < n_lists ? s_n[t0 + k] : 0u;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {         // pass 0: entries of dense lists (placement), pass 1: jobs of every list
+    uint32_t v[PER], run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t q = t0 + k;
+      uint32_t x = 0;
+      if (q < n_lists) {
+        const uint32_t n = cnt[k];
+        x = pass == 0 ? (s_dense[level_of(q)] ? n : 0u) : (n + lp.target - 1u) / lp.target;
+      }
+      v[k] = run;
+      run += x;
+    }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63u) >= o) incl += t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 63u) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += s_wave[w];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k)
+      if (t0 + k < n_lists) s_n[t0 + k] = base + v[k];
+    if (threadIdx.x == 1023u) s_n[8191] = base + run;     // grand total (n_lists < 8192 is checked on the host)
+    __syncthreads();
+    if (pass == 0) {
+#pragma unroll
+      for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t q = t0 + k;
+        if (q < n_lists) lbase[q] = s_n[q] - s_n[s_qoff[level_of(q)]];   // restart at every level
+      }
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < PER; ++k)
+        if (t0 + k < n_lists) jobstart[t0 + k] = s_n[t0 + k];
+      if (threadIdx.x == 0) jobstart[n_lists] = s_n[8191];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(1024) void hashgrid_bwd_pairbins_kernel(const float* __restrict__ xin, uint32_t P, GridLevels lv,
                                                                       ListPlan lp, const float2* __restrict__ dg_t,
                                                                       const uint32_t* __restrict__ qcount,
                                                                       const uint32_t* __restrict__ lists,
                                                                       const uint32_t* __restrict__ gmax,
-                                                                      float* __restrict__ d_table) {
+                                                                      float* __restrict__ d_table,
+                                                                      const uint32_t* __restrict__ lbase,
+                                                                      const uint32_t* __restrict__ jobstart) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];
   const float mx = __uint_as_float(*gmax);
   const bool poisoned = gmax[1] != 0u;           // NaN / Inf upstream: NaN into the list's rows (see the binned kernel)
@@ -1387,7 +1486,31 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_pairbins_kernel(const float
   (void)frexpf(mx, &ex);
   const float scale = ldexpf(1.0f, 40 - ex);
   const double inv_scale = (double)ldexpf(1.0f, ex - 40);
-  const uint32_t qi = blockIdx.x / lp.slices, slice = blockIdx.x % lp.slices;   // list = (level, chunk)
+  uint32_t qi, slice;                            // list = (level, chunk), and which part of it
+  if (lp.balanced && !poisoned) {
+    // job -> list: the job prefix (n_lists + 1 words, behind the bins in LDS) is searched for the last list that starts at or
+    // before this job
+    uint32_t* js = reinterpret_cast<uint32_t*>(bins + ((size_t)2 << lp.chunk_shift));
+    const uint32_t n_lists = lp.qoff[lp.n];
+    for (uint32_t i = threadIdx.x; i <= n_lists; i += blockDim.x) js[i] = jobstart[i];
+    __syncthreads();
+    if (blockIdx.x >= js[n_lists]) return;       // (uniform) past the last job of this launch
+    uint32_t lo_q = 0, hi_q = n_lists;           // invariant: js[lo_q] <= job < js[hi_q]
+    while (hi_q - lo_q > 1u) {
+      const uint32_t mid = (lo_q + hi_q) >> 1;
+      if (js[mid] <= blockIdx.x) lo_q = mid; else hi_q = mid;
+    }
+    qi = lo_q;
+    slice = blockIdx.x - js[qi];
+    __syncthreads();                             // js lives in LDS the bins do not use; nothing else to order
+  } else if (lp.balanced) {                      // poisoned: one job per list writes the NaNs
+    qi = blockIdx.x;
+    slice = 0;
+    if (qi >= lp.qoff[lp.n]) return;
+  } else {
+    qi = blockIdx.x / lp.slices;
+    slice = blockIdx.x % lp.slices;
+  }
   uint32_t li = 0;
   while (li + 1 < lp.n && qi >= lp.qoff[li + 1]) ++li;
   const uint32_t ch = qi - lp.qoff[li], l = lp.level[li], cap = lp.cap[li];
@@ -1400,10 +1523,17 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_pairbins_kernel(const float
       for (uint32_t i = threadIdx.x; i < rows * 2; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
     return;
   }
-  const uint32_t n = min(qcount[qi], cap);
-  const uint32_t lo = (uint32_t)(((uint64_t)n * slice) / lp.slices), hi = (uint32_t)(((uint64_t)n * (slice + 1)) / lp.slices);
+  const uint32_t n = lp.dense[li] ? qcount[qi] : min(qcount[qi], cap);
+  uint32_t lo, hi;
+  if (lp.balanced) {
+    lo = slice * lp.target;
+    hi = min(n, lo + lp.target);
+  } else {
+    lo = (uint32_t)(((uint64_t)n * slice) / lp.slices);
+    hi = (uint32_t)(((uint64_t)n * (slice + 1)) / lp.slices);
+  }
   if (lo >= hi) return;                          // uniform per workgroup
-  const uint32_t* __restrict__ q = lists + lp.qbase[li] + (size_t)ch * cap;
+  const uint32_t* __restrict__ q = lists + lp.qbase[li] + (lp.dense[li] ? (size_t)lbase[qi] : (size_t)ch * cap);
   const float2* __restrict__ dgl = dg_t + (size_t)l * P;
   const float s = lv.scale[l];
   const bool hashed = lv.hashed[l] != 0;         // uniform
@@ -1481,8 +1611,10 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_pairbins_kernel(const float
   }
 }
 
-static bool list_dense() {
-  static const bool v = [] { const char* e = getenv("DNS_LIST_DENSE"); return e && e[0] == '1'; }();
+// dense levels of at least this many 8192-row chunks go through (exact-size) lists, smaller ones through the run-combining sweep
+// (DNS_LIST_DENSE_MIN overrides, for measurement; 0x7fffffff = none)
+static uint32_t list_dense_min_chunks() {
+  static const uint32_t v = [] { const char* e = getenv("DNS_LIST_DENSE_MIN"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1 ? n : 6); }();
   return v;
 }
 
@@ -1500,6 +1632,8 @@ static uint32_t list_threads(uint32_t shift) {
 
 static bool list_plan(const GridLevels& lv, uint32_t P, uint32_t queue_cap, uint32_t target_jobs, ListPlan& lp) {
   lp.n = 0;
+  lp.n_dense = 0;
+  for (uint32_t i = 0; i < DNS_MAX_LEVELS; ++i) lp.dense[i] = lp.dense_idx[i] = 0;
   lp.chunk_shift = list_chunk_shift();
   uint32_t queues = 0;
   uint64_t words = 0;
@@ -1508,11 +1642,13 @@ static bool list_plan(const GridLevels& lv, uint32_t P, uint32_t queue_cap, uint
     const uint32_t chunks = (lv.size[l] + (1u << lp.chunk_shift) - 1u) >> lp.chunk_shift;
     if (lv.size[l] <= 8192u || chunks > PART_MAX_CHUNKS) continue;   // one-chunk levels stay with the sweep
     if (lv.hashed[l] && (lv.size[l] & (lv.size[l] - 1u))) continue;
-    if (!lv.hashed[l] && !list_dense()) continue;
+    const bool dense = !lv.hashed[l];
+    if (dense && ((lv.size[l] + 8191u) >> 13) < list_dense_min_chunks()) continue;   // small dense levels: the run-combining sweep
     const uint64_t expect = ((uint64_t)P * 4u + chunks - 1) / chunks;
-    uint64_t cap = (lv.hashed[l] ? expect + expect / 8u : 4u * expect) + 4096u;
+    uint64_t cap = expect + expect / 8u + 4096u;
     if (cap > (uint64_t)P * 8u) cap = (uint64_t)P * 8u;          // a level emits at most 8 entries per point
     if (queue_cap) cap = queue_cap;                               // caller-chosen capacity (tests: the overflow fallback)
+    if (dense) cap = (uint64_t)P * 8u;                            // exact lists: the level's whole region
     cap = (cap + 3u) & ~3ull;
     if (cap > 0x7FFFFFFFull) return false;
     const uint32_t i = lp.n++;
@@ -1521,8 +1657,10 @@ static bool list_plan(const GridLevels& lv, uint32_t P, uint32_t queue_cap, uint
     lp.qoff[i] = queues;
     lp.cap[i] = (uint32_t)cap;
     lp.qbase[i] = words;
+    lp.dense[i] = dense ? 1u : 0u;
+    if (dense) lp.dense_idx[lp.n_dense++] = i;
     queues += chunks;
-    words += (uint64_t)chunks * cap;
+    words += dense ? cap : (uint64_t)chunks * cap;
   }
   lp.qoff[lp.n] = queues;
   for (uint32_t i = lp.n; i < DNS_MAX_LEVELS; ++i) {
@@ -1532,9 +1670,15 @@ static bool list_plan(const GridLevels& lv, uint32_t P, uint32_t queue_cap, uint
     lp.qbase[i] = words;
     lp.qoff[i + 1] = queues;
   }
-  if (!lp.n) return false;
+  if (!lp.n || queues >= 8192u) return false;
   lp.slices = (target_jobs + queues - 1) / queues;
   if (lp.slices < 1) lp.slices = 1;
+  lp.balanced = lp.n_dense ? 1u : 0u;
+  lp.target = 16u * list_threads(lp.chunk_shift);                 // 16 entries per thread
+  uint64_t mj = queues;                                           // every list's last, partial job
+  for (uint32_t i = 0; i < lp.n; ++i) mj += (lp.dense[i] ? (uint64_t)lp.cap[i] : (uint64_t)lp.chunks[i] * lp.cap[i]) / lp.target;
+  if (mj > 0x7FFFFFFFull) return false;
+  lp.max_jobs = (uint32_t)mj;
   static const uint32_t tiles_env = [] { const char* e = getenv("DNS_LIST_TILES"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1 && n <= 32 ? n : 0); }();
   lp.tiles = tiles_env ? tiles_env : LIST_TILES;
   return true;
@@ -1542,7 +1686,7 @@ static bool list_plan(const GridLevels& lv, uint32_t P, uint32_t queue_cap, uint
 
 static uint64_t list_words(const ListPlan& lp) {
   uint64_t w = 0;
-  for (uint32_t i = 0; i < lp.n; ++i) w += (uint64_t)lp.chunks[i] * lp.cap[i];
+  for (uint32_t i = 0; i < lp.n; ++i) w += lp.dense[i] ? (uint64_t)lp.cap[i] : (uint64_t)lp.chunks[i] * lp.cap[i];
   return w;
 }
 
@@ -1643,8 +1787,8 @@ static ScatterWs scatter_ws(uint32_t P, const GridLevels& lv, uint32_t flags, ui
   uint64_t n = (uint64_t)P * lv.n_levels * 2;
   w.gmax = n;
   n += 4;
-  w.lcount = n;                                  // directly behind the max words: one fill clears both
-  if (w.lists) n += w.lp.qoff[w.lp.n];
+  w.lcount = n;                                  // directly behind the max words: one fill clears max words, counts and cursors
+  if (w.lists) n += (uint64_t)4u * w.lp.qoff[w.lp.n] + 4u;      // [counts | cursors | list starts | job prefix (+1)]
   w.qcount = n;
   if (w.part) n += (uint64_t)DNS_MAX_LEVELS * PART_MAX_CHUNKS;
   w.queues = n;
@@ -1842,7 +1986,7 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     uint4* rows16 = n_replay ? reinterpret_cast<uint4*>(ws + W.replay) : nullptr;
     uint32_t* gmax = (uint32_t*)(ws + W.gmax);
     {                                                                          // max word, non-finite flag, pad
-      const int rc = fill_words(gmax, 0u, 4 + (W.lists ? W.lp.qoff[W.lp.n] : 0u), st, "dns_encode_bwd");
+      const int rc = fill_words(gmax, 0u, 4 + (W.lists ? 2u * W.lp.qoff[W.lp.n] : 0u), st, "dns_encode_bwd");
       if (rc != DNS_OK) return rc;
     }
     static const uint32_t dg_tiles = [] { const char* e = getenv("DNS_DG_TILES"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 1 && n <= 64 ? n : DG_TILES); }();
@@ -1855,11 +1999,24 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
       const ListPlan& lp = W.lp;
       uint32_t* lcount = reinterpret_cast<uint32_t*>(ws + W.lcount);
       uint32_t* lists = reinterpret_cast<uint32_t*>(ws + W.lwords);
-      DNS_LAUNCH(hashgrid_bwd_pairlist_kernel, dim3((P + LIST_THREADS * lp.tiles - 1) / (LIST_THREADS * lp.tiles), lp.n), dim3(LIST_THREADS), 0,
-                 st, x, P, lv, lp, (const float2*)ws, gmax, lcount, lists, d_table);
-      DNS_LAUNCH(hashgrid_bwd_pairbins_kernel, dim3(lp.qoff[lp.n] * lp.slices), dim3(list_threads(lp.chunk_shift)),
-                 lds_bytes >> (13u - lp.chunk_shift), st, x, P, lv, lp,
-                 (const float2*)ws, lcount, lists, gmax, d_table);
+      const uint32_t n_lists = lp.qoff[lp.n];
+      uint32_t* lcursor = lcount + n_lists;
+      uint32_t* lbase = lcursor + n_lists;
+      uint32_t* jobstart = lbase + n_lists;
+      const uint32_t gx = (P + LIST_THREADS * lp.tiles - 1) / (LIST_THREADS * lp.tiles);
+      DNS_LAUNCH(hashgrid_bwd_pairlist_kernel, dim3(gx, lp.n), dim3(LIST_THREADS), 0, st, x, P, lv, lp, (const float2*)ws, gmax, lcount,
+                 lists, d_table, 0u, (const uint32_t*)nullptr);
+      size_t bins_lds = lds_bytes >> (13u - lp.chunk_shift);
+      uint32_t jobs2 = n_lists * lp.slices;
+      if (lp.balanced) {
+        DNS_LAUNCH(hashgrid_bwd_pairscan_kernel, dim3(1), dim3(1024), 0, st, lp, (const uint32_t*)lcount, lbase, jobstart);
+        DNS_LAUNCH(hashgrid_bwd_pairlist_kernel, dim3(gx, lp.n_dense), dim3(LIST_THREADS), 0, st, x, P, lv, lp, (const float2*)ws, gmax,
+                   lcursor, lists, d_table, 1u, (const uint32_t*)lbase);
+        bins_lds += (size_t)4u * (n_lists + 1u);
+        jobs2 = lp.max_jobs;
+      }
+      DNS_LAUNCH(hashgrid_bwd_pairbins_kernel, dim3(jobs2), dim3(list_threads(lp.chunk_shift)), bins_lds, st, x, P, lv, lp,
+                 (const float2*)ws, lcount, lists, gmax, d_table, (const uint32_t*)lbase, (const uint32_t*)jobstart);
     }
     if (part) {
       uint32_t* qcount = reinterpret_cast<uint32_t*>(ws + W.qcount);

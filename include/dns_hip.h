@@ -174,13 +174,13 @@ int dns_encode_fwd_split(const float* in, const double* bound, uint32_t P, uint3
  * same points and table (then the grid part of d_x needs no table access).  ws: 8-byte aligned scratch of
  * dns_encode_bwd_ws_floats(P, meta, flags, queue_cap) floats for the LDS-binned table scatter (NULL = per-corner atomics).
  * flags selects the form of the table scatter (tcnn kernel_grid_backward).  DNS_SCATTER_AUTO: HASHED levels of more than 8192 rows
- * through pair lists (ABI v10, below: 64-bit fixed-point LDS bins, exact order-independent sums per workgroup), levels of one
- * chunk and dense levels of < 16 chunks through the LDS-bin sweep (FLOAT64 bins, ds_add_f64: sums good to ~1e-16 of the terms but
- * dependent on their order; dense levels keep a cell's 8 x 2 sums in registers while consecutive points stay in the cell), dense
- * levels of >= 16 chunks through per-chunk queues of {row, w g0, w g1} (fixed-point bins).  Whatever the form, a chunk's sums
- * reach d_table by float atomics, so d_table is not bit-reproducible from run to run.
- * _ATOMIC = one float atomic per corner (tcnn's form; order-dependent fp32 sums); _BINNED / _QUEUES = force the sweep / the
- * queues for every level (no lists).  queue_cap: 0, or the entry capacity of each queue and list (what does
+ * and DENSE levels of at least six 8192-row chunks through pair lists (ABI v10, below: 64-bit fixed-point LDS bins, exact
+ * order-independent sums per workgroup), the other levels through the LDS-bin sweep (FLOAT64 bins, ds_add_f64: sums good to ~1e-16
+ * of the terms but dependent on their order; dense levels keep a cell's 8 x 2 sums in registers while consecutive points stay in
+ * the cell).  Whatever the form, a chunk's sums reach d_table by float atomics, so d_table is not bit-reproducible from run to run.
+ * _ATOMIC = one float atomic per corner (tcnn's form; order-dependent fp32 sums); _BINNED = the sweep for every level; _QUEUES =
+ * per-chunk queues of {row, w g0, w g1} for every multi-chunk level (rounds 1-3's form for large tables; fixed-point bins); neither
+ * uses lists unless DNS_SCATTER_LISTS is added.  queue_cap: 0, or the entry capacity of each queue and hashed list (what does
  * not fit falls back to float atomics) -- same value in both calls.  A NaN / Inf in d_grid gives a non-finite d_table in
  * every form. */
 #define DNS_SCATTER_AUTO 0u
@@ -193,11 +193,14 @@ int dns_encode_fwd_split(const float* in, const double* bound, uint32_t P, uint3
  * level, counted by dns_encode_bwd_ws_floats with the same flags) and the 8 chunk visits of a level replay them instead of
  * hashing the 8 corners again.  Same sums. */
 #define DNS_SCATTER_REPLAY 0x10u
-/* | DNS_SCATTER_LISTS (ABI v10; implied by _AUTO, may be added to _BINNED / _QUEUES): hashed levels of 2^14 .. 2^20 rows go through
- * PAIR LISTS: pass 1 hashes each point-level once and appends one 32-bit word {point, x-pair of corners} to the list of the pair's
- * 4096-row chunk (16 bytes per point-level instead of the 8 chunk visits of the sweep or the 192 bytes of the queues; workspace
- * counted by dns_encode_bwd_ws_floats with the same flags), pass 2 gives every lane one entry, re-forms its two rows and weights
- * from the point and adds into the chunk's 64-bit fixed-point LDS bins.  P < 2^30. */
+/* | DNS_SCATTER_LISTS (ABI v10; implied by _AUTO, may be added to _BINNED / _QUEUES): PAIR LISTS.  Pass 1 hashes each point-level
+ * once and appends one 32-bit word {point, x-pair of corners} to the list of the pair's 4096-row chunk (16 bytes per point-level
+ * instead of the 8 chunk visits of the sweep or the 192 bytes of the queues; workspace counted by dns_encode_bwd_ws_floats with
+ * the same flags), pass 2 gives every lane one entry, re-forms its two rows and weights from the point and adds into the chunk's
+ * 64-bit fixed-point LDS bins.  Hashed levels (2^14 .. 2^20 rows): fixed-capacity lists (uniform hash), a fixed number of jobs per
+ * list.  Dense levels: the lists fill by where the rays are -- they are sized EXACTLY (a counting sweep, a one-workgroup scan that
+ * places every chunk's list inside the level's 8 P-word region, a writing sweep) and cut into jobs of 8192 entries from the actual
+ * counts.  P < 2^30. */
 #define DNS_SCATTER_LISTS 0x20u
 int dns_encode_bwd(const float* x, const double* bound, uint32_t P, uint32_t n_bins,
                    const float* table, const DnsGridMeta* meta,
