@@ -56,3 +56,29 @@ def test_ops_refuse_cpu_tensors():
         ops.composite(torch.zeros(2, 4, 4), torch.zeros(2, 4), None)
     with pytest.raises(ValueError):
         ops.mlp(torch.zeros(4, 80), torch.zeros(ops.mlp_param_count(80, 33, 32, 1)), 80, 33)
+
+
+def test_scatter_workspace_sizes_per_form():
+    """dns_encode_bwd_ws_floats is host arithmetic (no GPU): the workspace of the table scatter per form.  Every form holds the
+    level-major gradient copy (P x L x 2 floats) + the max words; the pair lists (DNS_SCATTER_LISTS, implied by _AUTO) add
+    16 bytes per point and hashed level (+ slack) and, for large dense levels, an exact 8 P-word region each; the queue form adds
+    its 24-byte-per-corner queues; a caller-chosen capacity shrinks lists and queues alike; the replayed rows add 4 floats per
+    point and level."""
+    from dns_slam_amd import _lib, ops
+    ws = lambda meta, P, flags, cap=0: int(_lib.lib.dns_encode_bwd_ws_floats(P, ctypes.byref(meta.c), flags, cap))
+    P = 262144
+    small, big = ops.GridMeta(16, 592), ops.GridMeta(20, 231)         # T = 2^16: 4 dense + 12 hashed levels; T = 2^20: 11 dense + 5 hashed
+    base = P * 16 * 2 + 4
+    assert ws(small, P, ops.SCATTER_BINNED) == base                   # sweep only: no lists, no queues (levels of < 16 chunks)
+    auto, lists = ws(small, P, ops.SCATTER_AUTO), ws(small, P, ops.SCATTER_BINNED | ops.SCATTER_LISTS)
+    assert auto == lists > base
+    n_hashed = sum(1 for l in range(16) if small.c.hashed[l])
+    per_level = (auto - base) / n_hashed / P                          # words per point and hashed level: 4 entries + 1/8 slack
+    assert 4.0 <= per_level <= 5.0, per_level
+    assert ws(small, P, ops.SCATTER_AUTO, 64) < auto                  # 64-entry lists
+    assert ws(small, P, ops.SCATTER_AUTO | ops.SCATTER_REPLAY) == ((auto + 3) // 4) * 4 + P * 16 * 4
+    q, a = ws(big, P, ops.SCATTER_QUEUES), ws(big, P, ops.SCATTER_AUTO)
+    assert q > base and a > base
+    n_dense_big = sum(1 for l in range(16) if not big.c.hashed[l] and big.c.size[l] >= 6 * 8192 - 8191)
+    assert a - base >= n_dense_big * 8 * P                            # every large dense level owns an 8 P-word region
+    assert ws(small, 0, ops.SCATTER_AUTO) <= 4 + 4 * 8192 + 8         # no points: counters only
