@@ -53,12 +53,14 @@ class _TimedLib:
     _live = staticmethod(lambda n_in, flags: ((int(flags) >> 16) & 0xff) or n_in)
     @staticmethod
     def _grid_info(meta_ref):
-        """levels of a grid and how many of them the scatter sends through pair lists (hashed, more than one 8192-row chunk)"""
+        """levels of a grid and how many of them the scatter sends through pair lists (hashed levels of more than one 8192-row
+        chunk, dense levels of at least six: csrc/encode.hip list_plan)"""
         m = getattr(meta_ref, "_obj", None)
         if m is None:
             return None
         L = int(m.n_levels)
-        return {"n_levels": L, "list_levels": sum(1 for l in range(L) if m.hashed[l] and 8192 < m.size[l] <= (1 << 20))}
+        in_lists = lambda l: 8192 < m.size[l] <= (1 << 20) and (m.hashed[l] or (m.size[l] + 8191) // 8192 >= 6)
+        return {"n_levels": L, "list_levels": sum(1 for l in range(L) if in_lists(l))}
 
     _INFO = {"dns_encode_bwd": lambda a: _TimedLib._grid_info(a[5]),
              "dns_mlp_fwd": lambda a: {"n_in": _TimedLib._live(a[6], a[17]), "n_out": a[7], "nn": a[8], "nl": a[9]},
