@@ -53,6 +53,8 @@ def test_hashgrid_rows_bit_exact(hash_size, res):
     (16, 592, 3000, "l", 64),         # ... with 64-entry lists: most pairs take the overflow fallback (float atomics)
     (20, 231, 4000, "l", None),       # ... T = 2^20: up to 128 chunks per level, large dense levels (pairs that straddle chunks)
     (14, 200, 2000, "l", None),
+    (16, 592, 1, "l", None),          # ... a single point, and fewer points than one pass-1 tile
+    (20, 231, 63, "l", None),
 ])
 def test_encode_forward_backward(hash_size, res, P, scatter, cap, monkeypatch):
     ops = _ops()
