@@ -13,6 +13,7 @@ void set_error(const char* fmt, ...);
 // Sticky per-device error word in pinned host memory (host.cpp): kernels that consume device counters set a bit instead of
 // storing out of bounds; poll_device_error() is a plain host read, no synchronisation.
 constexpr uint32_t DNS_DEVERR_GROUP_CURSOR = 1u;
+constexpr uint32_t DNS_DEVERR_MLP_RANGE = 2u;   // a row of an MLP backward operand lies beyond the 2 GiB a buffer descriptor addresses
 uint32_t* device_error_word();               // device-visible pointer for kernel arguments (NULL before dns_init)
 int poll_device_error(const char* what);     // DNS_OK, or DNS_E_LAUNCH + message while the word is non-zero
 

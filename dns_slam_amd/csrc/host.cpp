@@ -43,7 +43,8 @@ int poll_device_error(const char* what) {
   if (!w) return DNS_OK;
   set_error("%s: a kernel of this library hit a device-side capacity check (error word 0x%x%s); results since then are "
             "incomplete -- dns_device_error(1) clears the word", what, w,
-            (w & DNS_DEVERR_GROUP_CURSOR) ? ": group cursor past n_slots in dns_group_slots / dns_group_scatter" : "");
+            (w & DNS_DEVERR_GROUP_CURSOR) ? ": group cursor past n_slots in dns_group_slots / dns_group_scatter"
+            : (w & DNS_DEVERR_MLP_RANGE) ? ": dns_mlp_bwd was handed a row index beyond 2 GiB of its dy / d_x matrix" : "");
   return DNS_E_LAUNCH;
 }
 

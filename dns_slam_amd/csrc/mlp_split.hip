@@ -367,6 +367,19 @@ int launch_mlp_bwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
   a.dseg = {(d_x && x2) ? d_x2 : nullptr, lddx2, (uint32_t)acc1 & 1u, (uint32_t)acc2, (uint32_t)acc1 >> 8};   // (col_lo rides in acc1's upper bits)
   a.d_params = d_params; a.dh1 = d_params ? ws : nullptr;
   a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
+  // The kernel addresses dy, d_x, d_x2, dH_1 and the row table through buffer descriptors (mlp_split.hpp): 2 GiB per matrix.
+  // Slot-ordered rows are checked here; rows behind a row table are checked on the device (DNS_DEVERR_MLP_RANGE).
+  a.err = device_error_word();
+  {
+    uint64_t ld_max = lddy;
+    if (d_x) ld_max = lddx > ld_max ? lddx : ld_max;
+    if (d_x && x2 && d_x2) ld_max = lddx2 > ld_max ? lddx2 : ld_max;
+    const uint64_t rows = row_index ? 0ull : (uint64_t)n_slots;
+    DNS_REQUIRE(rows * ld_max * 4ull < (uint64_t)BUF_LIMIT && (uint64_t)n_slots * n_neurons * 4ull < (uint64_t)BUF_LIMIT &&
+                    (uint64_t)n_slots * 4ull < (uint64_t)BUF_LIMIT,
+                "dns_mlp_bwd: %u slots x %llu floats per row exceed the 2 GiB per matrix this kernel addresses", n_slots,
+                (unsigned long long)ld_max);
+  }
   // Without weight gradients (the tracker's frozen scene; a network without a weight-set table) the kernel has no persistent
   // accumulators and runs with EIGHT waves per workgroup -- two per SIMD on one set of LDS weight images: 1.28-1.37x
   const bool wide = !d_params && !tile_group && !h_saved;

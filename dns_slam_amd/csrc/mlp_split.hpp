@@ -287,6 +287,44 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// ---- buffer-addressed global I/O (round 5) -------------------------------------------------------------------------
+// A wave that is alone on its SIMD pays every memory round trip it waits for, and gfx9's vmcnt counts loads AND stores in
+// issue order: a guarded access (`if (row >= 0) store`) is a divergent branch around a vector-memory instruction, behind which
+// hipcc can no longer count what is in flight and waits for vmcnt(0) -- round 4's backward kernel drained EVERY outstanding
+// store before each of its twelve dX stores per tile (ISA: s_waitcnt vmcnt(0) in front of every v_pk_add / store pair).
+// Raw buffer instructions make the guard part of the ADDRESS instead: an offset at or beyond num_records reads zeros and
+// drops the store, so the tile's accesses are straight-line code (exact vmcnt(N) waits), carry a 32-bit offset (no 64-bit
+// address arithmetic per access) and need no clamp / select around them.  Every matrix handled this way must lie below
+// BUF_OOB bytes from its base (2 GiB: checked on the host for slot-ordered rows, per row on the device behind a row table).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t BUF_OOB = 0x80000000u;    // = num_records of every descriptor: this offset and everything above is out of range
+constexpr uint32_t BUF_LIMIT = BUF_OOB - 65536u;   // first byte offset of a row that is refused (room for the row itself)
+
+__device__ __forceinline__ rsrc_t buf_make(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)BUF_OOB, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, uint32_t off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t off, const float4& v) {
+  u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)off, 0, 0);
+}
+// byte offset of row `row` (< 0: a padding slot) in a matrix of row stride ld floats; a row that does not fit below BUF_LIMIT
+// is dropped like a padding slot and reported through the library's sticky device error word
+__device__ __forceinline__ uint32_t buf_row_off(int row, uint32_t ld, uint32_t* __restrict__ err) {
+  const uint64_t o = (uint64_t)(uint32_t)row * ((uint64_t)ld * 4u);
+  const bool fits = o < (uint64_t)BUF_LIMIT;
+  if (row >= 0 && !fits && err) atomicOr(err, DNS_DEVERR_MLP_RANGE);
+  return (row >= 0 && fits) ? (uint32_t)o : BUF_OOB;
+}
+
 __device__ __forceinline__ void tile_rows_publish(int* __restrict__ rows_lds, const int32_t* __restrict__ row_index,
                                                   uint32_t slot0, uint32_t n_slots, uint32_t lane) {
   if (lane < 32u) {
@@ -719,6 +757,165 @@ __device__ __forceinline__ void transpose_frags(const f32x16& a, int k_lane, Fra
   wave_lds_fence();
 }
 
+// ---- the backward kernel's buffer-addressed tile I/O -----------------------------------------------------------------
+// Per wave and tile three tables of 32 byte offsets (one per slot of the tile; BUF_OOB for a padding slot) in LDS: the rows
+// of dy, of d_x and of d_x2.  An access adds its lane's column bytes -- or takes BUF_OOB where the lane has nothing to do.
+constexpr uint32_t BWD_OFFS = 96;            // ints: dy | d_x | d_x2
+constexpr uint32_t BWD_WAVE_FLOATS = STG_WAVE_FLOATS + BWD_OFFS;
+
+__device__ __forceinline__ void tile_offs_publish(uint32_t* __restrict__ offs, const int* __restrict__ rows_lds, uint32_t lddy,
+                                                  uint32_t lddx, uint32_t lddx2, uint32_t* __restrict__ err, uint32_t lane) {
+  if (lane < 32u) {
+    const int row = rows_lds[lane];
+    offs[lane] = buf_row_off(row, lddy, err);
+    offs[32u + lane] = buf_row_off(row, lddx, err);
+    offs[64u + lane] = buf_row_off(row, lddx2, err);
+  }
+  wave_lds_fence();
+}
+
+// dy columns 32c .. 32c+31 of the tile's rows, lane = column: 2 rows x 128 B per instruction.  A padding slot reads zeros
+// (BUF_OOB); a column past n_out reads the last valid one -- a finite stand-in that cannot reach a result: the rows of the
+// W_out^T image past n_out are zero, the weight-gradient rows past n_out are not flushed, and a duplicate of a valid column
+// cannot raise the maximum the point's scale comes from.
+__device__ __forceinline__ void dy_chunk_issue_buf(DyChunk& d, rsrc_t rdy, const uint32_t* __restrict__ dyoff, uint32_t n_out,
+                                                   uint32_t c, uint32_t lane) {
+  const uint32_t colb = 4u * min(32u * c + (lane & 31u), n_out - 1u);
+  uint32_t off[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) off[i] = dyoff[(lane >> 5) + 2 * i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d.v[i] = buf_load1(rdy, off[i] + colb);
+}
+
+// the input gradient's two segments as buffer descriptors + what is constant over the kernel
+struct DxIo {
+  rsrc_t r1, r2;
+  uint32_t two, acc1, acc2, n_in1, col_lo;    // two: a second segment exists (columns >= n_in1 go to r2)
+};
+
+// The lane's four byte offsets (rows (lane >> 3) + 8 i, columns col0 + 4 (lane & 7) ..+3) of column tile [col0, col0 + ncols)
+// in segment `which`; BUF_OOB where the lane's columns are not part of it (past ncols, below col_lo, the other segment)
+__device__ __forceinline__ void dx_tile_offs(uint32_t (&f)[4], const DxIo& io, const uint32_t* __restrict__ offs, uint32_t which,
+                                             uint32_t col0, uint32_t ncols, uint32_t lane) {
+  const uint32_t c4 = 4u * (lane & 7u), col = col0 + c4, rr = lane >> 3;
+  const bool second = io.two != 0u && col >= io.n_in1;
+  const bool mine = c4 < ncols && col >= io.col_lo && (second == (which != 0u));
+  const uint32_t cb = 4u * (which ? col - io.n_in1 : col);
+  const uint32_t* t = offs + 32u + 32u * which;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t o = t[rr + 8 * i] + cb;    // (BUF_OOB + a few hundred bytes stays out of range)
+    f[i] = mine ? o : BUF_OOB;
+  }
+}
+
+// which segments column tile [col0, col0 + 32) touches (uniform)
+__device__ __forceinline__ void dx_tile_segs(const DxIo& io, uint32_t col0, uint32_t ncols, bool& use1, bool& use2) {
+  use1 = io.two == 0u || col0 < io.n_in1;
+  use2 = io.two != 0u && col0 + ncols > io.n_in1;
+}
+
+// what a read-add-write store of the tile will add to (zeros where nothing is added): requested a column tile AHEAD of its
+// store and BEFORE the stores of the tile in front of it, so that the wait for these loads never includes a store
+__device__ __forceinline__ void dx_old_issue_buf(DxOld& o, const DxIo& io, const uint32_t* __restrict__ offs, uint32_t col0,
+                                                 uint32_t ncols, uint32_t lane) {
+  bool use1, use2;
+  dx_tile_segs(io, col0, ncols, use1, use2);
+  const bool l1 = use1 && io.acc1 != 0u, l2 = use2 && io.acc2 != 0u;
+  uint32_t f1[4], f2[4];
+  dx_tile_offs(f1, io, offs, 0u, col0, ncols, lane);
+  dx_tile_offs(f2, io, offs, 1u, col0, ncols, lane);
+  if (l1 && l2) {
+    // a tile that straddles the segment boundary: a lane belongs to ONE segment -- the two batches write disjoint lanes of the
+    // same registers (exec-masked), nothing to merge afterwards
+    const bool second = col0 + 4u * (lane & 7u) >= io.n_in1;
+    if (!second) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.v[i] = buf_load4(io.r1, f1[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.v[i] = buf_load4(io.r2, f2[i]);
+    }
+  } else if (l1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = buf_load4(io.r1, f1[i]);
+  } else if (l2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = buf_load4(io.r2, f2[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// a: 32 features x 32 points (true scale) -> the tile's rows of d_x / d_x2; straight-line: no guarded access.  `old` (what a
+// read-add-write store adds to; only read when `add`) is consumed BEFORE the next column tile's values are requested into the
+// same registers (has_next), and those requests leave before this tile's stores.
+__device__ __forceinline__ void store_tile_rows_buf(const DxIo& io, const uint32_t* __restrict__ offs, uint32_t col0, uint32_t ncols,
+                                                    const f32x16& a, DxOld& old, bool add, bool has_next, uint32_t next_ncols,
+                                                    float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  bool use1, use2;
+  dx_tile_segs(io, col0, ncols, use1, use2);
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(stg + (rr + 8 * i) * STG_LD + c4);
+  if (add) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 u = old.v[i];
+      v[i].x += u.x; v[i].y += u.y; v[i].z += u.z; v[i].w += u.w;
+    }
+    // The adds first, THEN the requests into the same registers: left to itself hipcc sinks the adds below the requests (they
+    // are only needed by the stores), gives the requests registers of their own and copies them behind an s_waitcnt vmcnt(0)
+    // at the end of the iteration.  The empty asm pins the sums in front of the requests.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+    if (has_next) dx_old_issue_buf(old, io, offs, col0 + 32u, next_ncols, lane);
+  }
+  {
+    // the first segment's four stores are UNCONDITIONAL (a tile that lies in the second segment sends four out-of-range
+    // offsets): a store count the compiler can rely on keeps the wait for `old` at vmcnt(N >= 4) instead of vmcnt(<= 3)
+    uint32_t f[4];
+    dx_tile_offs(f, io, offs, 0u, col0, ncols, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) buf_store4(io.r1, f[i], v[i]);
+  }
+  if (use2) {
+    uint32_t f[4];
+    dx_tile_offs(f, io, offs, 1u, col0, ncols, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) buf_store4(io.r2, f[i], v[i]);
+  }
+  wave_lds_fence();
+}
+
+// a: 32 features x 32 points -> rows (row0 + r) of a slot-major [n][ld] matrix behind descriptor r (r < nrows), columns
+// col0 .. col0 + 31; 16-byte aligned rows
+__device__ __forceinline__ void store_tile_staged_buf(rsrc_t rd, uint32_t row0_bytes, uint32_t ld, uint32_t col0, uint32_t nrows,
+                                                      const f32x16& a, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t rr = lane >> 3, c4 = 4u * (lane & 7u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = rr + 8 * i;
+    const float4 v = *reinterpret_cast<const float4*>(stg + row * STG_LD + c4);
+    const uint32_t off = row < nrows ? row0_bytes + (row * ld + col0 + c4) * 4u : BUF_OOB;
+    buf_store4(rd, off, v);
+  }
+  wave_lds_fence();
+}
+
 // ---- LDS layout of the forward kernel (bytes) ----
 template <int NN, int NL>
 struct FwdLds {
@@ -786,6 +983,7 @@ struct BwdArgs {
   XsIn xs;                                   // split-row input (xs.s1.rows != NULL: x / seg are unused)
   uint32_t n_waves;                          // waves per workgroup the launcher planned the grid for (4, or 8: frozen-scene form)
   uint32_t n_in_w;                           // storage width of W_in's rows (= n_in, or larger with DNS_MLP_LIVE_IN)
+  uint32_t* err;                             // the library's sticky device error word (DNS_DEVERR_MLP_RANGE)
 #ifdef DNS_BWD_TRACE
   unsigned long long* trace;                 // tools build only (make trace): s_memtime stamps at the phase boundaries
 #endif
@@ -825,9 +1023,10 @@ DNS_DECL_PREP(64, 2)
 
 // adds the workgroup's four copies of one 32 x 32 accumulator tile (rows = dW rows, lanes = dW columns) and issues the
 // float atomics: one 128-byte row segment per lane half per instruction
+template <uint32_t WAVE_FLOATS = STG_WAVE_FLOATS>
 __device__ __forceinline__ void flush_tile(const f32x16& a, float* __restrict__ dst, uint32_t ld, uint32_t rows_valid,
                                            uint32_t cols_valid, float* __restrict__ stg_base, uint32_t wave, uint32_t lane) {
-  float* stg = stg_base + wave * STG_WAVE_FLOATS;
+  float* stg = stg_base + wave * WAVE_FLOATS;
   const uint32_t j = lane & 31u, h = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * STG_LD + j] = a[r];
@@ -837,7 +1036,7 @@ __device__ __forceinline__ void flush_tile(const f32x16& a, float* __restrict__ 
     const uint32_t row = wave * 8u + 2u * i + h;
     float v = 0.f;
 #pragma unroll
-    for (uint32_t w = 0; w < 4u; ++w) v += stg_base[w * STG_WAVE_FLOATS + row * STG_LD + j];
+    for (uint32_t w = 0; w < 4u; ++w) v += stg_base[w * WAVE_FLOATS + row * STG_LD + j];
     if (row < rows_valid && j < cols_valid && v != 0.f) atomicAdd(dst + (size_t)row * ld + j, v);
   }
   __syncthreads();
