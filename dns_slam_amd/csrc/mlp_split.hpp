@@ -316,14 +316,10 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t off, const float4&
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)off, 0, 0);
 }
-// byte offset of row `row` (< 0: a padding slot) in a matrix of row stride ld floats; a row that does not fit below BUF_LIMIT
-// is dropped like a padding slot and reported through the library's sticky device error word
-__device__ __forceinline__ uint32_t buf_row_off(int row, uint32_t ld, uint32_t* __restrict__ err) {
-  const uint64_t o = (uint64_t)(uint32_t)row * ((uint64_t)ld * 4u);
-  const bool fits = o < (uint64_t)BUF_LIMIT;
-  if (row >= 0 && !fits && err) atomicOr(err, DNS_DEVERR_MLP_RANGE);
-  return (row >= 0 && fits) ? (uint32_t)o : BUF_OOB;
-}
+// byte offset of row `row` (< 0: a padding slot) in a matrix of row stride ld floats; rows at or beyond row_limit (the first row
+// whose offset in the widest matrix would pass BUF_LIMIT: computed once on the host side of the kernel) are dropped like a
+// padding slot and counted in `bad`, which the kernel reports once, at its end, through the sticky device error word
+__device__ __forceinline__ uint32_t buf_row_off(int row, uint32_t ld, bool ok) { return ok ? (uint32_t)row * (ld * 4u) : BUF_OOB; }
 
 __device__ __forceinline__ void tile_rows_publish(int* __restrict__ rows_lds, const int32_t* __restrict__ row_index,
                                                   uint32_t slot0, uint32_t n_slots, uint32_t lane) {
@@ -764,12 +760,14 @@ constexpr uint32_t BWD_OFFS = 96;            // ints: dy | d_x | d_x2
 constexpr uint32_t BWD_WAVE_FLOATS = STG_WAVE_FLOATS + BWD_OFFS;
 
 __device__ __forceinline__ void tile_offs_publish(uint32_t* __restrict__ offs, const int* __restrict__ rows_lds, uint32_t lddy,
-                                                  uint32_t lddx, uint32_t lddx2, uint32_t* __restrict__ err, uint32_t lane) {
+                                                  uint32_t lddx, uint32_t lddx2, uint32_t row_limit, uint32_t& bad, uint32_t lane) {
   if (lane < 32u) {
     const int row = rows_lds[lane];
-    offs[lane] = buf_row_off(row, lddy, err);
-    offs[32u + lane] = buf_row_off(row, lddx, err);
-    offs[64u + lane] = buf_row_off(row, lddx2, err);
+    const bool ok = (uint32_t)row < row_limit;          // a padding slot (-1) fails the unsigned compare as well
+    bad |= (row >= 0 && !ok) ? 1u : 0u;
+    offs[lane] = buf_row_off(row, lddy, ok);
+    offs[32u + lane] = buf_row_off(row, lddx, ok);
+    offs[64u + lane] = buf_row_off(row, lddx2, ok);
   }
   wave_lds_fence();
 }
