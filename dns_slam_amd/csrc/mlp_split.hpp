@@ -50,6 +50,26 @@ __device__ __forceinline__ f32x16 zero16() {
 
 __device__ __forceinline__ float pow2f(int k) { return ldexpf(1.0f, k); }
 
+// Cross-lane maxima without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (address arithmetic, an LDS-queue
+// instruction, s_waitcnt lgkmcnt(0)): a wave that is alone on its SIMD pays ~100 cycles for each, and the per-tile row maximum
+// ran twelve of them back to back (round 5 stamps: 2.6 k cycles of a 26 k-cycle tile).  DPP modifiers and gfx950's
+// v_permlane32_swap move the values inside the vector ALU instead.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// max over the 8 lanes that share lane >> 3 (what xor-shuffles by 1, 2, 4 give), in every one of them
+__device__ __forceinline__ float max_lanes8(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));            // quad_perm [1,0,3,2]: lane ^ 1
+  v = fmaxf(v, dpp_mov<0x4E>(v));            // quad_perm [2,3,0,1]: lane ^ 2
+  return fmaxf(v, dpp_mov<0x141>(v));        // row_half_mirror: the other quad of the 8 lanes (every quad already holds its maximum)
+}
+// max(v[lane], v[lane ^ 32]) in every lane (what an xor-shuffle by 32 gives)
+__device__ __forceinline__ float max_halves(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // 8 fp32 values (already in the lane's k order) -> hi / lo halfs of v * s
 __device__ __forceinline__ Frag split8(const float (&v)[8], float s) {
   Frag f;
@@ -491,8 +511,7 @@ __device__ __forceinline__ void x_row_max(const XChunk (&xc)[NCH], uint32_t n_ch
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int o = 1; o <= 4; o <<= 1) rm[i] = fmaxf(rm[i], __shfl_xor(rm[i], o));
+    rm[i] = max_lanes8(rm[i]);
     if ((lane & 7u) == 0) rmax[(lane >> 3) + 8 * i] = rm[i];
   }
   wave_lds_fence();
@@ -569,7 +588,7 @@ __device__ __forceinline__ float tile_max(const f32x16 (&a)[NT]) {      // after
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(a[t][r]));
-  return fmaxf(m, __shfl_xor(m, 32));        // the point's other lane half
+  return max_halves(m);                      // the point's other lane half
 }
 
 // out[t] = W[t-th 32 rows] * act, act = accumulator tiles scaled by 2^kf on conversion; image in the CHAIN map.

@@ -20,11 +20,11 @@ for n_in, n_out, nn, nl, two, live in ((80, 33, 64, 2, False, 0), (112, 3, 64, 2
     enc = torch.randn(P, 80, generator=g).to(dev)
     feat = torch.randn(P, 64, generator=g).to(dev)
     dy = torch.randn(P, n_out, generator=g).to(dev)
-    dx, dx2, dp = torch.empty(P, 80, device=dev), torch.empty(P, 64, device=dev), torch.zeros_like(w)
+    dx, dx2, dp = torch.zeros(P, 80, device=dev), torch.zeros(P, 64, device=dev), torch.zeros_like(w)
     ws = torch.empty(P * nn, device=dev)
     x2, n1 = (feat, 48) if two else (None, 0)
     st = stream_ptr()
-    flag = ops.MLP_NO_DWIN_FLAG | (ops.MLP_LIVE_IN(live) if live else 0)
+    flag = ops.MLP_NO_DWIN_FLAG | (ops.MLP_LIVE_IN(live) if live else 0) | (3 if os.environ.get("DNS_ACC") else 0)   # DNS_ACC=1: read-add-write of d_x / d_x2
     fn = lambda: check(lib.dns_mlp_bwd(ptr(enc), 80, ptr(x2), 64, n1, ptr(dy), n_out, ptr(w), n_in, n_out, nn, nl, ptr(dx), 80,
                                        ptr(dx2) if two else None, 64, ptr(dp), ptr(ws), P, None, None, 0, None, flag, st), "b")
     for _ in range(3):
