@@ -57,6 +57,7 @@ WORKLOADS = {
 
 
 F16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 1024 flop/clk/SIMD (32x32x16 in 32 clk) x 1024 SIMDs x 2.4 GHz
+LDS_ADD_U64_PEAK_GADDS = 64 / 11.9 * 256 * 2.4   # = 3304 G adds/s (see kernel_cost: hashgrid_bwd_pairbins_kernel)
 SPLIT_PRODUCTS = 3             # f16 MFMAs per fp32 product on the forward-type products (hi*hi + hi*lo + lo*hi); weight gradients: 6 bf16
 
 
@@ -83,7 +84,11 @@ def kernel_cost(entry, kernel, units, info, wl):
     if k in ("hashgrid_bwd_binned_kernel", "hashgrid_bwd_queue_kernel"):
         return ("hbm", units * ((L - n_list) * (2 * 8 * 8 + 8) + 12))
     if k == "hashgrid_bwd_pairbins_kernel":
-        return ("hbm", units * (n_list * (2 * 8 * 8 + 8 + 4 * 4) + 12))     # the RMW (SURVEY 8d prices it as memory traffic) + gradient + entries
+        # The read-modify-write of the table rows happens in LDS bins (64-bit fixed-point ds_add_u64), not in memory: pricing it
+        # as HBM traffic (round 4) gave "6.4 TB/s" against 89 MB of PMC bytes.  Yardstick = the LDS atomic rate measured with
+        # tools/lds_atomic_rate.hip: one ds_add_u64 wave-instruction per 11.9 cycles per CU; an entry (one x-pair of a point-level:
+        # 4 entries per point-level) adds 2 rows x 2 features = 4 values.
+        return ("lds_atomic", units * n_list * 4 * 4)
     if k == "hashgrid_bwd_pairlist_kernel":
         return ("hbm", units * n_list * (2 * (12 + 8) + 16))
     if k in ("composite_fwd_kernel", "composite_bwd_kernel"):
@@ -103,15 +108,18 @@ def kernel_cost(entry, kernel, units, info, wl):
         wgrad = (m_out + m_hid) if info["dw"] else 0                                # dW_out, dW_hidden (dW_in: mlp_dwin_kernel)
         return ("mfma", 2 * units * (chain + wgrad), 2 * units * ((recompute + chain) * pf + wgrad * pw))
     if k == "mlp_dwin_kernel":
-        m_in = mlp_macs(info)[0]
-        return ("mfma", 2 * units * m_in, 2 * units * m_in * (3 if wl.get("mlp_dtype") == "fp16" else 6))
+        # a STREAMING kernel (x and dH_1 read once, 96-128 accumulator registers, no reuse): its honest bound is HBM
+        return ("hbm", units * (info["n_in"] + info["nn"]) * 4)
     # the streaming kernels of the losses and of the iteration's glue (units = ray-samples of the launch)
     if k == "loss_point_sums_kernel":
         return ("hbm", units * 2 * 33 * 4)                                 # fine + coarse latents read
     if k == "loss_point_bwd_kernel":
         return ("hbm", units * 4 * 33 * 4)                                 # ... read again, their gradients written
     if k in ("feature_block_kernel", "feature_block_split_kernel"):
-        return ("hbm", units * (33 * 4 + (32 * 4 if wl.get("code_seed") is not None else 0) + 64 * 4))
+        # fine latent row read; with a 2-D code: the code read and [latent | masked code] = 64 columns written; without one the
+        # code columns are identically zero and neither written nor read (DNS_MLP_LIVE_IN): 32 columns written
+        coded = wl.get("code_seed") is not None
+        return ("hbm", units * (33 * 4 + (32 * 4 if coded else 0) + (64 if coded else 32) * 4))
     if k == "raw_bwd_kernel":
         return ("hbm", units * (3 * 16 + 8))
     if k == "rgb_sigmoid_kernel":
@@ -129,6 +137,8 @@ def kernel_rooflines(spans, wl, steps, pmc):
         row["ms"] += ms
         if c and c[0] == "hbm":
             row["bytes"] += c[1]
+        elif c and c[0] == "lds_atomic":
+            row["lds_adds"] = row.get("lds_adds", 0) + c[1]
         elif c:
             row["flops"] += c[1]
             row["issued"] += c[2]
@@ -140,6 +150,12 @@ def kernel_rooflines(spans, wl, steps, pmc):
             ach = r["bytes"] / sec / 1e9
             out.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]})
+        elif r.get("lds_adds"):
+            ach = r["lds_adds"] / sec / 1e9
+            out.update({"bound": "lds_atomic", "achieved": ach, "peak": LDS_ADD_U64_PEAK_GADDS, "unit": "G adds/s",
+                        "frac": ach / LDS_ADD_U64_PEAK_GADDS, "algorithmic_adds_per_launch": r["lds_adds"] / r["launches"],
+                        "peak_note": "64-bit fixed-point LDS atomics (ds_add_u64): 64 adds per wave-instruction, one per 11.9 cycles per "
+                                     "CU (tools/lds_atomic_rate.hip) x 256 CUs x 2.4 GHz; HBM bytes of the kernel: `traffic`"})
         elif r["flops"]:
             ach = r["flops"] / sec / 1e12
             peak = F16_MFMA_PEAK_TFLOPS / (1 if wl.get("mlp_dtype") == "fp16" else SPLIT_PRODUCTS)
@@ -266,6 +282,78 @@ def capture(step, n_warm=3):
     return replay
 
 
+def slam_loop(cfg, bound, cam, frames, mapper, step, device, n_frames, map_every=5, map_iters=100):
+    """BASELINE configs[2] as a LOOP (reference slams/dns_slam.py:161-172 runs Tracker and Mapper as two processes on one GPU):
+    every frame is tracked (n_iters pose iterations against a frozen copy of the scene, slams/tracking.py:81,313-340), every
+    `map_every`-th frame starts `map_iters` mapping iterations (slams/mapping.py:881-910).  One process, two streams: the
+    tracker's launches go to a high-priority stream, the mapper's to a second one, and the host interleaves their enqueues
+    (map_iters / map_every mapping iterations behind each tracked frame), so both streams always have work queued -- the two step
+    drivers of this package in a for-loop, no control plane.  After a keyframe's last mapping iteration the tracker's copy of
+    the scene is refreshed in place (the reference's update_para_from_mapping)."""
+    import copy
+    from dns_slam_amd.tracking import Tracker
+    trk_dec = copy.deepcopy(mapper.decoder)
+    tracker = Tracker(dict(cfg), trk_dec, bound, cam, device=device)
+    tracker.use_track_step = True
+    n_it = cfg["tracking"]["n_iters"]
+    s_trk, s_map = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+    src = [p for p in mapper.decoder.parameters()]
+    dst = [p for p in trk_dec.parameters()]
+    per_frame = -(-map_iters // map_every)
+
+    def run(nf, record):
+        pending = 0
+        ev = []
+        for f in range(nf):
+            k = f % 4
+            cur = {"gt_color": frames["gt_color"][k], "gt_depth": frames["gt_depth"][k], "gt_label": frames["gt_label"][k]}
+            with torch.cuda.stream(s_trk):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                tracker.track_frame(cur, frames["est_c2w"][k], n_iters=n_it, graph=False)
+                e1.record()
+                if record:
+                    ev.append(("trk", e0, e1))
+            if f % map_every == 0:
+                pending = map_iters
+                m0 = torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(s_map):
+                    m0.record()
+            if pending:
+                with torch.cuda.stream(s_map):
+                    n = min(pending, per_frame)
+                    for _ in range(n):
+                        step()
+                    pending -= n
+                    if pending == 0:
+                        with torch.no_grad():
+                            torch._foreach_copy_(dst, src)            # the tracker's scene copy, refreshed in place
+                        m1 = torch.cuda.Event(enable_timing=True)
+                        m1.record()
+                        if record:
+                            ev.append(("map", m0, m1))
+                        s_trk.wait_stream(s_map)                      # the next tracked frame sees the refreshed copy
+        return ev
+
+    cur_stream = torch.cuda.current_stream()
+    s_trk.wait_stream(cur_stream)
+    s_map.wait_stream(cur_stream)
+    run(map_every, False)                                             # warm-up: one keyframe period
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev = run(n_frames, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    trk = sorted(a.elapsed_time(b) for kind, a, b in ev if kind == "trk")
+    mp = sorted(a.elapsed_time(b) for kind, a, b in ev if kind == "map")
+    med = lambda v: v[len(v) // 2] if v else None
+    return {"frames": n_frames, "frames_per_s": n_frames / dt, "ms_per_frame_wall": dt * 1e3 / n_frames,
+            "tracker_ms_per_frame": med(trk), "tracker_iters_per_frame": n_it, "tracker_rays": cfg["tracking"]["n_pixels"],
+            "mapper_ms_per_keyframe": med(mp), "mapper_iters_per_keyframe": map_iters, "keyframe_every": map_every,
+            "what": "tracker on a high-priority stream, mapper (this line's mapping iteration) on a second stream of the same process; "
+                    "stream spans are event pairs on each stream while BOTH run (they stretch each other); frames_per_s is host wall time"}
+
+
 def host_cores():
     """CPU threads this process may actually use: min(affinity, cgroup quota) -- os.cpu_count() reports the whole node."""
     n = os.cpu_count() or 1
@@ -345,6 +433,55 @@ def cpu_baseline(wl, cfg, bound, cam, frames, budget_s=25.0):
                       f"than SURVEY 8d's 5 warm-up + 20 timed iterations; torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
+def relay_rank0_line(cmd, n_gpus, env=None):
+    """Parent side of ``bench.py --gpus N`` (N > 1, not yet under a launcher): run ``cmd`` (the one-process-per-GPU launcher) as a
+    CHILD process, pass its stderr through, and relay rank 0's JSON line -- but only if the child exited 0 and the line says the
+    job really ran on ``n_gpus`` ranks.  Returns the exit code for the parent.  The parent never touches the GPU (it must not:
+    its children own the devices)."""
+    import subprocess
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    text = p.stdout.decode(errors="replace")
+    line = None
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                cand = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(cand, dict) and "metric" in cand:
+                line = (ln, cand)
+    if p.returncode != 0:
+        sys.stderr.write(text)
+        print(f"[bench] the {n_gpus}-rank launch exited with code {p.returncode}: no result line", file=sys.stderr, flush=True)
+        return p.returncode
+    if line is None:
+        sys.stderr.write(text)
+        print(f"[bench] the {n_gpus}-rank launch printed no result line", file=sys.stderr, flush=True)
+        return 3
+    if line[1].get("n_gpus") != n_gpus or line[1].get("rccl_ranks", line[1].get("n_gpus")) != n_gpus:
+        print(f"[bench] asked for {n_gpus} ranks, the launch reports n_gpus={line[1].get('n_gpus')} "
+              f"rccl_ranks={line[1].get('rccl_ranks')}: refusing to relay a line for a different job size", file=sys.stderr, flush=True)
+        return 4
+    print(line[0], flush=True)
+    return 0
+
+
+def launch_ranks(n_gpus, argv):
+    """``python bench.py --gpus N`` outside a launcher: start ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a
+    child (one rank per GPU over RCCL; rendezvous on 127.0.0.1) and relay rank 0's line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return relay_rank0_line(cmd, n_gpus, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,16 +504,29 @@ def main():
     ap.add_argument("--stem-features", action="store_true",
                     help="run the 2-D feature branch INSIDE every iteration (feature_matching + Decoder.merge on stem feature maps of 3 "
                          "reference views per target frame, slams/mapping.py:532-557) instead of a precomputed per-sample code")
+    ap.add_argument("--loop", type=int, default=0, metavar="F",
+                    help="after the timed region: the interleaved SLAM loop of BASELINE configs[2] over F frames (track every frame, "
+                         "map every 5th; reported as `slam_loop`)")
     ap.add_argument("--union-batch", action="store_true",
                     help="N>1: the N ranks share ONE batch of the configured size (shared-seed draws, rank slices of the rays and "
                          "of the smoothness lattice; strong scaling) instead of one batch per rank (weak scaling, the default)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher yet: this process becomes the parent of N ranks and touches no GPU itself
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from dns_slam_amd import dist as ddist
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # intended: the lattice branch's stream
     from dns_slam_amd import ops
     ctx = ddist.init_from_env(mode="union" if args.union_batch else "weak")
+    if ctx.world_size != args.gpus:
+        # a line for a job of another size than the one asked for would be read as the asked-for size: refuse
+        print(f"[bench] --gpus {args.gpus} but the process group has {ctx.world_size} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE')}): "
+              "launch one rank per GPU (python bench.py --gpus N does it itself)", file=sys.stderr, flush=True)
+        sys.exit(5)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("DNS_FORCE_DEVICE") is not None:       # rehearsal of the N-rank path on a one-GPU box (with gloo)
         local = int(os.environ["DNS_FORCE_DEVICE"])
@@ -557,6 +707,7 @@ def main():
                 "traffic = sum of the PMC FETCH+WRITE bytes of every kernel of one iteration (profiles/pmc_traffic.json)"}
     out = {
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
+        "rccl_ranks": ctx.group_size(), "dist_backend": ctx.backend_name(),
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "step_ms_spread": spread, "higher_is_better": True,
         "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
                   "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "launch_mode": "hipGraph replay" if graphed else "eager",
@@ -624,6 +775,13 @@ def main():
                            "rays": tcfg["tracking"]["n_pixels"], "samples_per_ray": S, "iters_per_frame": n_it}
     except Exception as e:
         out["tracking"] = {"error": f"{type(e).__name__}: {e}"}
+    if args.loop > 0 and ctx.world_size == 1:
+        try:
+            mapper.overlap_smooth, mapper.prefetch_draws = True, True
+            mapper._pending_draws = None
+            out["slam_loop"] = slam_loop(cfg, bound, cam, frames, mapper, step, device, args.loop)
+        except Exception as e:
+            out["slam_loop"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, cfg, bound, cam, frames)

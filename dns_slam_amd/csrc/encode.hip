@@ -1484,6 +1484,10 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_pairbins_kernel(const float
   // per wave instruction against 21.6 for ds_add_f64 -- the conversion that lost in the (vector-bound) sweep form pays here
   int ex;
   (void)frexpf(mx, &ex);
+  //  gradients below 2^-87 would push the scale 2^(40 - ex) past fp32's range (inf, then NaN into the bins): the
+  // exponent is held at -80 -- such values then lose low bits below 2^-120 of themselves, i.e. nothing fp32 could represent
+  // in the sum anyway
+  ex = max(ex, -80);
   const float scale = ldexpf(1.0f, 40 - ex);
   const double inv_scale = (double)ldexpf(1.0f, ex - 40);
   uint32_t qi, slice;                            // list = (level, chunk), and which part of it
@@ -1806,7 +1810,10 @@ static int encode_init_attrs() {
   const int bytes = 8192 * 2 * (int)sizeof(unsigned long long);   // one 8192-row chunk of 64-bit bins: 128 KB
   if (hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
       hipFuncSetAttribute((const void*)hashgrid_bwd_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-      hipFuncSetAttribute((const void*)hashgrid_bwd_pairbins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+      // (+ the job prefix of balanced dense lists: 4 (n_lists + 1) bytes behind the bins; with DNS_LIST_SHIFT=13 the bins alone
+      //  are the whole 128 KB -- ADVICE r4)
+      hipFuncSetAttribute((const void*)hashgrid_bwd_pairbins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)encode_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * 64 + 1) * (int)sizeof(float)) != hipSuccess) {
     set_error("dns_init: hipFuncSetAttribute failed for the hash-grid scatter kernels");
     return DNS_E_LAUNCH;
   }
@@ -2015,6 +2022,8 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
         bins_lds += (size_t)4u * (n_lists + 1u);
         jobs2 = lp.max_jobs;
       }
+      DNS_REQUIRE(bins_lds <= (size_t)MAX_DYN_LDS, "dns_encode_bwd: the pair-list bins (%zu B: DNS_LIST_SHIFT=%u, %u lists) exceed the "
+                  "%d B of LDS a workgroup can have", bins_lds, lp.chunk_shift, n_lists, MAX_DYN_LDS);
       DNS_LAUNCH(hashgrid_bwd_pairbins_kernel, dim3(jobs2), dim3(list_threads(lp.chunk_shift)), bins_lds, st, x, P, lv, lp,
                  (const float2*)ws, lcount, lists, gmax, d_table, (const uint32_t*)lbase, (const uint32_t*)jobstart);
     }

@@ -159,6 +159,14 @@ class DistCtx:
     def enabled(self):
         return self.world_size > 1 or self.force
 
+    def group_size(self) -> int:
+        """Ranks of the process group the collectives run in, as the backend reports it (1 without a group): what ``bench.py``
+        prints as ``rccl_ranks`` next to ``n_gpus``."""
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def backend_name(self) -> str:
+        return str(dist.get_backend(self.group)) if (dist.is_available() and dist.is_initialized()) else "none"
+
     # ---- loss fix-ups -----------------------------------------------------------------------
     def global_mean_scale(self, local_count: torch.Tensor) -> torch.Tensor:
         """Factor s_r = W * count_r / sum_r(count_r) for a masked mean whose denominator is ``local_count``."""

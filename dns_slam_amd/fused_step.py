@@ -951,7 +951,23 @@ class TrackStep:
         if features is not None and features.dim() == 5:
             nets.append(dec.merge.decoder.params)
             fs = fs + (tuple(refer_frames["est_w2c"].shape),)
-        return (int(t.n_pixels), 0 if t.t_uniform is None else t.t_uniform.numel(), t.n_surface_ray, t.H, t.W, t.border, fs,
+        #  also baked into a capture: the networks' precision flag, the device, the level table of the grid (passed by
+        # value), the ADDRESS of the shared surface jitter, and -- with stem maps -- Merge's bound and OneBlob bin count
+        grid = dec.pe_fn.grid_fn
+        meta = getattr(grid, "meta", None)
+        meta_key = None
+        meta = getattr(meta, "c", meta)                      # ops.GridMeta wraps the ctypes DnsGridMeta
+        if meta is not None:
+            n_lv = int(meta.n_levels)
+            meta_key = (n_lv,) + tuple((float(meta.scale[l]), int(meta.resolution[l]), int(meta.size[l]), int(meta.offset[l]),
+                                        int(meta.hashed[l])) for l in range(n_lv))
+        extra = (bool(getattr(dec.coarse_fn.decoder, "fp16", False)), str(torch.device(t.device)), meta_key,
+                 int(dec.pe_fn.pe_fn.n_bins), 0 if t.t_uniform is None else t.t_uniform.data_ptr())
+        if features is not None and features.dim() == 5:
+            mb = getattr(dec.merge, "bound", None)
+            extra = extra + (None if mb is None else tuple(float(v) for v in torch.as_tensor(mb).reshape(-1)),
+                             int(getattr(getattr(dec.merge, "pe_fn", None), "n_bins", 0) or 0))
+        return extra + (int(t.n_pixels), 0 if t.t_uniform is None else t.t_uniform.numel(), t.n_surface_ray, t.H, t.W, t.border, fs,
                 float(t.lambda_p), float(t.lambda_d), float(t.lambda_l), float(t.cam_lr), bool(t.seperate_LR),
                 float(t.fx), float(t.fy), float(t.cx), float(t.cy), tuple(float(v) for v in torch.as_tensor(t.bound).reshape(-1)),
                 tuple((p.data_ptr(), p.numel()) for p in nets))

@@ -911,3 +911,34 @@ def test_mlp_bwd_dx_from_skips_the_leading_columns():
     (dx0, ws0, dp0), (dx1, ws1, dp1) = res
     assert torch.equal(dx1[:, 48:], dx0[:, 48:]) and bool((dx1[:, :48] == -7.0).all()) and torch.equal(ws0, ws1)
     assert_close(dp1.cpu(), dp0.cpu(), rtol=1e-5, elementwise=False, what="DX_FROM: dW")
+
+
+# ----------------------------------------------------------------------------------------- round 5
+def test_oneblob_alone_with_64_bins_leaves_through_the_lds_tile():
+    """A OneBlob-only call takes the LDS-tiled store path; with n_bins >= 43 its tile is larger than the 64 KB a kernel gets without
+    the MaxDynamicSharedMemorySize attribute (such a call failed at launch)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3000, 3, generator=g)
+    y = ops.encode(x.to(DEV), None, None, None, 64, True, False)
+    assert_close(y.cpu(), tr.oneblob_forward(x, 64), rtol=1e-6, what="oneblob n=64")
+
+
+def test_pair_list_scatter_of_tiny_gradients_stays_finite(monkeypatch):
+    """The pair-list bins are fixed-point with a scale 2^(40 - ex) from the largest gradient: below 2^-87 that scale left fp32's
+    range (inf / NaN in the table gradient).  Gradients of ~1e-30 must come out as (tiny) finite numbers equal to
+    1e-30 times the gradient of the unscaled problem."""
+    ops = _ops()
+    pm = ops.GridMeta(16, 592)
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(20000, 3, generator=g).to(DEV)
+    gy = torch.randn(20000, 32, generator=g).to(DEV)
+    monkeypatch.setattr(ops, "SCATTER_FORM", (ops.SCATTER_LISTS, 0))
+    out = []
+    for s in (1.0, 1e-30):
+        table = torch.rand(pm.total_rows * 2, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+        ops.encode(x, table, pm, None, 16, False, True).backward(gy * s)
+        out.append(table.grad.clone())
+    assert bool(torch.isfinite(out[1]).all())
+    ref = out[0].double() * 1e-30
+    assert float((out[1].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

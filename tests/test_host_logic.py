@@ -229,3 +229,30 @@ def test_fixed_launch_sequences_refuse_to_run_without_a_gpu():
         MapStep(SimpleNamespace(device="cpu"), {})
     with pytest.raises(ValueError, match="GPU only"):
         TrackStep(SimpleNamespace(device="cpu"), {}, None)
+
+
+def test_bench_parent_relays_only_a_line_of_the_size_it_asked_for(tmp_path, capsys):
+    """``bench.py --gpus N`` starts N ranks as a child and relays rank 0's line; a line that reports another job size (a child
+    that ran one rank), a missing line or a failing child must NOT produce a result line on the parent's stdout."""
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    child = tmp_path / "child.py"
+
+    def run(body, n):
+        child.write_text(body)
+        rc = bench.relay_rank0_line([sys.executable, str(child)], n)
+        return rc, capsys.readouterr().out
+
+    good = 'import json; print("noise"); print(json.dumps({"metric": "ray-samples/s", "value": 1.0, "n_gpus": %d, "rccl_ranks": %d}))'
+    rc, out = run(good % (2, 2), 2)
+    assert rc == 0 and '"n_gpus": 2' in out
+    rc, out = run(good % (1, 1), 2)                  # the child ran ONE rank
+    assert rc != 0 and out.strip() == ""
+    rc, out = run(good % (2, 1), 2)                  # n_gpus claimed, but the process group had one rank
+    assert rc != 0 and out.strip() == ""
+    rc, out = run('print("no line")', 2)
+    assert rc != 0 and out.strip() == ""
+    rc, out = run(good % (2, 2) + "; import sys; sys.exit(7)", 2)      # a line, but the launch failed
+    assert rc == 7 and out.strip() == ""
