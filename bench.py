@@ -762,16 +762,23 @@ def main():
             res[mode] = (time.perf_counter() - t1) * 1e3 / n_it
         # the same loop as a fixed launch sequence (fused_step.TrackStep), eager and as one captured iteration replayed n_it times
         tracker.use_track_step = True
-        for mode in ("eager", "graph"):
-            tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, graph=(mode == "graph"))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, graph=(mode == "graph"))
-            torch.cuda.synchronize()
-            res["step_" + mode] = (time.perf_counter() - t1) * 1e3 / n_it
+        for fused in (False, True):
+            tracker.use_fused_kernel = fused
+            for mode in ("eager", "graph"):
+                tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, graph=(mode == "graph"))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    tracker.track_frame(cur, frames["est_c2w"][1], n_iters=n_it, graph=(mode == "graph"))
+                torch.cuda.synchronize()
+                res[("fused_" if fused else "step_") + mode] = (time.perf_counter() - t1) * 1e3 / (3 * n_it)
         out["tracking"] = {"ms_per_iter_eager": res["eager"], "ms_per_iter_graph_incl_capture": res["graph"],
                            "ms_per_iter_track_step_eager": res["step_eager"],
                            "ms_per_iter_track_step_graph": res["step_graph"],       # the tracker keeps its TrackStep: capture paid once, by the first frame
+                           # round 5: the iteration as ONE kernel + a pose kernel (2 launches; csrc/track_fused.inc), incl. the frame's
+                           # up-front draws and dns_track_fused_begin
+                           "ms_per_iter_fused_eager": res["fused_eager"], "ms_per_iter_fused_graph": res["fused_graph"],
+                           "launches_per_iter_fused": 2,
                            "rays": tcfg["tracking"]["n_pixels"], "samples_per_ray": S, "iters_per_frame": n_it}
     except Exception as e:
         out["tracking"] = {"error": f"{type(e).__name__}: {e}"}

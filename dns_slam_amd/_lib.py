@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class DnsGridMeta(C.Structure):
@@ -36,6 +36,24 @@ class DnsAdamTensor(C.Structure):
 _P = C.c_void_p
 _U = C.c_uint32
 _I = C.c_int
+
+
+class DnsTrackFused(C.Structure):
+    """include/dns_hip.h: the argument block of dns_track_fused_iter (the tracker's iteration as one kernel + a pose kernel)."""
+    _fields_ = [("color", _P), ("depth", _P), ("label", _P),
+                ("H", C.c_int32), ("W", C.c_int32), ("H0", C.c_int32), ("H1", C.c_int32), ("W0", C.c_int32), ("W1", C.c_int32),
+                ("cam", _P), ("bound", _P),
+                ("pix", _P), ("t_uniform", _P), ("t_surf", _P), ("t_zero", _P), ("dmax", _P), ("iter", _P), ("n_iters", _U),
+                ("n_uniform", _U), ("n_surface", _U), ("n_rays", _U),
+                ("quat", _P), ("trans", _P),
+                ("table", _P), ("meta", C.POINTER(DnsGridMeta)), ("n_bins", _U),
+                ("w_coarse", _P), ("w_color", _P), ("w_logit", _P),
+                ("n_neurons", _U), ("n_hidden_layers", _U), ("hidden", _U), ("n_feat", _U), ("n_class", _U),
+                ("code", _P), ("code_dim", _U),
+                ("lambda_p", C.c_float), ("lambda_d", C.c_float), ("lambda_l", C.c_float),
+                ("ws", _P), ("adam_m", _P), ("adam_v", _P), ("adam_state", _P),
+                ("lr_quat", C.c_float), ("lr_trans", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("best_loss", _P), ("best_cam", _P), ("out", _P), ("g_quat", _P), ("g_trans", _P)]
 
 # name -> (restype, argtypes); must list every symbol include/dns_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -86,6 +104,9 @@ SIGNATURES = {
     "dns_track_mask": (C.c_int, [_P, _P, _U, C.c_float, _P, _P]),
     "dns_keep_best": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "dns_force_half": (C.c_int, [_P, _U, _U, _P]),
+    "dns_track_fused_ws_floats": (C.c_uint64, [C.POINTER(DnsTrackFused)]),
+    "dns_track_fused_begin": (C.c_int, [_P, _U, _U, _P, _I, _I, _I, _I, _P, _U, _P, _P]),
+    "dns_track_fused_iter": (C.c_int, [C.POINTER(DnsTrackFused), _P]),
     "dns_feature_gather": (C.c_int, [_P, _P, _P, _P, _U, _U, _U, _I, _I, _I, _I, _P, _P, _P]),
     "dns_feature_gather_frames": (C.c_int, [_P, _P, _P, _P, _P, _U, _U, _U, _U, _I, _I, _I, _I, _P, _U, _P, _P]),
     "dns_refer_poses": (C.c_int, [_P, _P, _P, _P, _U, _P, _P, _P]),

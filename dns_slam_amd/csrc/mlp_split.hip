@@ -8,185 +8,11 @@ namespace sp {
 unsigned long long* g_bwd_trace = nullptr;
 #endif
 
-struct FwdArgs {
-  const float* x;
-  uint32_t ldx;
-  XSeg seg;
-  const float* params;
-  uint32_t n_in, n_out;
-  float* y;
-  uint32_t ldy, n_slots;
-  const int32_t* row_index;
-  const int32_t* tile_group;
-  uint32_t param_stride, tiles_per_block;
-  float* h_save;
-  const unsigned char* prep;                 // prepared images (NULL: build them from params)
-  uint32_t prep_stride;                      // bytes per weight set
-  XsIn xs;                                   // split-row input (XS kernels; x / seg unused then)
-  uint32_t n_in_w;                           // storage width of W_in's rows (= n_in, or larger with DNS_MLP_LIVE_IN)
-};
-
-// XS: the input arrives in the split-row format (split_rows.hpp) and goes from memory straight into the B operand
 template <int NN, int NL, int PREC, bool XS = false>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
-  constexpr int NT = NN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  using L = FwdLds<NN, NL>;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t n_in = a.n_in, n_out = a.n_out;
-  const uint32_t ns0 = L::ns0(n_in), mt = L::mt(n_out);
-  const uint32_t n_chunks = (n_in + 31u) / 32u;
-  const uint32_t n_btiles = (a.n_slots + 127u) / 128u;
-  const uint32_t bt0 = blockIdx.x * a.tiles_per_block;
-  const uint32_t bt1 = min(bt0 + a.tiles_per_block, n_btiles);
-  const _Float16* img_in = reinterpret_cast<const _Float16*>(lds + L::img_in(n_in));
-  const _Float16* img_h = reinterpret_cast<const _Float16*>(lds + L::img_h(n_in));
-  const _Float16* img_out = reinterpret_cast<const _Float16*>(lds + L::img_out(n_in));
-  int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
-  float* stg = reinterpret_cast<float*>(lds + L::stage(n_in, n_out)) + wave * STG_WAVE_FLOATS;
-  int* rows_all = reinterpret_cast<int*>(stg + STG_FLOATS);
-  XChunk xc[XS ? 1 : 4];                         // n_in <= 128: at most 4 chunks of 32 columns
-  XsTile xt;                                     // (XS) the tile's operand fragments
-  bool have_x = false;
-  uint32_t cur_buf = 0;
-  int cur_group = -2;
-  for (uint32_t bt = bt0; bt < bt1; ++bt) {
-    const int grp = a.tile_group ? a.tile_group[bt] : 0;
-    if (grp != cur_group) {
-      __syncthreads();
-      if (grp >= 0) {
-        if (a.prep) {
-          const unsigned char* src = a.prep + (size_t)grp * a.prep_stride;
-          images_copy_in(lds, src, L::misc(n_in, n_out), src + L::misc(n_in, n_out), wexp);
-        }
-        if (!a.prep) build_fwd_images<NN, NL>(lds, a.params + (size_t)grp * a.param_stride, n_in, n_out, a.n_in_w);
-      }
-      cur_group = grp;
-      __syncthreads();
-    }
-    if (grp < 0) continue;
-    const uint32_t slot0 = bt * 128u + wave * 32u;
-    const uint32_t nrows = slot0 < a.n_slots ? min(32u, a.n_slots - slot0) : 0u;
-    // The tile's x rows (all <= 4 chunks of 32 columns) were requested while the PREVIOUS tile ran its later layers; only
-    // a workgroup's first live tile pays the latency here.
-    if (have_x) {
-      cur_buf ^= 1u;
-    } else {
-      tile_rows_publish(rows_all + 32u * cur_buf, a.row_index, slot0, a.n_slots, lane);
-      if constexpr (XS) {
-        xs_issue<PREC>(xt, a.xs, ns0, rows_all + 32u * cur_buf, lane);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * cur_buf, c, lane);
-      }
-    }
-    const int* rows_lds = rows_all + 32u * cur_buf;
-    int kc;                                        // cumulative exponent: accumulators hold 2^kc * (true value)
-    f32x16 a0[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a0[t] = zero16();
-    if constexpr (XS) {
-      kc = xs_align<PREC>(xt, a.xs, ns0) + wexp[0];
-      layer_first_xs<PREC, NT>(xt, ns0, img_in, ns0, lane, a0);
-    } else {
-    float* rmax = stg + STG_FLOATS + STG_ROWS;
-    x_row_max<4>(xc, n_chunks, rmax, lane);
-    kc = scale_exp(rmax[lane & 31u]);
-    const float sx = pow2f(kc);
-    kc += wexp[0];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if ((uint32_t)c < n_chunks) {                // uniform
-        float xs[16];
-        x_chunk_commit(xc[c], stg, lane);
-        x_chunk_read(xs, stg, lane);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const uint32_t ks = 2u * c + s;
-          if (ks < ns0) {                          // uniform
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = xs[8 * s + j];
-            const Frag b = split8(v, sx);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a0[t] = mma<PREC>(load_frag<PREC>(img_in, ns0, t, ks, lane), b, a0[t]);
-          }
-        }
-      }
-    }
-    }
-    // request the next live tile's rows now: they arrive while this tile runs its later layers
-    have_x = false;
-    for (uint32_t nbt = bt + 1; nbt < bt1; ++nbt) {
-      if ((a.tile_group ? a.tile_group[nbt] : 0) < 0) continue;
-      int* nrows_lds = rows_all + 32u * (cur_buf ^ 1u);
-      tile_rows_publish(nrows_lds, a.row_index, nbt * 128u + wave * 32u, a.n_slots, lane);
-      if constexpr (XS) {
-        xs_issue<PREC>(xt, a.xs, ns0, nrows_lds, lane);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, nrows_lds, c, lane);
-      }
-      have_x = true;
-      break;
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a0[t][r] = fmaxf(a0[t][r], 0.f);
-    if (a.h_save) {                                // kept for callers that want the hidden activations
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        f32x16 hv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hv[r] = ldexpf(a0[t][r], -kc);
-        store_tile_staged(a.h_save + (size_t)slot0 * NN + t * 32, NN, nrows, hv, stg, lane);
-      }
-    }
-    f32x16 a1[NT];
-    if (NL == 2) {
-      const int kf = scale_exp(tile_max<NT>(a0)) ;
-      layer_chain<PREC, NT, NT>(a0, pow2f(kf), img_h, lane, a1);
-      kc += kf + wexp[1];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[t][r] = fmaxf(a1[t][r], 0.f);
-      if (a.h_save) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          f32x16 hv;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hv[r] = ldexpf(a1[t][r], -kc);
-          store_tile_staged(a.h_save + (size_t)(a.n_slots + slot0) * NN + t * 32, NN, nrows, hv, stg, lane);
-        }
-      }
-    }
-    const f32x16(&hl)[NT] = (NL == 2) ? a1 : a0;
-    const int kf = scale_exp(tile_max<NT>(hl));
-    kc += kf + wexp[2];
-    const float fo = pow2f(kf);
-    if (mt >= 2u) {
-      f32x16 o[2];
-      layer_chain<PREC, 2, NT>(hl, fo, img_out, lane, o);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] = ldexpf(o[t][r], -kc);
-      store_tile_rows_scalar(a.y, a.ldy, 0, 32u, rows_lds, o[0], stg, lane);
-      store_tile_rows_scalar(a.y, a.ldy, 32, n_out - 32u, rows_lds, o[1], stg, lane);
-    } else {
-      f32x16 o[1];
-      layer_chain<PREC, 1, NT>(hl, fo, img_out, lane, o);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[0][r] = ldexpf(o[0][r], -kc);
-      store_tile_rows_scalar(a.y, a.ldy, 0, n_out, rows_lds, o[0], stg, lane);
-    }
-  }
+  mlp_fwd_body<NN, NL, PREC, XS>(a, blockIdx.x, lds);
 }
-
 
 // =================================================================================================================
 // dW_in[n][c] = sum_points dH_1[point][n] * X[point][c]: a streaming product whose K axis is the point axis.  Both

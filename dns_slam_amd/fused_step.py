@@ -33,7 +33,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import DnsAdamTensor, DnsSplitRows, check, ptr
+from ._lib import DnsAdamTensor, DnsSplitRows, DnsTrackFused, check, ptr
 from .common import get_quad_from_c2w, get_rotation_from_quad
 
 _V = C.c_void_p
@@ -1001,6 +1001,105 @@ class TrackStep:
         st = _V(torch.cuda.current_stream().cuda_stream)
         for (p_, shp_), w in zip(self._nets_w, self.w):
             check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w), st), "dns_mlp_prepare")
+
+    # ---- the iteration as ONE kernel + a pose kernel (csrc/track_fused.inc, ABI v11) ------------------------------------------
+    def fused_supported(self):
+        """Can ``run_fused`` take this tracker?  (S <= 64, 64 x 2 or 32 x 1 networks, no in-loop stem branch, fp32-grade MLPs.)"""
+        if self.stem or self.fp16 or self.S > 64:
+            return False
+        if (self.shp_c[2], self.shp_c[3]) not in ((64, 2), (32, 1)):
+            return False
+        return self._fused_block(1) is not None
+
+    def _fused_block(self, n_iters):
+        """The DnsTrackFused argument block for a frame of n_iters iterations (draw arrays allocated here), or None when the
+        library refuses the shape."""
+        t, dev = self.t, self.dev
+        key = int(n_iters)
+        fb = getattr(self, "_fb", None)
+        if fb is not None and fb["n_iters"] == key:
+            return fb
+        b, H, W, N, ns = t.border, t.H, t.W, self.N, self.ns
+        a = DnsTrackFused()
+        keep = {"pix": torch.zeros(key, N, device=dev, dtype=torch.int64), "t_surf": torch.zeros(key, ns, device=dev),
+                "t_zero": torch.zeros(key, ns, device=dev), "dmax": torch.zeros(key, device=dev, dtype=torch.int32),
+                "iter": torch.zeros(1, device=dev, dtype=torch.int32), "out": torch.zeros(8, device=dev)}
+        a.color, a.depth, a.label = self.prep["color"].data_ptr(), self.prep["depth"].data_ptr(), self.prep["label"].data_ptr()
+        a.H, a.W, a.H0, a.H1, a.W0, a.W1 = H, W, b, H - b, b, W - b
+        a.cam, a.bound = C.addressof(self.camv), C.addressof(self.b6)
+        a.pix, a.t_surf, a.t_zero, a.dmax = (keep[k].data_ptr() for k in ("pix", "t_surf", "t_zero", "dmax"))
+        a.t_uniform = 0 if t.t_uniform is None else t.t_uniform.data_ptr()
+        a.iter, a.n_iters = keep["iter"].data_ptr(), key
+        a.n_uniform, a.n_surface, a.n_rays = self.nu, ns, N
+        a.quat, a.trans = self.Q.data_ptr(), self.T.data_ptr()
+        a.table, a.meta, a.n_bins = self.p_table.data_ptr(), C.pointer(self.meta.c), self.n_bins
+        a.w_coarse, a.w_color, a.w_logit = self.w_coarse.data_ptr(), self.w_color.data_ptr(), self.w_logit.data_ptr()
+        a.n_neurons, a.n_hidden_layers = self.shp_c[2], self.shp_c[3]
+        a.hidden, a.n_feat, a.n_class = self.hid, self.n_feat, self.n_class
+        if self.features is not None:
+            a.code, a.code_dim = self.features.data_ptr(), self.features.shape[-1]
+        else:
+            a.code, a.code_dim = 0, 0
+        a.lambda_p, a.lambda_d, a.lambda_l = float(t.lambda_p), float(t.lambda_d), float(t.lambda_l)
+        lr = float(t.cam_lr)
+        a.lr_quat, a.lr_trans = lr, (lr * 0.2 if t.seperate_LR else lr)
+        a.beta1, a.beta2, a.eps = self.betas[0], self.betas[1], self.eps
+        a.adam_m, a.adam_v, a.adam_state = self.M.data_ptr(), self.V.data_ptr(), self.adam_state.data_ptr()
+        a.best_loss, a.best_cam = self.best_loss.data_ptr(), self.best_cam.data_ptr()
+        a.out, a.g_quat, a.g_trans = keep["out"].data_ptr(), self.g_quat.data_ptr(), self.g_trans.data_ptr()
+        n_ws = int(ops.lib._raw.dns_track_fused_ws_floats(C.byref(a)))
+        if n_ws == 0:
+            return None
+        keep["ws"] = torch.empty(n_ws + 64, device=dev)
+        off = (-keep["ws"].data_ptr() // 4) % 64                       # 256-byte aligned start
+        a.ws = keep["ws"].data_ptr() + 4 * off
+        self._fb = {"n_iters": key, "args": a, "keep": keep, "graph": None}
+        return self._fb
+
+    @torch.no_grad()
+    def run_fused(self, n_iters, graph=False, draws=None):
+        """n_iters iterations, two launches each (``dns_track_fused_iter``): the frame's draws are made up front -- ``draws`` =
+        (pix [n_iters, N] int64, t_surf [n_iters, ns], t_zero [n_iters, ns]) or None for the device generator (ONE randint and
+        two rand calls per frame instead of three launches per iteration) -- and a device counter selects the iteration's rows,
+        so every launch of a frame has the same arguments: ``graph`` replays one captured iteration."""
+        t, lib = self.t, ops.lib
+        fb = self._fused_block(n_iters)
+        if fb is None:
+            raise ValueError("TrackStep.run_fused: shape outside the fused form (fused_supported() tells)")
+        a, keep = fb["args"], fb["keep"]
+        st = _V(torch.cuda.current_stream().cuda_stream)
+        b, H, W, N = t.border, t.H, t.W, self.N
+        if draws is None:
+            keep["pix"].copy_(torch.randint((H - 2 * b) * (W - 2 * b), (n_iters, N), device=self.dev))
+            keep["t_surf"].copy_(torch.rand(n_iters, self.ns, device=self.dev))
+            keep["t_zero"].copy_(torch.rand(n_iters, self.ns, device=self.dev))
+        else:
+            for k, v in zip(("pix", "t_surf", "t_zero"), draws):
+                keep[k].copy_(v.to(self.dev))
+        keep["iter"].zero_()
+        self._prepare_weights_if_stale()
+        check(lib.dns_track_fused_begin(ptr(keep["pix"]), N, n_iters, ptr(self.prep["depth"]), W, b, b, W - b, ptr(keep["t_surf"]), self.ns,
+                                        ptr(keep["dmax"]), st), "dns_track_fused_begin")
+        if not graph:
+            for _ in range(n_iters):
+                check(lib._raw.dns_track_fused_iter(C.byref(a), st), "dns_track_fused_iter")
+        else:
+            if fb["graph"] is None:
+                from ._lib import ensure_init
+                ensure_init()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    check(lib._raw.dns_track_fused_iter(C.byref(a), _V(torch.cuda.current_stream().cuda_stream)), "dns_track_fused_iter")
+                keep["iter"].zero_()                       # (nothing executed during capture)
+                fb["graph"] = g
+            for _ in range(n_iters):
+                fb["graph"].replay()
+        self.steps += n_iters
+        self.fused_out = keep["out"]
+        return self.best_cam, self.best_loss[0]
+
+    def _prepare_weights_if_stale(self):
+        pass                                               # (reset() rebuilds the operand images per frame; nothing to do here)
 
     def run(self, n_iters, graph=True):
         """n_iters iterations -> (best camera tensor [7] = (quat | T), best loss).  ``graph``: capture one iteration into a

@@ -177,7 +177,12 @@ class Tracker:
             else:
                 ts = TrackStep(self, cur_frames, est_c2w, features=features, refer_frames=refer_frames)
                 self._track_step, self._track_step_key = ts, key
-            cam, best = ts.run(n_iters, graph=graph)
+            # round 5: the whole iteration as ONE kernel + a pose kernel (csrc/track_fused.inc) wherever the shape allows it
+            # (S <= 64, 64 x 2 / 32 x 1 networks, no in-loop stem branch); use_fused_kernel = False keeps the launch sequence
+            if getattr(self, "use_fused_kernel", True) and ts.fused_supported():
+                cam, best = ts.run_fused(n_iters, graph=graph)
+            else:
+                cam, best = ts.run(n_iters, graph=graph)
             cam, best = cam.clone(), best.clone()          # the TrackStep's own buffers are overwritten by the next frame
             self.last_track_step = ts
             self.last_optimizer = None

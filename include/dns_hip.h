@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 10
+#define DNS_ABI_VERSION 11
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -395,6 +395,70 @@ typedef struct DnsAdamTensor {
 } DnsAdamTensor;
 int dns_adam_step(const DnsAdamTensor* tensors, uint32_t n_tensors, float beta1, float beta2, float eps,
                   float* state, void* stream);
+
+/* ---- the tracker's optimise iteration as ONE kernel + a pose kernel (ABI v11) ---------------------------------------
+ * Replaces the per-iteration body of Tracker.run (reference slams/tracking.py:313-340: get_target_samples :128-186,
+ * renderer :188-214, the three masked losses :85-96, backward to the pose, Adam on (quat, T), keep-best :326-335) for the
+ * frozen scene.  A 256-thread workgroup owns 2 (S > 32) or 4 rays from the pixel draw to their share of the pose gradient:
+ * sampling, OneBlob + hash-grid encoding, coarse / colour / logit networks forward, compositing, losses, compositing and
+ * network backward, encoding backward; a one-workgroup pose kernel sums the workgroups' partial results, forms the loss,
+ * keeps the best pose, runs the quaternion chain rule and the Adam update.  Two launches per iteration.
+ *   The draws of ALL n_iters iterations of a frame are made up front: pix [n_iters, n_rays] int64 (index into the window
+ *   [H0,H1) x [W0,W1)), t_surf / t_zero [n_iters, n_surface], dmax [n_iters] (bits of max(gt_depth > 0) over each draw;
+ *   dns_track_fused_begin computes it and forces the mid sample of every t_surf row in one launch: neither depends on the
+ *   pose); t_uniform [n_uniform] is shared.  iter [1] uint32: device counter of the frame's iterations (zero it per frame):
+ *   launch k reads draws min(iter, n_iters - 1) and the pose kernel advances it -- every launch of a frame has the SAME
+ *   arguments, so one captured iteration replays n_iters times.
+ *   quat [4], trans [3]: the pose, updated in place.  adam_m / adam_v [8] (quat at 0, trans at 4), adam_state [3] (step count,
+ *   1 - beta1^t, 1 - beta2^t): zero them per frame.  best_loss [1] (+inf per frame), best_cam [7].
+ *   w_coarse / w_color / w_logit: dns_mlp_prepare images of the three networks (inputs 3 n_bins + 2 n_levels -> hidden + 1;
+ *   3 n_bins + n_feat -> 3 and -> n_class).  code [n_rays * S, code_dim] or NULL: the 2-D feature code of every sample.
+ *   ws: dns_track_fused_ws_floats(a) floats, 256-byte aligned (rows the workgroups hand from phase to phase).
+ *   out [8]: loss terms p, d, l, total, n_valid of THIS iteration (before the update); g_quat [4], g_trans [3]: its gradient.
+ * Supported: S <= 64, networks 64 x 2 or 32 x 1, 64 < 3 n_bins + 2 n_levels <= 96, 96 < 3 n_bins + n_feat <= 128; otherwise
+ * DNS_E_ARG (callers fall back to the launch sequence of the single entry points). */
+typedef struct DnsTrackFused {
+  const float* color;
+  const float* depth;
+  const float* label;
+  int32_t H, W, H0, H1, W0, W1;
+  const double* cam;                 /* fx fy cx cy */
+  const double* bound;               /* [3][2] */
+  const int64_t* pix;
+  const float* t_uniform;
+  const float* t_surf;
+  const float* t_zero;
+  const uint32_t* dmax;
+  uint32_t* iter;
+  uint32_t n_iters;
+  uint32_t n_uniform, n_surface, n_rays;
+  float* quat;
+  float* trans;
+  const float* table;
+  const DnsGridMeta* meta;
+  uint32_t n_bins;
+  const float* w_coarse;
+  const float* w_color;
+  const float* w_logit;
+  uint32_t n_neurons, n_hidden_layers, hidden, n_feat, n_class;
+  const float* code;
+  uint32_t code_dim;
+  float lambda_p, lambda_d, lambda_l;
+  float* ws;
+  float* adam_m;
+  float* adam_v;
+  float* adam_state;
+  float lr_quat, lr_trans, beta1, beta2, eps;
+  float* best_loss;
+  float* best_cam;
+  float* out;
+  float* g_quat;
+  float* g_trans;
+} DnsTrackFused;
+uint64_t dns_track_fused_ws_floats(const DnsTrackFused* a);
+int dns_track_fused_begin(const int64_t* pix_all, uint32_t n_rays, uint32_t n_iters, const float* depth, int W, int H0, int W0,
+                          int W1, float* t_surf_all, uint32_t n_surface, uint32_t* dmax_all, void* stream);
+int dns_track_fused_iter(const DnsTrackFused* a, void* stream);
 
 /* ---- small fused helpers of the mapping iteration ----------------------------------------------
  * Total-variation smoothness of coarse[:, 0] on a lattice of nx x n x n points (x-major; nx = n: the n^3 cube of

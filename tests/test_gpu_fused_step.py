@@ -643,3 +643,64 @@ def test_composite_rgb_logits_and_point_loss_backward_with_occupancy():
             assert_close(a.cpu(), b.cpu(), rtol=1e-6, what=f"point losses + d occupancy: {name}")
         else:
             assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("code", [False, True])
+@pytest.mark.parametrize("nn,nl,nu,ns", [(64, 2, 32, 15), (64, 2, 48, 16), (32, 1, 22, 10)])
+def test_track_step_fused_kernel_equals_the_launch_sequence(nn, nl, nu, ns, code):
+    """``TrackStep.run_fused`` (round 5: the tracker's iteration as ONE kernel + a pose kernel, csrc/track_fused.inc) against the
+    28-launch ``TrackStep.step`` on the SAME draws (pixels, surface jitter with its forced mid sample, zero-depth jitter): the
+    same per-ray and per-point arithmetic (shared device functions, the same MLP bodies); what differs is the order of the
+    fp32 sums of the pose gradient and ONE division by the valid-ray count instead of one per ray.  15 free-running iterations:
+    best loss to 1e-5, pose and best camera to 2e-5, the last iteration's loss terms to 2e-5 of themselves.  S = 47, 64 and 32
+    (two and four rays per workgroup), 64 x 2 and 32 x 1 networks, with and without a per-sample 2-D code; eager and replayed
+    from ONE captured iteration."""
+    from dns_slam_amd.fused_step import TrackStep
+    from dns_slam_amd.tracking import Tracker
+    cfg, bound, cam, frames, dec, mapper = _setup(nn, nl, n_pixels=400)
+    cfg["tracking"]["n_pixels"] = 250
+    cfg["training"]["n_samples_ray"], cfg["training"]["n_surface_ray"] = nu, ns
+    cur = {"gt_color": frames["gt_color"][2], "gt_depth": frames["gt_depth"][2], "gt_label": frames["gt_label"][2]}
+    c2w = frames["est_c2w"][2].clone()
+    c2w[:3, 3] += torch.tensor([0.02, -0.01, 0.015], dtype=c2w.dtype)
+    n_it, N = 15, 250
+    feats = (torch.rand(N, nu + ns, 32, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(DEV) if code else None
+    g = torch.Generator().manual_seed(9)
+
+    def mk():
+        tracker = Tracker(cfg, dec, bound, cam, device=DEV)
+        tracker.border = 5
+        tracker.static_shapes = True
+        return tracker
+
+    tracker = mk()
+    H, W, b = tracker.H, tracker.W, tracker.border
+    draws = (torch.randint((H - 2 * b) * (W - 2 * b), (n_it, N), generator=g), torch.rand(n_it, tracker.n_surface_ray, generator=g),
+             torch.rand(n_it, tracker.n_surface_ray, generator=g))
+    res = {}
+    for mode in ("fused", "fused_graph"):
+        tracker = mk()
+        with tracker.frozen_scene():
+            ts = TrackStep(tracker, cur, c2w, features=feats)
+            assert ts.fused_supported()
+            cam7, best = ts.run_fused(n_it, graph=(mode == "fused_graph"), draws=draws)
+            torch.cuda.synchronize()
+            t_surf_forced = ts._fb["keep"]["t_surf"].clone()
+            res[mode] = (cam7.cpu().clone(), float(best), ts.Q.cpu().clone(), ts.T.cpu().clone(), ts.fused_out.cpu().clone())
+    # the launch sequence on the same draws (the forced mid sample as dns_track_fused_begin left it)
+    tracker = mk()
+    with tracker.frozen_scene():
+        ts = TrackStep(tracker, cur, c2w, features=feats)
+        for k in range(n_it):
+            ts.step(draws=(draws[0][k].to(DEV), t_surf_forced[k].contiguous(), draws[2][k].to(DEV)))
+        torch.cuda.synchronize()
+        ref = (ts.best_cam.cpu().clone(), float(ts.best_loss[0]), ts.Q.cpu().clone(), ts.T.cpu().clone(), ts.out.cpu().clone())
+    for mode in ("fused", "fused_graph"):
+        cam7, best, Q, T, out = res[mode]
+        assert abs(best - ref[1]) <= 1e-5 * abs(ref[1]), (mode, best, ref[1])
+        assert float((cam7 - ref[0]).abs().max()) <= 2e-5, (mode, cam7, ref[0])
+        assert float((Q - ref[2]).abs().max()) <= 2e-5 and float((T - ref[3]).abs().max()) <= 2e-5, (mode, Q, ref[2], T, ref[3])
+        # last iteration's terms: fused out = (p, d, l, total, n_valid); launch sequence out = (p, d, l, lt, fs, op, total, ...)
+        for i, j in ((0, 0), (1, 1), (2, 2), (3, 6)):
+            assert abs(float(out[i]) - float(ref[4][j])) <= 2e-5 * abs(float(ref[4][j])) + 1e-7, (mode, i, float(out[i]), float(ref[4][j]))
+    assert float((ref[3].reshape(-1) - c2w[:3, 3].float()).abs().max()) > 0              # the pose did move
