@@ -256,7 +256,18 @@ __device__ __forceinline__ void images_copy_in(unsigned char* lds, const unsigne
                                                const unsigned char* __restrict__ exps, int* wexp) {
   const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
   uint4* d4 = reinterpret_cast<uint4*>(lds);
-  for (uint32_t e = threadIdx.x; e < bytes / 16u; e += blockDim.x) d4[e] = s4[e];
+  // eight 16-byte requests per thread in flight before the first LDS store (round 5: rolled, every trip of this loop was a
+  // dependent load -> store pair -- 26 L2 round trips for a 104 KB backward image set, a third of a small launch's time)
+  const uint32_t n = bytes / 16u, stride = blockDim.x;
+  uint32_t e = threadIdx.x;
+  for (; e + 7u * stride < n; e += 8u * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = s4[e + k * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d4[e + k * stride] = v[k];
+  }
+  for (; e < n; e += stride) d4[e] = s4[e];
   if (threadIdx.x < 3) wexp[threadIdx.x] = reinterpret_cast<const int*>(exps)[threadIdx.x];
 }
 __device__ __forceinline__ void images_copy_out(const unsigned char* lds, unsigned char* __restrict__ dst, uint32_t bytes, const int* wexp) {
@@ -1025,6 +1036,19 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
     const int grp = a.tile_group ? a.tile_group[bt] : 0;
     if (grp != cur_group) {
       __syncthreads();
+      if (grp >= 0 && !have_x) {
+        // the tile's rows are requested BEFORE the weight images are copied in / built: the two are independent, and a launch
+        // of one tile per wave (the tracker's 32 768 points) otherwise pays the rows' memory latency behind the images'
+        tile_rows_publish(rows_all + 32u * (cur_buf ^ 1u), a.row_index, bt * 128u + wave * 32u, a.n_slots, lane);
+        if constexpr (XS) {
+          xs_issue<PREC>(xt, a.xs, ns0, rows_all + 32u * (cur_buf ^ 1u), lane);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * (cur_buf ^ 1u), c, lane);
+        }
+        have_x = true;
+      }
       if (grp >= 0) {
         if (a.prep) {
           const unsigned char* src = a.prep + (size_t)grp * a.prep_stride;
