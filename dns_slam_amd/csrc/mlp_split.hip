@@ -151,6 +151,12 @@ int launch_mlp_fwd_split(const float* x, uint32_t ldx, const float* x2, uint32_t
   a.x = x; a.ldx = ldx; a.seg = {x2, ldx2, x2 ? n_in1 : n_in}; a.params = params; a.n_in = n_in; a.n_out = n_out;
   a.y = y; a.ldy = ldy; a.n_slots = n_slots; a.row_index = row_index; a.tile_group = tile_group; a.param_stride = param_stride;
   a.h_save = h_save;
+  // y and h_save are addressed through buffer descriptors (mlp_split.hpp): 2 GiB per matrix.  Slot-ordered rows are checked
+  // here; rows behind a row table on the device (DNS_DEVERR_MLP_RANGE)
+  a.err = device_error_word();
+  DNS_REQUIRE((row_index ? 0ull : (uint64_t)n_slots) * ldy * 4ull < (uint64_t)BUF_LIMIT &&
+                  (!h_save || 2ull * n_slots * n_neurons * 4ull < (uint64_t)BUF_LIMIT),
+              "dns_mlp_fwd: %u slots x %u output floats per row exceed the 2 GiB per matrix this kernel addresses", n_slots, ldy);
   const uint32_t n_btiles = (n_slots + 127u) / 128u;
   uint32_t tpb = (n_btiles + 511u) / 512u;       // ~2 workgroups of 4 waves per CU, contiguous tile ranges
   if (tpb < 1) tpb = 1;

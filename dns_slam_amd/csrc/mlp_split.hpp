@@ -308,6 +308,7 @@ constexpr uint32_t STG_FLOATS = 32 * STG_LD;
 constexpr uint32_t STG_ROWS = 64;            // two row tables: the tile being computed and the one being prefetched
 constexpr uint32_t STG_RMAX = 32;            // per-row maxima of the tile's input rows
 constexpr uint32_t STG_WAVE_FLOATS = STG_FLOATS + STG_ROWS + STG_RMAX;
+constexpr uint32_t FWD_WAVE_FLOATS = STG_WAVE_FLOATS + 32;   // the forward kernel's wave area: + the tile's 32 row offsets in y
 
 // (Measured in round 2: volatile staging accesses instead of this fence -- so that unrelated LDS reads, e.g. the next weight
 // fragments, may move across a staging round trip -- let hipcc hoist so much that every backward instance spilled 60-198
@@ -924,6 +925,35 @@ __device__ __forceinline__ void store_tile_rows_buf(const DxIo& io, const uint32
   wave_lds_fence();
 }
 
+// a (32 features x 32 points, accumulator layout, already unscaled) -> y[row][col0 + f], f < ncols, rows through the tile's
+// offset table (BUF_OOB = a padding slot); dword stores with lane = feature: 2 rows x 128 bytes per instruction, any row
+// stride / alignment; straight-line (store_tile_rows_scalar's guarded stores kept hipcc from counting what is in flight)
+__device__ __forceinline__ void store_tile_rows_scalar_buf(rsrc_t ry, const uint32_t* __restrict__ yoff, uint32_t col0, uint32_t ncols,
+                                                           const f32x16& a, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(stg + pt * STG_LD + 8 * g + 4 * h) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+  wave_lds_fence();
+  const uint32_t f = lane & 31u;
+  const uint32_t cb = f < ncols ? 4u * (col0 + f) : BUF_OOB;
+  uint32_t off[16];
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t r = (lane >> 5) + 2 * i;
+    off[i] = yoff[r];
+    v[i] = stg[r * STG_LD + f];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    // (an out-of-range row offset plus an out-of-range column marker would wrap: the column marker wins by select)
+    const uint32_t o = f < ncols ? off[i] + cb : BUF_OOB;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), ry, (int)o, 0, 0);
+  }
+  wave_lds_fence();
+}
+
 // a: 32 features x 32 points -> rows (row0 + r) of a slot-major [n][ld] matrix behind descriptor r (r < nrows), columns
 // col0 .. col0 + 31; 16-byte aligned rows
 __device__ __forceinline__ void store_tile_staged_buf(rsrc_t rd, uint32_t row0_bytes, uint32_t ld, uint32_t col0, uint32_t nrows,
@@ -955,7 +985,7 @@ struct FwdLds {
   static __host__ __device__ uint32_t misc(uint32_t n_in, uint32_t n_out) { return img_out(n_in) + mt(n_out) * (NN / 16) * 2048u; }
   static __host__ __device__ uint32_t stage(uint32_t n_in, uint32_t n_out) { return misc(n_in, n_out) + 256u; }   // exps + reduction
   static __host__ __device__ uint32_t total(uint32_t n_in, uint32_t n_out, uint32_t nwaves) {
-    return stage(n_in, n_out) + nwaves * STG_WAVE_FLOATS * 4u;
+    return stage(n_in, n_out) + nwaves * FWD_WAVE_FLOATS * 4u;
   }
 };
 
@@ -1005,6 +1035,7 @@ struct FwdArgs {
   uint32_t prep_stride;                      // bytes per weight set
   XsIn xs;                                   // split-row input (XS kernels; x / seg unused then)
   uint32_t n_in_w;                           // storage width of W_in's rows (= n_in, or larger with DNS_MLP_LIVE_IN)
+  uint32_t* err;                             // the library's sticky device error word (DNS_DEVERR_MLP_RANGE)
 };
 
 // XS: the input arrives in the split-row format (split_rows.hpp) and goes from memory straight into the B operand
@@ -1025,30 +1056,44 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
   const _Float16* img_h = reinterpret_cast<const _Float16*>(lds + L::img_h(n_in));
   const _Float16* img_out = reinterpret_cast<const _Float16*>(lds + L::img_out(n_in));
   int* wexp = reinterpret_cast<int*>(lds + L::misc(n_in, n_out));
-  float* stg = reinterpret_cast<float*>(lds + L::stage(n_in, n_out)) + wave * STG_WAVE_FLOATS;
+  float* stg = reinterpret_cast<float*>(lds + L::stage(n_in, n_out)) + wave * FWD_WAVE_FLOATS;
   int* rows_all = reinterpret_cast<int*>(stg + STG_FLOATS);
   XChunk xc[XS ? 1 : 4];                         // n_in <= 128: at most 4 chunks of 32 columns
   XsTile xt;                                     // (XS) the tile's operand fragments
-  bool have_x = false;
-  uint32_t cur_buf = 0;
+  uint32_t cur_buf = 1;
   int cur_group = -2;
+  const rsrc_t r_y = buf_make(a.y), r_hs = buf_make(a.h_save);
+  uint32_t* yoff = reinterpret_cast<uint32_t*>(stg + STG_WAVE_FLOATS);      // byte offsets of the tile's rows in y (BUF_OOB: padding)
+  const uint32_t y_row_limit = BUF_LIMIT / (4u * max(a.ldy, 1u));
+  uint32_t bad_rows = 0;
+  // the rows and inputs of live tile `nbt` -> row table `buf`, registers xc / xt
+  auto request = [&](uint32_t nbt, uint32_t buf) {
+    int* nrows_lds = rows_all + 32u * buf;
+    tile_rows_publish(nrows_lds, a.row_index, nbt * 128u + wave * 32u, a.n_slots, lane);
+    if constexpr (XS) {
+      xs_issue<PREC>(xt, a.xs, ns0, nrows_lds, lane);
+    } else {
+      // all FOUR chunks, unconditionally: a chunk past n_in re-reads the row's last four columns (x_chunk_issue clamps: one
+      // 16-byte piece per row, L1 hits) and is never consumed -- with the requests under `c < n_chunks` hipcc cannot count on
+      // any request behind a chunk's and waits for vmcnt(3..0) at every chunk's first use: for every chunk behind it AND the
+      // previous tile's output stores
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, nrows_lds, c, lane);
+    }
+  };
+  // The workgroup's FIRST live tile is requested here -- in front of the weight images' copy-in / build, which it does not
+  // depend on --, every later one while the tile in front of it runs its later layers.  One request site inside the loop:
+  // with a second one at its top ("not requested yet") the two definitions of the input registers met in a copy behind
+  // s_waitcnt vmcnt(0) at every tile start, i.e. behind every output store of the previous tile (round 5, ISA).
+  for (uint32_t nbt = bt0; nbt < bt1; ++nbt) {
+    if ((a.tile_group ? a.tile_group[nbt] : 0) < 0) continue;
+    request(nbt, 0u);
+    break;
+  }
   for (uint32_t bt = bt0; bt < bt1; ++bt) {
     const int grp = a.tile_group ? a.tile_group[bt] : 0;
     if (grp != cur_group) {
       __syncthreads();
-      if (grp >= 0 && !have_x) {
-        // the tile's rows are requested BEFORE the weight images are copied in / built: the two are independent, and a launch
-        // of one tile per wave (the tracker's 32 768 points) otherwise pays the rows' memory latency behind the images'
-        tile_rows_publish(rows_all + 32u * (cur_buf ^ 1u), a.row_index, bt * 128u + wave * 32u, a.n_slots, lane);
-        if constexpr (XS) {
-          xs_issue<PREC>(xt, a.xs, ns0, rows_all + 32u * (cur_buf ^ 1u), lane);
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * (cur_buf ^ 1u), c, lane);
-        }
-        have_x = true;
-      }
       if (grp >= 0) {
         if (a.prep) {
           const unsigned char* src = a.prep + (size_t)grp * a.prep_stride;
@@ -1062,21 +1107,16 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
     if (grp < 0) continue;
     const uint32_t slot0 = bt * 128u + wave * 32u;
     const uint32_t nrows = slot0 < a.n_slots ? min(32u, a.n_slots - slot0) : 0u;
-    // The tile's x rows (all <= 4 chunks of 32 columns) were requested while the PREVIOUS tile ran its later layers; only
-    // a workgroup's first live tile pays the latency here.
-    if (have_x) {
-      cur_buf ^= 1u;
-    } else {
-      tile_rows_publish(rows_all + 32u * cur_buf, a.row_index, slot0, a.n_slots, lane);
-      if constexpr (XS) {
-        xs_issue<PREC>(xt, a.xs, ns0, rows_all + 32u * cur_buf, lane);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, rows_all + 32u * cur_buf, c, lane);
-      }
-    }
+    // the tile's x rows (all <= 4 chunks of 32 columns) were requested while the PREVIOUS live tile ran its later layers
+    cur_buf ^= 1u;
     const int* rows_lds = rows_all + 32u * cur_buf;
+    if (lane < 32u) {                                // the rows' byte offsets in y (a padding slot: out of range)
+      const int row = rows_lds[lane];
+      const bool ok = (uint32_t)row < y_row_limit;
+      bad_rows |= (row >= 0 && !ok) ? 1u : 0u;
+      yoff[lane] = buf_row_off(row, a.ldy, ok);
+    }
+    wave_lds_fence();
     int kc;                                        // cumulative exponent: accumulators hold 2^kc * (true value)
     f32x16 a0[NT];
 #pragma unroll
@@ -1112,19 +1152,9 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
     }
     }
     // request the next live tile's rows now: they arrive while this tile runs its later layers
-    have_x = false;
     for (uint32_t nbt = bt + 1; nbt < bt1; ++nbt) {
       if ((a.tile_group ? a.tile_group[nbt] : 0) < 0) continue;
-      int* nrows_lds = rows_all + 32u * (cur_buf ^ 1u);
-      tile_rows_publish(nrows_lds, a.row_index, nbt * 128u + wave * 32u, a.n_slots, lane);
-      if constexpr (XS) {
-        xs_issue<PREC>(xt, a.xs, ns0, nrows_lds, lane);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if ((uint32_t)c < n_chunks) x_chunk_issue(xc[c], a.x, a.ldx, a.seg, n_in, nrows_lds, c, lane);
-      }
-      have_x = true;
+      request(nbt, cur_buf ^ 1u);
       break;
     }
 #pragma unroll
@@ -1137,7 +1167,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
         f32x16 hv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = ldexpf(a0[t][r], -kc);
-        store_tile_staged(a.h_save + (size_t)slot0 * NN + t * 32, NN, nrows, hv, stg, lane);
+        store_tile_staged_buf(r_hs, slot0 * (uint32_t)(NN * 4), NN, t * 32, nrows, hv, stg, lane);
       }
     }
     f32x16 a1[NT];
@@ -1155,7 +1185,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
           f32x16 hv;
 #pragma unroll
           for (int r = 0; r < 16; ++r) hv[r] = ldexpf(a1[t][r], -kc);
-          store_tile_staged(a.h_save + (size_t)(a.n_slots + slot0) * NN + t * 32, NN, nrows, hv, stg, lane);
+          store_tile_staged_buf(r_hs, (a.n_slots + slot0) * (uint32_t)(NN * 4), NN, t * 32, nrows, hv, stg, lane);
         }
       }
     }
@@ -1170,16 +1200,17 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, uint32_t vb, unsi
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = ldexpf(o[t][r], -kc);
-      store_tile_rows_scalar(a.y, a.ldy, 0, 32u, rows_lds, o[0], stg, lane);
-      store_tile_rows_scalar(a.y, a.ldy, 32, n_out - 32u, rows_lds, o[1], stg, lane);
+      store_tile_rows_scalar_buf(r_y, yoff, 0, 32u, o[0], stg, lane);
+      store_tile_rows_scalar_buf(r_y, yoff, 32, n_out - 32u, o[1], stg, lane);
     } else {
       f32x16 o[1];
       layer_chain<PREC, 1, NT>(hl, fo, img_out, lane, o);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[0][r] = ldexpf(o[0][r], -kc);
-      store_tile_rows_scalar(a.y, a.ldy, 0, n_out, rows_lds, o[0], stg, lane);
+      store_tile_rows_scalar_buf(r_y, yoff, 0, n_out, o[0], stg, lane);
     }
   }
+  if (bad_rows != 0u && a.err) atomicOr(a.err, DNS_DEVERR_MLP_RANGE);
 }
 
 
