@@ -767,6 +767,35 @@ __device__ __forceinline__ float wave_max(float m) {
   return m;
 }
 
+// transpose_frags in two halves, for callers that put other work between the staging tile's write and its read (the LDS round
+// trip then hides behind that work) and matrix instructions beside the read's conversions: the caller places a
+// wave_lds_fence() behind the LAST use of the staged tile (i.e. before the next transpose_write)
+__device__ __forceinline__ void transpose_write(const f32x16& a, int k_lane, float* __restrict__ stg, uint32_t lane) {
+  const uint32_t pt = lane & 31u, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * STG_LD + pt] = ldexpf(a[r], -k_lane);
+  wave_lds_fence();
+}
+struct TrRaw {
+  float4 x[4];                               // the lane's two K-steps of the transposed tile, still fp32
+};
+__device__ __forceinline__ void transpose_read(TrRaw& t, const float* __restrict__ stg, uint32_t lane) {
+  const float* src = stg + (lane & 31u) * STG_LD + 8u * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    t.x[2 * s] = *reinterpret_cast<const float4*>(src + 16 * s);
+    t.x[2 * s + 1] = *reinterpret_cast<const float4*>(src + 16 * s + 4);
+  }
+}
+__device__ __forceinline__ void transpose_split(const TrRaw& t, Frag3 (&out)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float4 x0 = t.x[2 * s], x1 = t.x[2 * s + 1];
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    out[s] = split8_bf3(v);
+  }
+}
+
 // accumulator tile (holding 2^k_lane * value, k_lane per lane) -> the two K-step fragments of the point-transposed form of
 // the TRUE values (lane = feature, elements = 8 consecutive points)
 __device__ __forceinline__ void transpose_frags(const f32x16& a, int k_lane, Frag3 (&out)[2], float* __restrict__ stg, uint32_t lane) {

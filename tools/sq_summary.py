@@ -5,6 +5,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:]
+        if os.environ.get("SQ_BY_LDS"):               # same-named instances of different translation units (64 x 2 / 32 x 1 networks)
+            k += f" [kernel id {r.get('Kernel_Id', '?')}, {r.get('VGPR_Count', '?')}+{r.get('Accum_VGPR_Count', '?')} registers]"
         if flt and flt not in r["Kernel_Name"]:
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
