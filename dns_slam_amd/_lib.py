@@ -79,7 +79,7 @@ SIGNATURES = {
     "dns_mlp_bwd_ws_floats": (C.c_uint64, [_U, _U, _U]),
     "dns_mlp_dwin": (C.c_int, [_P, _U, _P, _U, _U, _U, _U, _U, _P, _P, _U, _P, _P, _U, _U, _P]),
     "dns_mlp_prepared_floats": (C.c_uint64, [_U, _U, _U, _U]),
-    "dns_mlp_prepare": (C.c_int, [_P, _U, _U, _U, _U, _U, _U, _P, _P]),
+    "dns_mlp_prepare": (C.c_int, [_P, _U, _U, _U, _U, _U, _U, _P, _U, _P]),
     "dns_encode_fwd_split": (C.c_int, [_P, _P, _U, _U, _P, C.POINTER(DnsGridMeta), _P, _P, _U, _P, _U, _P, _U, _P, _P]),
     "dns_mlp_fwd_split": (C.c_int, [C.POINTER(DnsSplitRows), C.POINTER(DnsSplitRows), _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U,
                                     _U, _P]),

@@ -113,6 +113,6 @@ int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2
 uint32_t mlp_prepared_fwd_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl);
 uint32_t mlp_prepared_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl);
 int launch_mlp_prepare(const float* params, uint32_t param_stride, uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl,
-                       uint32_t n_sets, unsigned char* blob, hipStream_t st);
+                       uint32_t n_sets, unsigned char* blob, hipStream_t st, uint32_t n_in_w = 0);
 
 }  // namespace dns

@@ -49,8 +49,7 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   DNS_REQUIRE(!prepared || (((uintptr_t)params) % 16) == 0, "dns_mlp_fwd: prepared images must be 16-byte aligned");
   DNS_REQUIRE(!h_save || (((uintptr_t)h_save) % 16) == 0, "dns_mlp_fwd: h_save must be 16-byte aligned");
   const uint32_t n_live = live_in(flags, n_in, n_in1, x2 != nullptr);
-  DNS_REQUIRE(n_live != 0 && (n_live == n_in || !prepared), "dns_mlp_fwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in], not with "
-              "DNS_MLP_PREPARED)");
+  DNS_REQUIRE(n_live != 0, "dns_mlp_fwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in])");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_fwd: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
@@ -65,7 +64,7 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   const unsigned char* prep = prepared ? reinterpret_cast<const unsigned char*>(params) : nullptr;
   return launch_mlp_fwd_split(x, ldx, x2, ldx2, n_in1, params, n_live, n_out, n_neurons, n_hidden_layers, y, ldy, n_slots,
                               row_index, tile_group, param_stride, h_save, (flags & DNS_MLP_FP16) != 0, prep,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), nullptr, (hipStream_t)stream, n_in);
+                              mlp_prepared_bytes(n_live, n_out, n_neurons, n_hidden_layers), nullptr, (hipStream_t)stream, n_in);   // (prepared images: laid out for the LIVE width, dns_mlp_prepare)
 }
 
 extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1, const float* dy,
@@ -81,8 +80,8 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
   const uint32_t dx_from = ((uint32_t)accumulate_dx >> 24) & 0x7fu;
   DNS_REQUIRE(dx_from % 4 == 0 && dx_from < n_in, "dns_mlp_bwd: DNS_MLP_DX_FROM(%u) must be a multiple of 4 below n_in", dx_from);
   const uint32_t n_live = live_in((uint32_t)accumulate_dx, n_in, n_in1, x2 != nullptr);
-  DNS_REQUIRE(n_live != 0 && (n_live == n_in || (!(accumulate_dx & (int)DNS_MLP_PREPARED) && !h_saved)),
-              "dns_mlp_bwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in], not with DNS_MLP_PREPARED / h_saved)");
+  DNS_REQUIRE(n_live != 0 && (n_live == n_in || !h_saved),
+              "dns_mlp_bwd: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (n_in1, n_in], not with h_saved)");
   const bool dx_first = (accumulate_dx & (int)DNS_MLP_DX_FIRST) != 0;
   DNS_REQUIRE(!dx_first || x2, "dns_mlp_bwd: DNS_MLP_DX_FIRST needs a two-segment input");
   const bool prepared = (accumulate_dx & (int)DNS_MLP_PREPARED) != 0;
@@ -108,9 +107,9 @@ extern "C" int dns_mlp_bwd(const float* x, uint32_t ldx, const float* x2, uint32
                               d_x2, lddx2, d_params, ws, n_slots, row_index, tile_group, param_stride,
                               (accumulate_dx & 1) | (int)(dx_from << 8),
                               (accumulate_dx >> 1) & 1, (accumulate_dx & (int)DNS_MLP_FP16) != 0,
-                              prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_in, n_out, n_neurons, n_hidden_layers)
+                              prepared ? reinterpret_cast<const unsigned char*>(params) + mlp_prepared_fwd_bytes(n_live, n_out, n_neurons, n_hidden_layers)
                                        : nullptr,
-                              mlp_prepared_bytes(n_in, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, nullptr, st,
+                              mlp_prepared_bytes(n_live, n_out, n_neurons, n_hidden_layers), (accumulate_dx & (int)DNS_MLP_NO_DWIN) == 0, h_saved, nullptr, st,
                               n_in);
 }
 
@@ -143,17 +142,21 @@ extern "C" uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint3
 }
 
 extern "C" int dns_mlp_prepare(const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
-                               uint32_t n_sets, uint32_t param_stride, float* prepared, void* stream) {
+                               uint32_t n_sets, uint32_t param_stride, float* prepared, uint32_t flags, void* stream) {
   if (n_sets == 0) return DNS_OK;
   DNS_REQUIRE(params && prepared, "dns_mlp_prepare: NULL argument");
+  DNS_REQUIRE((flags & ~0xff0000u) == 0, "dns_mlp_prepare: unknown flags 0x%x (DNS_MLP_LIVE_IN(n) only)", flags);
+  const uint32_t n_live = live_in(flags, n_in, 0, false);
+  DNS_REQUIRE(n_live != 0, "dns_mlp_prepare: bad DNS_MLP_LIVE_IN value (a multiple of 8 in (0, n_in])");
   DNS_REQUIRE(shape_ok(n_in, n_out, n_neurons, n_hidden_layers), "dns_mlp_prepare: unsupported shape in=%u out=%u neurons=%u layers=%u",
               n_in, n_out, n_neurons, n_hidden_layers);
   DNS_REQUIRE((((uintptr_t)prepared) % 16) == 0, "dns_mlp_prepare: prepared must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int rc = ensure_ready(st, "dns_mlp_prepare");
   if (rc != DNS_OK) return rc;
-  return launch_mlp_prepare(params, param_stride, n_in, n_out, n_neurons, n_hidden_layers, n_sets,
-                            reinterpret_cast<unsigned char*>(prepared), st);
+  // the images are built (and the blob is laid out) for the LIVE width; W_in keeps its row stride n_in in `params`
+  return launch_mlp_prepare(params, param_stride, n_live, n_out, n_neurons, n_hidden_layers, n_sets,
+                            reinterpret_cast<unsigned char*>(prepared), st, n_in);
 }
 
 // ---- split-row input (include/dns_hip.h, DnsSplitRows) ---------------------------------------------------------------

@@ -290,14 +290,16 @@ uint32_t mlp_prepared_fwd_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint
 uint32_t mlp_prepared_bytes(uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl) {
   return prepared_fwd_bytes(n_in, n_out, nn, nl) + prepared_bwd_bytes(n_in, n_out, nn, nl);
 }
+// n_in: the width the images are built for (the LIVE width with DNS_MLP_LIVE_IN); n_in_w: the row stride of W_in in `params`
 int launch_mlp_prepare(const float* params, uint32_t param_stride, uint32_t n_in, uint32_t n_out, uint32_t nn, uint32_t nl,
-                       uint32_t n_sets, unsigned char* blob, hipStream_t st) {
+                       uint32_t n_sets, unsigned char* blob, hipStream_t st, uint32_t n_in_w) {
   using namespace sp;
+  if (n_in_w == 0) n_in_w = n_in;
   const uint32_t stride = mlp_prepared_bytes(n_in, n_out, nn, nl), fb = prepared_fwd_bytes(n_in, n_out, nn, nl);
-  if (nn == 32 && nl == 1) return prepare_32_1(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
-  if (nn == 32) return prepare_32_2(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
-  if (nl == 1) return prepare_64_1(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
-  return prepare_64_2(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st);
+  if (nn == 32 && nl == 1) return prepare_32_1(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st, n_in_w);
+  if (nn == 32) return prepare_32_2(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st, n_in_w);
+  if (nl == 1) return prepare_64_1(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st, n_in_w);
+  return prepare_64_2(params, param_stride, n_in, n_out, n_sets, blob, fb, stride, st, n_in_w);
 }
 
 }  // namespace dns

@@ -1298,7 +1298,7 @@ int launch_bwd_64_2(const BwdArgs& a, uint32_t blocks, bool fp16_single, hipStre
 #define DNS_DECL_PREP(nn, nl)                                                                                                  \
   uint32_t prepared_bwd_bytes_##nn##_##nl(uint32_t n_in, uint32_t n_out);                                                     \
   int prepare_##nn##_##nl(const float* params, uint32_t param_stride, uint32_t n_in, uint32_t n_out, uint32_t n_sets,         \
-                          unsigned char* blob, uint32_t fwd_bytes, uint32_t blob_stride, hipStream_t st);
+                          unsigned char* blob, uint32_t fwd_bytes, uint32_t blob_stride, hipStream_t st, uint32_t n_in_w);
 DNS_DECL_PREP(32, 1)
 DNS_DECL_PREP(32, 2)
 DNS_DECL_PREP(64, 1)

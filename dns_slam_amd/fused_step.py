@@ -186,6 +186,29 @@ class MapStep:
         self.sr = bool(split_rows) and ld % 16 == 0 and self.pe_dim % 16 == 0 and self.n_feat % 16 == 0 and not keep_hidden
         if self.sr and self.live:                      # the split-row entry points take full-width rows: keep the zero code columns
             self.n_feat, self.live = self.shp_col[0] - self.pe_dim, 0
+        # ---- prepared operand images (round 5): every MLP launch of the step copies its weight images in (dns_mlp_prepare, built
+        # once per step on the side stream under the ray branch's sampling / encoding) instead of building them per workgroup:
+        # -10..17 us per backward launch and -2..6 us per forward launch since the copy-in keeps eight requests in flight.
+        # mapper.prepared_images = False keeps the per-workgroup build; the split-row form takes fp32 weights
+        self.use_prep = bool(getattr(m, "prepared_images", os.environ.get("DNS_PREPARED_IMAGES", "1") != "0")) and not self.sr
+        self._blobs, self._prep_jobs = {}, []
+        if self.use_prep:
+            raw_lib = ops.lib._raw
+            G = int(self.p_pool.shape[0]) if self.p_pool.dim() == 2 else 1
+            live_n = (self.live >> 16) & 0xff
+            jobs = [(self.p_coarse, self.shp_c, self.shp_c[1], 1, 0, 0),            # (params, shape, n_out, n_sets, stride, live flag)
+                    (self.p_coarse, self.shp_c, 1, 1, 0, 0),                          # the lattice runs the occupancy row only
+                    (self.p_pool, self.shp_f, self.shp_f[1], G, int(self.p_pool.shape[-1]), 0),
+                    (self.p_color, self.shp_col, self.shp_col[1], 1, 0, self.live),
+                    (self.p_logit, self.shp_log, self.shp_log[1], 1, 0, self.live)]
+            for prm, shp_, n_out, n_sets, stride, lv in jobs:
+                n_in_eff = live_n if lv else shp_[0]
+                nfl = int(raw_lib.dns_mlp_prepared_floats(n_in_eff, n_out, shp_[2], shp_[3]))
+                blob = torch.empty(nfl * n_sets + 64, device=dev)
+                off = (-blob.data_ptr() // 4) % 4                      # 16-byte aligned start
+                view = blob[off:off + nfl * n_sets]
+                self._blobs[(prm.data_ptr(), n_out)] = view
+                self._prep_jobs.append((prm, shp_[0], n_out, shp_[2], shp_[3], n_sets, stride, view, lv, blob))
         self.sr_planes = 1 if self.fp16 else 2           # half-width networks read the hi plane only
         self.sr_flags = 1 if self.fp16 else 0            # DNS_SPLIT_HI_ONLY
         if self.sr:
@@ -337,6 +360,18 @@ class MapStep:
         self.steps = 0
 
     # ------------------------------------------------------------------------------------------------------------------
+    def _prepare_weights(self, st):
+        """The step's operand images from the CURRENT weights (after the last Adam step): five small launches."""
+        for prm, n_in, n_out, nn, nl, n_sets, stride, view, lv, _ in self._prep_jobs:
+            check(ops.lib.dns_mlp_prepare(ptr(prm), n_in, n_out, nn, nl, n_sets, stride, ptr(view), lv, st), "dns_mlp_prepare")
+
+    def _w(self, params, n_out):
+        """(pointer, flag) of a network's weights for an MLP launch: its prepared images, or the fp32 parameters."""
+        blob = self._blobs.get((params.data_ptr(), n_out)) if self.use_prep else None
+        if blob is None:
+            return ptr(params), 0
+        return ptr(blob), ops.MLP_PREPARED_FLAG
+
     def _lattice_branch(self, cur, st):
         """Forward and backward of the smoothness term on the side stream: its loss weight is a constant, so its backward
         needs nothing from the ray branch."""
@@ -356,8 +391,9 @@ class MapStep:
         else:
             check(lib.dns_encode_fwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
                                      grid_l, ld, None, st), "dns_encode_fwd")
-            check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
-                                  None, None, 0, ptr(self.h_l), self.fp16, st), "dns_mlp_fwd")
+            wl, wflag = self._w(self.p_coarse, 1)
+            check(lib.dns_mlp_fwd(ptr(self.bufl), ld, None, 0, 0, wl, n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
+                                  None, None, 0, ptr(self.h_l), self.fp16 | wflag, st), "dns_mlp_fwd")
         # the branch runs in MORTON order of the lattice elements (see __init__); the TV kernels want the x-major cube: two 1 MB
         # permutations (the network's occupancy out, its gradient back in)
         torch.index_select(self.occ, 0, self.lat_slot, out=self.occ_x)
@@ -373,9 +409,10 @@ class MapStep:
                                    0, self.fp16, st), "dns_mlp_dwin")
         else:
             # (the lattice points carry no pose: only the grid columns' input gradient has a consumer, the table scatter)
-            check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
+            wl, wflag = self._w(self.p_coarse, 1)
+            check(lib.dns_mlp_bwd(ptr(self.bufl), ld, None, 0, 0, ptr(self.d_occ), 1, wl, n_in, 1, nn, nl,
                                   ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0, ptr(self.h_l),
-                                  self.fp16 | (0 if self.h_l is not None else ops.MLP_DX_FROM(pe)), st), "dns_mlp_bwd")
+                                  self.fp16 | wflag | (0 if self.h_l is not None else ops.MLP_DX_FROM(pe)), st), "dns_mlp_bwd")
         d_grid_l = _V(self.d_bufl.data_ptr() + 4 * pe)
         check(lib.dns_encode_bwd(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ld, d_grid_l, ld,
                                  ptr(cur.g_table), None, None, ptr(self.ws_enc_l), self.scatter_form, self.scatter_cap, st),
@@ -461,6 +498,15 @@ class MapStep:
         on_side = self.smooth and getattr(m, "overlap_smooth", False)
         if on_side or prefetch:
             self.side.wait_stream(main)                # behind the last Adam step and the last reads of the other set's buffers
+        prep_ev = None
+        if self.use_prep:
+            if on_side or prefetch:                    # under the ray branch's sampling and encoding; the lattice branch follows it
+                with torch.cuda.stream(self.side):
+                    self._prepare_weights(_V(self.side.cuda_stream))
+                    prep_ev = torch.cuda.Event()
+                    prep_ev.record(self.side)
+            else:
+                self._prepare_weights(st)
         # (host order: the side stream's launches go out first.  Measured against "main stream's first launches first" and
         # "next set's preparation after the forward": 2.06 / 2.08 / 2.09 ms per step at cfg2 -- the lattice branch and the ~20
         # tiny preparation kernels overlap best with the ray branch's long FORWARD kernels, not with its backward.)
@@ -523,10 +569,13 @@ class MapStep:
                 check(lib.dns_mlp_fwd_split(rows_x, None if x2 is None else rows_f, n_in1, ptr(params), n_in, n_out, nn, nl, ptr(y),
                                             y.stride(0), n_slots, ptr(ri), ptr(tg), stride, fp16, st), "dns_mlp_fwd_split")
                 return
-            check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
+            wp, wflag = self._w(params, n_out)
+            check(lib.dns_mlp_fwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, wp, n_in, n_out,
                                   nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(hs),
-                                  fp16 | (0 if x2 is None else self.live), st), "dns_mlp_fwd")
+                                  fp16 | wflag | (0 if x2 is None else self.live), st), "dns_mlp_fwd")
 
+        if prep_ev is not None:
+            main.wait_event(prep_ev)                   # the operand images of this step (side stream)
         fwd(None, 0, self.p_coarse, self.shp_c, self.coarse, None, None, P, 0, self.h_c)
         fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
         fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1], self.h_f)
@@ -597,10 +646,11 @@ class MapStep:
                     check(lib.dns_mlp_dwin(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, n_in, nn, nl, ptr(d_p),
                                            ptr(ws), n_slots, ptr(ri), ptr(tg), stride, fp16 | live, st), "dns_mlp_dwin")
             else:
+                wp, wflag = self._w(params, n_out)
                 check(lib.dns_mlp_bwd(ptr(self.buf), ld, ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
-                                      ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
+                                      wp, n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
                                       0 if d_x2 is None else d_x2.stride(0), ptr(d_p), ptr(ws), n_slots, ptr(ri), ptr(tg),
-                                      stride, ptr(hs), acc | fp16 | live | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
+                                      stride, ptr(hs), acc | fp16 | wflag | live | (ops.MLP_NO_DWIN_FLAG if fork_dwin else 0), st), "dns_mlp_bwd")
             if fork_dwin:
                 # dW_in = dH_1^T x (memory-bound, needs only what this launch left in ws) on the side stream, beside the next
                 # network's vector-bound backward kernel
@@ -1000,7 +1050,7 @@ class TrackStep:
     def _prepare_weights(self):
         st = _V(torch.cuda.current_stream().cuda_stream)
         for (p_, shp_), w in zip(self._nets_w, self.w):
-            check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w), st), "dns_mlp_prepare")
+            check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w), 0, st), "dns_mlp_prepare")
 
     # ---- the iteration as ONE kernel + a pose kernel (csrc/track_fused.inc, ABI v11) ------------------------------------------
     def fused_supported(self):

@@ -260,8 +260,11 @@ int dns_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, u
                  uint32_t n_hidden_layers, float* d_params, const float* ws, uint32_t n_slots, const int32_t* row_index,
                  const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);
 uint64_t dns_mlp_prepared_floats(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers);
+/* (ABI v11: `flags` = DNS_MLP_LIVE_IN(n) or 0.  With a live width the images are built -- and the blob is laid out:
+ * dns_mlp_prepared_floats(n, ...) floats per weight set -- for the n-input network on the same parameter tensor; dns_mlp_fwd /
+ * dns_mlp_bwd then take DNS_MLP_PREPARED | DNS_MLP_LIVE_IN(n) together.) */
 int dns_mlp_prepare(const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
-                    uint32_t n_sets, uint32_t param_stride, float* prepared, void* stream);
+                    uint32_t n_sets, uint32_t param_stride, float* prepared, uint32_t flags, void* stream);
 int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2, uint32_t n_in1,
                 const float* params, uint32_t n_in, uint32_t n_out,
                 uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,

@@ -774,7 +774,7 @@ def test_mlp_prepared_images_are_bit_identical(n_in, n_out, nn, nl, grouped):
     nf = int(lib.dns_mlp_prepared_floats(n_in, n_out, nn, nl))
     assert nf > 0 and nf % 4 == 0
     prep = torch.empty(G, nf, device=DEV)
-    check(lib.dns_mlp_prepare(ptr(params), n_in, n_out, nn, nl, G, count, ptr(prep), stream_ptr()), "dns_mlp_prepare")
+    check(lib.dns_mlp_prepare(ptr(params), n_in, n_out, nn, nl, G, count, ptr(prep), 0, stream_ptr()), "dns_mlp_prepare")
     stride = count if grouped else 0
     ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(n_slots, nn, nl)), device=DEV)
     outs = []

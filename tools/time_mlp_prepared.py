@@ -13,7 +13,7 @@ for n_in, n_out, nn, nl in ((80, 33, 64, 2), (112, 8, 64, 2)):
     y = torch.empty(P, n_out, device="cuda"); dx = torch.empty(P, n_in, device="cuda"); dp = torch.zeros(count, device="cuda")
     ws = torch.empty(int(lib.dns_mlp_bwd_ws_floats(P, nn, nl)), device="cuda")
     prep = torch.empty(int(lib.dns_mlp_prepared_floats(n_in, n_out, nn, nl)), device="cuda")
-    check(lib.dns_mlp_prepare(ptr(params), n_in, n_out, nn, nl, 1, 0, ptr(prep), stream_ptr()))
+    check(lib.dns_mlp_prepare(ptr(params), n_in, n_out, nn, nl, 1, 0, ptr(prep), 0, stream_ptr()))
     for name, w, flag in (("fp32 weights", params, 0), ("prepared", prep, ops.MLP_PREPARED_FLAG)):
         def fwd(): check(lib.dns_mlp_fwd(ptr(x), n_in, None, 0, 0, ptr(w), n_in, n_out, nn, nl, ptr(y), n_out, P, None, None, 0, None, flag, stream_ptr()))
         def bwd(): check(lib.dns_mlp_bwd(ptr(x), n_in, None, 0, 0, ptr(dy), n_out, ptr(w), n_in, n_out, nn, nl, ptr(dx), n_in, None, 0, ptr(dp), ptr(ws), P, None, None, 0, None, flag, stream_ptr()))
