@@ -47,8 +47,9 @@ static int track_shape(const char* who, const DnsTrackFused* a, uint32_t& ld, ui
               "%s: encoding outside the fused form (n_bins %u, levels %u)", who, a->n_bins, L);
   DNS_REQUIRE(ld > 64u && ld <= 96u && (ld % 8u) == 0, "%s: the coarse network's input width %u is outside (64, 96]", who, ld);
   DNS_REQUIRE(a->hidden >= 32u && a->hidden <= 63u && (a->hidden % 4u) == 0, "%s: latent width %u outside [32, 63]", who, a->hidden);
-  DNS_REQUIRE((a->n_feat % 4u) == 0 && a->n_feat >= a->hidden && pe + a->n_feat > 96u && pe + a->n_feat <= 128u && ((pe + a->n_feat) % 8u) == 0,
-              "%s: colour / logit input width %u outside (96, 128]", who, pe + a->n_feat);
+  DNS_REQUIRE((a->n_feat % 4u) == 0 && a->n_feat >= a->hidden && pe + a->n_feat > 64u && pe + a->n_feat <= 128u && ((pe + a->n_feat) % 8u) == 0,
+              "%s: colour / logit input width %u outside (64, 128]", who, pe + a->n_feat);
+  DNS_REQUIRE(a->code || a->n_feat == a->hidden || a->n_feat > a->hidden, "%s: n_feat", who);
   DNS_REQUIRE(a->n_class >= 1 && a->n_class <= 64, "%s: n_class %u outside [1, 64]", who, a->n_class);
   DNS_REQUIRE(!a->code || (a->code_dim % 4u == 0 && a->hidden + a->code_dim <= a->n_feat && (((uintptr_t)a->code) & 15u) == 0),
               "%s: code width %u does not fit the feature block / is not 16-byte aligned", who, a->code_dim);

@@ -1051,6 +1051,16 @@ class TrackStep:
         st = _V(torch.cuda.current_stream().cuda_stream)
         for (p_, shp_), w in zip(self._nets_w, self.w):
             check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w), 0, st), "dns_mlp_prepare")
+        # the fused kernel's colour / logit images without a 2-D code: the LIVE networks (pe + latent inputs; the zero code columns
+        # are not there at all -- no feature block is built, the latent is read out of the coarse network's rows)
+        if self.features is None and not self.stem:
+            live = ops.MLP_LIVE_IN(self.pe_dim + self.hid)
+            if getattr(self, "w_live", None) is None:
+                f = lambda n: torch.empty(n, device=self.dev, dtype=torch.float32)
+                self.w_live = [f(int(ops.lib._raw.dns_mlp_prepared_floats(self.pe_dim + self.hid, shp_[1], shp_[2], shp_[3])))
+                               for shp_ in (self.shp_col, self.shp_log)]
+            for (p_, shp_), w in zip(((self.p_color, self.shp_col), (self.p_logit, self.shp_log)), self.w_live):
+                check(ops.lib.dns_mlp_prepare(ptr(p_), shp_[0], shp_[1], shp_[2], shp_[3], 1, 0, ptr(w), live, st), "dns_mlp_prepare")
 
     # ---- the iteration as ONE kernel + a pose kernel (csrc/track_fused.inc, ABI v11) ------------------------------------------
     def fused_supported(self):
@@ -1090,6 +1100,10 @@ class TrackStep:
             a.code, a.code_dim = self.features.data_ptr(), self.features.shape[-1]
         else:
             a.code, a.code_dim = 0, 0
+            if getattr(self, "w_live", None) is not None and (self.pe_dim + self.hid) % 8 == 0 and self.pe_dim + self.hid > 64:
+                # no code: the live networks (no feature block, narrower colour / logit networks)
+                a.n_feat = self.hid
+                a.w_color, a.w_logit = self.w_live[0].data_ptr(), self.w_live[1].data_ptr()
         a.lambda_p, a.lambda_d, a.lambda_l = float(t.lambda_p), float(t.lambda_d), float(t.lambda_l)
         lr = float(t.cam_lr)
         a.lr_quat, a.lr_trans = lr, (lr * 0.2 if t.seperate_LR else lr)

@@ -416,6 +416,9 @@ int dns_adam_step(const DnsAdamTensor* tensors, uint32_t n_tensors, float beta1,
  *   1 - beta1^t, 1 - beta2^t): zero them per frame.  best_loss [1] (+inf per frame), best_cam [7].
  *   w_coarse / w_color / w_logit: dns_mlp_prepare images of the three networks (inputs 3 n_bins + 2 n_levels -> hidden + 1;
  *   3 n_bins + n_feat -> 3 and -> n_class).  code [n_rays * S, code_dim] or NULL: the 2-D feature code of every sample.
+ *   n_feat = hidden + code_dim; WITHOUT a code either n_feat = the networks' full second-segment width (zero code columns, images
+ *   of the full networks) or n_feat = hidden with images prepared with DNS_MLP_LIVE_IN(3 n_bins + hidden): no feature block is
+ *   built then, the colour / logit networks read the latent out of the coarse network's output rows.
  *   ws: dns_track_fused_ws_floats(a) floats, 256-byte aligned (rows the workgroups hand from phase to phase).
  *   out [8]: loss terms p, d, l, total, n_valid of THIS iteration (before the update); g_quat [4], g_trans [3]: its gradient.
  * Supported: S <= 64, networks 64 x 2 or 32 x 1, 64 < 3 n_bins + 2 n_levels <= 96, 96 < 3 n_bins + n_feat <= 128; otherwise
