@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNS_HIP_LIB") or os.path.join(_HERE, "libdns_hip.so")   # override: A/B of two builds
 DNS_MAX_LEVELS = 32
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class DnsGridMeta(C.Structure):
@@ -85,6 +85,8 @@ SIGNATURES = {
                                     _U, _P]),
     "dns_mlp_bwd_split": (C.c_int, [C.POINTER(DnsSplitRows), C.POINTER(DnsSplitRows), _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U,
                                     _P, _P, _U, _P, _P, _U, _I, _P]),
+    "dns_mlp_fwd_half": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _P, _P, _U, _U, _P]),
+    "dns_mlp_bwd_half": (C.c_int, [_P, _U, _P, _U, _U, _P, _U, _P, _U, _U, _U, _U, _P, _U, _P, _U, _P, _U, _P, _P, _U, _I, C.c_float, _P]),
     "dns_feature_block_split": (C.c_int, [_P, _U, _U, _P, _U, _U, _U, _P, _P, _U, _U, _P, _U, _P, _U, _P, _U, _P, _P]),
     "dns_loss_sums": (C.c_int, [_P, _U, _U, _U, _U, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dns_loss_rays": (C.c_int, [_P, _U, _U, _U, _U, _I] + [_P] * 19),

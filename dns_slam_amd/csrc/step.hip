@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void feature_block_split_kernel(const float* _
     const float sum = ((f0 + f1) + (f2 + f3)) + ((cv.x + cv.y) + (cv.z + cv.w));
     if (!(fabsf(sum) < INFINITY)) m = INFINITY;            // fmaxf drops a NaN: a non-finite row keeps exponent 0 and propagates
     for (uint32_t o = 1; o < qn; o <<= 1) m = fmaxf(m, __shfl_xor(m, (int)o));
-    const int e = sr::scale_exp(m);
+    const int e = (hi_only & 2u) ? 0 : sr::scale_exp(m);      // (DNS_SPLIT_PLAIN: half rows -- unscaled f16, no exponent)
     const float sc = ldexpf(1.0f, e);
     if (feat) {
       float* o = feat + (size_t)p * ld_feat;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void feature_block_split_kernel(const float* _
       if (!hi_only) *reinterpret_cast<uint2*>(row + F + hidden + 4u * q) = l;
     }
     if (q == 0) {
-      xexp[p] = e;
+      if (!(hi_only & 2u)) xexp[p] = e;
       if (raw) raw[(size_t)p * 4u + 3u] = occ;
     }
   }
@@ -281,11 +281,12 @@ extern "C" int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint
                                        uint32_t flags, float* raw, void* stream) {
   const uint64_t P = (uint64_t)N * S;
   if (P == 0) return DNS_OK;
-  DNS_REQUIRE(fine && (xs_out ? xexp != nullptr : feat != nullptr), "dns_feature_block_split: NULL argument");
-  DNS_REQUIRE((flags & ~DNS_SPLIT_HI_ONLY) == 0, "dns_feature_block_split: unknown flags 0x%x", flags);
+  const bool plain = (flags & DNS_SPLIT_PLAIN) != 0;       // half rows: unscaled f16, no exponents, hi plane only
+  DNS_REQUIRE(fine && (xs_out ? (xexp != nullptr || plain) : feat != nullptr), "dns_feature_block_split: NULL argument");
+  DNS_REQUIRE((flags & ~(DNS_SPLIT_HI_ONLY | DNS_SPLIT_PLAIN)) == 0, "dns_feature_block_split: unknown flags 0x%x", flags);
   DNS_REQUIRE(P < (1ull << 31), "dns_feature_block_split: too many points");
   const uint32_t F = hidden + C;
-  const bool hi_only = (flags & DNS_SPLIT_HI_ONLY) != 0;
+  const bool hi_only = (flags & DNS_SPLIT_HI_ONLY) != 0 || plain;
   DNS_REQUIRE(hidden % 4 == 0 && C % 4 == 0 && hidden >= 4 && ld_fine >= hidden + 1 && F % 8 == 0,
               "dns_feature_block_split: hidden %u / C %u / ld_fine %u", hidden, C, ld_fine);
   DNS_REQUIRE(!feat || (ld_feat % 4 == 0 && ld_feat >= F && ((uintptr_t)feat & 15) == 0), "dns_feature_block_split: feat alignment / ld_feat");
@@ -300,7 +301,7 @@ extern "C" int dns_feature_block_split(const float* fine, uint32_t ld_fine, uint
   hipStream_t st = (hipStream_t)stream;
   DNS_LAUNCH(feature_block_split_kernel, dim3(grid_for(P * qn, 16384)), dim3(256), 0, st, fine, ld_fine, hidden, code, C, n_ref,
              pts_per_frame, z, gt_depth, (uint32_t)P, S, feat, ld_feat, reinterpret_cast<_Float16*>(xs_out), ldxs, xexp,
-             hi_only ? 1u : 0u, raw, qn);
+             (hi_only ? 1u : 0u) | (plain ? 2u : 0u), raw, qn);
   return check_launch("dns_feature_block_split");
 }
 

@@ -371,6 +371,62 @@ def mlp(x: torch.Tensor, params: torch.Tensor, n_in: int, n_out: int, n_neurons:
     return _MlpFn.apply(x, params, (n_in, n_out, n_neurons, n_hidden_layers, bool(fp16)), None, None, 0)
 
 
+# ---- half rows (include/dns_hip.h, ABI v12): tcnn's own arithmetic -- f16 activations and weight operands, fp32 accumulation, a
+# static loss scale.  Thin, non-autograd wrappers (fused_step.MapStep drives the entry points directly; tests use these).
+HALF_LOSS_SCALE = 128.0                       # tcnn's default loss_scale for half-precision networks
+SPLIT_PLAIN = 2                               # DNS_SPLIT_PLAIN: dns_encode_fwd_split / dns_feature_block_split write plain f16 rows
+
+
+def _cuda_rows(*tensors):
+    """CUDA tensors with unit column stride (row-strided views are what these entry points take: ld arguments)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise ValueError("dns_slam_amd ops run on the GPU only (got a non-CUDA tensor); there is no CPU fallback")
+        if t.dim() == 2 and t.stride(1) != 1:
+            raise ValueError("dns_slam_amd ops need unit column stride")
+
+
+def _half_rows_ok(t):
+    return t is None or (t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1)
+
+
+def mlp_fwd_half(x, params, n_in, n_out, n_neurons, n_hidden_layers, x2=None, row_index=None, tile_group=None, n_slots=None,
+                 param_stride=0, live_in=0, out=None):
+    """y = MLP(x | x2) on f16 rows (dns_mlp_fwd_half): x [rows, >= n_in1] / x2 [rows, >= n_in - n_in1] float16, params fp32 (a pool
+    [G, stride] with tile_group), y fp32 [rows, n_out].  ``live_in``: DNS_MLP_LIVE_IN width (0 = n_in)."""
+    _cuda_rows(x, x2, out)
+    require_cuda(params)
+    if not (_half_rows_ok(x) and _half_rows_ok(x2)):
+        raise ValueError("mlp_fwd_half: x / x2 must be 2-D float16 CUDA tensors with unit column stride")
+    rows = x.shape[0]
+    n_slots = rows if n_slots is None else n_slots
+    y = out if out is not None else torch.zeros(rows, n_out, device=x.device, dtype=torch.float32)
+    n_in1 = x.shape[1] if x2 is not None else 0
+    check(lib.dns_mlp_fwd_half(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params), n_in, n_out,
+                               n_neurons, n_hidden_layers, ptr(y), y.stride(0), n_slots, ptr(row_index), ptr(tile_group), param_stride,
+                               MLP_LIVE_IN(live_in) if live_in else 0, stream_ptr()), "dns_mlp_fwd_half")
+    return y
+
+
+def mlp_bwd_half(x, dy, params, n_in, n_out, n_neurons, n_hidden_layers, x2=None, d_x=None, d_x2=None, d_params=None, row_index=None,
+                 tile_group=None, n_slots=None, param_stride=0, accumulate=0, loss_scale=HALF_LOSS_SCALE):
+    """Input and weight gradients of the same network (dns_mlp_bwd_half; ONE kernel, dW_in included).  dy fp32 [rows, n_out];
+    d_x / d_x2 fp32 (None = skip), d_params fp32 like params (+=; None = skip).  ``accumulate``: the entry point's accumulate_dx
+    word (bits 0 / 1, MLP_DX_FIRST_FLAG, MLP_LIVE_IN(n), MLP_DX_FROM(c))."""
+    _cuda_rows(x, x2, dy, d_x, d_x2)
+    require_cuda(params, d_params)
+    if not (_half_rows_ok(x) and _half_rows_ok(x2)):
+        raise ValueError("mlp_bwd_half: x / x2 must be 2-D float16 CUDA tensors with unit column stride")
+    n_slots = x.shape[0] if n_slots is None else n_slots
+    n_in1 = x.shape[1] if x2 is not None else 0
+    check(lib.dns_mlp_bwd_half(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(dy), dy.stride(0),
+                               ptr(params), n_in, n_out, n_neurons, n_hidden_layers, ptr(d_x), 0 if d_x is None else d_x.stride(0),
+                               ptr(d_x2), 0 if d_x2 is None else d_x2.stride(0), ptr(d_params), n_slots, ptr(row_index),
+                               ptr(tile_group), param_stride, int(accumulate), float(loss_scale), stream_ptr()), "dns_mlp_bwd_half")
+
+
 def group_slots(slot_of_point: torch.Tensor, n_groups: int, min_count: int = 2):
     """Device-side (sync-free) layout for the grouped MLP: points counting-sorted by weight-set id into 128-slot tiles
     (dns_group_slots).  ``slot_of_point`` [P] int64 in [0, n_groups) (negative = no network).  Returns (row_index

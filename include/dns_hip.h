@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DNS_ABI_VERSION 11
+#define DNS_ABI_VERSION 12
 #define DNS_MAX_LEVELS 32
 
 #define DNS_OK 0
@@ -159,6 +159,10 @@ typedef struct DnsSplitRows {
   uint32_t lo_off;
 } DnsSplitRows;
 #define DNS_SPLIT_HI_ONLY 1u
+/* DNS_SPLIT_PLAIN (ABI v12): HALF ROWS -- the row is written as K plain f16 values, no scale, no exponent (xexp may be NULL), no lo
+ * plane: tcnn's own activation format (its networks round their fp32 inputs to half precision, models/decoder.py:93-94,123-125),
+ * what dns_mlp_fwd_half / dns_mlp_bwd_half read.  160 bytes per [OneBlob | grid] row instead of 320. */
+#define DNS_SPLIT_PLAIN 2u
 /* dns_encode_fwd with the (OneBlob | grid) row written in the split-row format: xs_out [P, ldxs] halfs (ldxs >= 2 K, or >= K
  * with DNS_SPLIT_HI_ONLY; K = 3 n_bins + 2 n_levels, both parts multiples of 8), xexp [P]; f32_out (NULL = skip) [P, ld32]
  * additionally receives the fp32 row (the streaming dW_in kernel dns_mlp_dwin reads fp32 rows).  x_out, dy_dx, bound as in
@@ -304,6 +308,27 @@ int dns_mlp_bwd_split(const DnsSplitRows* x, const DnsSplitRows* x2, uint32_t n_
                       float* d_x, uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params, float* ws, uint32_t n_slots,
                       const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, int accumulate_dx,
                       void* stream);
+
+/* ---- the same network in tcnn's OWN arithmetic: HALF ROWS (ABI v12) -------------------------------------------------------
+ * Replaces tcnn.Network{CutlassMLP} as the reference runs it (models/decoder.py:58-64,84-90,101-116 construct half-precision
+ * networks; :94 `.float()`s their output): f16 activations, f16 weight operands, fp32 accumulation in v_mfma_f32_32x32x16_f16, a
+ * STATIC loss scale on the gradients (tcnn's default: 128).  BASELINE configs[4].  No row maxima, no per-point exponents, no hi / lo
+ * parts: x / x2 are plain f16 rows (DNS_SPLIT_PLAIN: dns_encode_fwd_split, dns_feature_block_split), [rows, ldx] halfs, 16-byte
+ * aligned, ldx % 8 == 0; n_in (the live width) % 16 == 0, n_in1 % 8 == 0; params / d_params: the fp32 master weights in the layout
+ * of dns_mlp_fwd (rounded to f16 when a workgroup builds its LDS images -- ONE image per matrix, read row-wise for W and with
+ * ds_read_b64_tr_b16 for W^T).  y, dy, d_x, d_x2 stay fp32 rows (the compositing / loss / encoder-backward kernels' format).
+ * row_index / tile_group / param_stride as in dns_mlp_fwd.  flags: DNS_MLP_LIVE_IN(n) (n % 16 == 0) or 0.
+ * dns_mlp_bwd_half: ONE kernel produces d_x (/ d_x2) and ALL weight gradients, dW_in included (no workspace, no dns_mlp_dwin);
+ * hidden activations are recomputed.  dY is multiplied by loss_scale before it is rounded to f16, every hidden gradient is f16
+ * at that scale, d_x and d_params receive 1 / loss_scale times the fp32 sums.  accumulate_dx: bits 0 / 1 (d_x / d_x2 +=),
+ * DNS_MLP_DX_FIRST, DNS_MLP_LIVE_IN(n), DNS_MLP_DX_FROM(c) as in dns_mlp_bwd. */
+int dns_mlp_fwd_half(const void* x, uint32_t ldx, const void* x2, uint32_t ldx2, uint32_t n_in1, const float* params, uint32_t n_in,
+                     uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* y, uint32_t ldy, uint32_t n_slots,
+                     const int32_t* row_index, const int32_t* tile_group, uint32_t param_stride, uint32_t flags, void* stream);
+int dns_mlp_bwd_half(const void* x, uint32_t ldx, const void* x2, uint32_t ldx2, uint32_t n_in1, const float* dy, uint32_t lddy,
+                     const float* params, uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers, float* d_x,
+                     uint32_t lddx, float* d_x2, uint32_t lddx2, float* d_params, uint32_t n_slots, const int32_t* row_index,
+                     const int32_t* tile_group, uint32_t param_stride, int accumulate_dx, float loss_scale, void* stream);
 
 /* ---- occupancy compositing (raw2nerf_color, utils/common.py:506-537, + the logit composite of
  * slams/mapping.py:633 / slams/tracking.py:212) ----------------------------------------------
