@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
   const rsrc_t r_y = buf_make(a.y);
   const uint32_t y_row_limit = BUF_LIMIT / (4u * max(a.ldy, 1u));
   uint32_t bad_rows = 0;
+  LaneAddr A = lane_addr(lane, L::it(n_in), NN / 32u, 0u);          // (only the weight-image parts are used here)
   uint4 xf[8];                                   // the tile's B fragments of the first layer (n_in <= 128: at most 8 K-steps)
   uint32_t cur_buf = 1;
   int cur_group = -2;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
     }
     if (grp < 0) continue;
     cur_buf ^= 1u;
+    lane_addr_pin(A);
     const int* rows_lds = rows_all + 32u * cur_buf;
     if (lane < 32u) {                                // the rows' byte offsets in y (a padding slot: out of range)
       const int row = rows_lds[lane];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
     for (int s = 0; s < 8; ++s) {
       if ((uint32_t)s < ns0) {                       // uniform
 #pragma unroll
-        for (int t = 0; t < NT; ++t) h1[t] = mma(w_row_frag<K_NAT>(lds, w_in, t, s, lane), as_half8(xf[s]), h1[t]);
+        for (int t = 0; t < NT; ++t) h1[t] = mma(w_row_frag<K_NAT>(lds, A, w_in, t, s), as_half8(xf[s]), h1[t]);
       }
     }
     // the next live tile's rows: requested now, they arrive while this tile runs its later layers
@@ -109,10 +111,8 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
     half8 h1p[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h1[t][r] = fmaxf(h1[t][r], 0.f);
-      h1p[t][0] = pack_half<0>(h1[t]);
-      h1p[t][1] = pack_half<1>(h1[t]);
+      h1p[t][0] = relu8(pack_half<0>(h1[t]));
+      h1p[t][1] = relu8(pack_half<1>(h1[t]));
     }
     half8 h2p[NT][2];
     if constexpr (NL == 2) {
@@ -124,13 +124,11 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
 #pragma unroll
         for (int hf_ = 0; hf_ < 2; ++hf_)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) h2[t] = mma(w_row_frag<K_CHAIN>(lds, w_h, t, 2 * tk + hf_, lane), h1p[tk][hf_], h2[t]);
+          for (int t = 0; t < NT; ++t) h2[t] = mma(w_row_frag<K_CHAIN>(lds, A, w_h, t, 2 * tk + hf_), h1p[tk][hf_], h2[t]);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h2[t][r] = fmaxf(h2[t][r], 0.f);
-        h2p[t][0] = pack_half<0>(h2[t]);
-        h2p[t][1] = pack_half<1>(h2[t]);
+        h2p[t][0] = relu8(pack_half<0>(h2[t]));
+        h2p[t][1] = relu8(pack_half<1>(h2[t]));
       }
     }
     half8(&hlp)[NT][2] = (NL == 2) ? h2p : h1p;
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
 #pragma unroll
       for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
-        for (int hf_ = 0; hf_ < 2; ++hf_) o = mma(w_row_frag<K_CHAIN>(lds, w_out, m, 2 * tk + hf_, lane), hlp[tk][hf_], o);
+        for (int hf_ = 0; hf_ < 2; ++hf_) o = mma(w_row_frag<K_CHAIN>(lds, A, w_out, m, 2 * tk + hf_), hlp[tk][hf_], o);
       return o;
     };
     sp::store_tile_rows_scalar_buf(r_y, yoff, 0u, min(32u, n_out), out_tile(0u), stg, lane);

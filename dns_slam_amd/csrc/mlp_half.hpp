@@ -40,12 +40,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 // phase boundary: nothing is scheduled across it (with 512 registers to fill hipcc otherwise hoists the next phases' loads and
 // fragment reads over the current one and spills the weight-gradient accumulators it was given the room for)
-// `lane` passes through an empty asm: every LDS address is a function of the lane index and constant over the tile loop, so hipcc
-// otherwise computes ALL of a tile's ~600 addresses once, in front of the loop, and keeps them in registers across it (measured:
-// 327 vector registers of working set beside 224 accumulators, 71 spilled); behind the asm the addresses of a phase are formed
-// in that phase and die with it.
-__device__ __forceinline__ void phase_fence(uint32_t& lane) {
-  asm volatile("" : "+v"(lane) : : "memory");
+__device__ __forceinline__ void phase_fence() {
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -79,67 +75,124 @@ __device__ __forceinline__ f32x16 mma(const half8& a, const half8& b, f32x16 acc
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
 
-// registers 8 HALF .. 8 HALF + 7 of an accumulator tile, times f, as a K-step operand (CHAIN order: element j = register 8 HALF + j)
+// registers 8 HALF .. 8 HALF + 7 of an accumulator tile as a K-step operand (CHAIN order: element j = register 8 HALF + j)
 template <int HALF>
-__device__ __forceinline__ half8 pack_half(const f32x16& a, float f = 1.0f) {
+__device__ __forceinline__ half8 pack_half(const f32x16& a) {
   half8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (_Float16)(a[8 * HALF + j] * f);
+  for (int j = 0; j < 8; ++j) r[j] = (_Float16)a[8 * HALF + j];
   return r;
 }
 
-// ReLU' of a K-step operand of ACTIVATIONS (f16, >= +0 after the ReLU: an accumulator that starts at +0 never sums to -0) applied
-// to the matching K-step operand of gradients: a half passes where the activation's bits are non-zero.  Three packed
-// instructions per two values (v_pk_min_u16, v_pk_mul_lo_u16 / v_pk_sub_u16, v_and_b32) on operands that exist anyway -- the
-// fp32 compare-and-select needs the fp32 activations alive until the gradient arrives (64 registers at 64 x 2).
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// ---- packed 16-bit helpers (VOP3P: one instruction per two values) -------------------------------------------------------
+// ReLU on packed f16 as SIGNED 16-bit integers: a negative float (sign bit set, -0 included) is a negative integer, a
+// non-negative one keeps its bits -- max(x, 0) is exactly relu, and f16(relu(v)) == relu(f16(v)) (rounding keeps the sign).
+__device__ __forceinline__ uint32_t pk_relu(uint32_t x) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+// ReLU' mask of two ACTIVATIONS (relu-ed f16: bits >= 0 as signed integers): 0xffff per half whose activation is > 0
+__device__ __forceinline__ uint32_t pk_pos_mask(uint32_t act) {
+  uint32_t n, m;
+  asm("v_pk_sub_i16 %0, 0, %1" : "=v"(n) : "v"(act));          // -bits: negative exactly where the activation is non-zero
+  // sign fill (op_sel_hi [0, 1]: BOTH halves take their shift count from the low half of the inline constant -- by default the
+  // high half would read the constant's upper 16 bits, i.e. shift by 0)
+  asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(n));
+  return m;
+}
+__device__ __forceinline__ half8 relu8(const half8& v) {
+  const uint4 u = as_uint4(v);
+  return as_half8(make_uint4(pk_relu(u.x), pk_relu(u.y), pk_relu(u.z), pk_relu(u.w)));
+}
+// gradient operand (.) relu'(activation operand): 3 packed instructions per two values on operands that exist anyway -- the fp32
+// compare-and-select needs the fp32 activations alive until the gradient arrives (64 registers at 64 x 2)
 __device__ __forceinline__ half8 relu_mask(const half8& grad, const half8& act) {
-  const uint4 g = *reinterpret_cast<const uint4*>(&grad), h = *reinterpret_cast<const uint4*>(&act);
-  const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, hw[4] = {h.x, h.y, h.z, h.w};
-  uint32_t o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u16x2 one = {1, 1}, zero = {0, 0};
-    const u16x2 hv = *reinterpret_cast<const u16x2*>(&hw[i]);
-    const u16x2 m = zero - __builtin_elementwise_min(hv, one);       // 0 or 0xffff per half
-    o[i] = gw[i] & *reinterpret_cast<const uint32_t*>(&m);
-  }
-  const uint4 r = make_uint4(o[0], o[1], o[2], o[3]);
-  return *reinterpret_cast<const half8*>(&r);
+  const uint4 g = as_uint4(grad), h = as_uint4(act);
+  return as_half8(make_uint4(g.x & pk_pos_mask(h.x), g.y & pk_pos_mask(h.y), g.z & pk_pos_mask(h.z), g.w & pk_pos_mask(h.w)));
 }
 
-// ---- weight images ------------------------------------------------------------------------------------------------------
-// One f16 image per matrix M [R x C]: [R_pad][C_pad] in 8-row x 32-column subtiles of 512 B, the 16-byte chunk ch of a row
-// XOR-ed with (row >> 2) & 3 inside its subtile:
-//   off(row, ch) = ((row >> 3) (C_pad / 32) + (ch >> 2)) 512 + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3))
+// ---- LDS images and the lane's part of their addresses -------------------------------------------------------------------
+// Weight image of M [R x C], f16: [R_pad][C_pad] in 8-row x 32-column subtiles of 512 B, the 16-byte chunk ch of a row XOR-ed
+// with (row >> 2) & 3 inside its subtile:
+//   w_off(row, ch) = ((row >> 3) (C_pad / 32) + (ch >> 2)) 512 + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3))
+// Tile T[32 rows][32 cols] f16 (wave-private, 2 KB): 64-byte rows, chunk ch of a row at t_off = 64 row + 16 (ch ^ ((row >> 2) & 3)).
+// K orders of an operand fragment: NAT k = 16 s + 8 h + j;  CHAIN k = 16 s + 8 (j >> 2) + 4 h + (j & 3) (an accumulator's registers).
+//
+// Every address below is  (a function of the LANE)  +  (a compile-time constant of the fragment: tile, K-step, image).  The lane
+// parts -- 19 values -- are formed ONCE per kernel (LaneAddr) and the constants ride in the LDS instructions' 16-bit offset
+// fields: the first version of this file formed each address where it was used and spent 650 of a tile's 1500 vector
+// instructions on it (or, when hipcc hoisted them out of the tile loop, 327 registers).
+__device__ __forceinline__ uint32_t w_off(uint32_t row, uint32_t ch, uint32_t cs) {
+  return ((row >> 3) * cs + (ch >> 2)) * 512u + 64u * (row & 7u) + 16u * ((ch & 3u) ^ ((row >> 2) & 3u));
+}
+constexpr uint32_t TILE_BYTES = 2048u;
+__device__ __forceinline__ uint32_t t_off(uint32_t row, uint32_t ch) { return 64u * row + 16u * (ch ^ ((row >> 2) & 3u)); }
+
+struct LaneAddr {
+  uint32_t wrow_nat[2];     // A = W_in, NAT: K-step parity (cs = cs_in)
+  uint32_t wrow_chain[4];   // A = W_h / W_out, CHAIN: chunk 2 s + e of the row, (2 (s & 1) + e) = 0..3 (cs = NN / 32)
+  uint32_t wtr_nat[2];      // A = W_out^T, NAT: u = 0, 1 (cs = NN / 32)
+  uint32_t wtr_chain[2];    // A = W^T, CHAIN: u = 0, 1 (any cs)
+  uint32_t t_row[2];        // tile, row-wise operand / 16-byte row-chunk store: K-step s = 0, 1     (+ base of the wave's area)
+  uint32_t t_tr[2];         // tile, transposed operand: u = 0, 1                                         (+ base)
+  uint32_t t_st[4];         // tile, accumulator store: chunk c = 0..3                                    (+ base)
+  uint32_t x_st;            // tile, 16-byte store of the input rows' load layout                         (+ base)
+};
+// cs_in: subtiles per 8-row group of the W_in image; cs_h: of the W_h / W_out images; wave_base: byte offset of the wave's area
+__device__ __forceinline__ LaneAddr lane_addr(uint32_t lane, uint32_t cs_in, uint32_t cs_h, uint32_t wave_base) {
+  LaneAddr A;
+  const uint32_t r = lane & 31u, h = lane >> 5;
+  const uint32_t g = lane >> 4, wl = lane & 15u, gh = g & 1u, q = wl >> 2, p = wl & 3u;   // (h = g >> 1)
+  const uint32_t rx = (r >> 2) & 3u, cp = 2u * gh + (p >> 1);
+#pragma unroll
+  for (uint32_t par = 0; par < 2u; ++par) A.wrow_nat[par] = (r >> 3) * cs_in * 512u + 64u * (r & 7u) + 16u * ((2u * par + h) ^ rx);
+#pragma unroll
+  for (uint32_t c = 0; c < 4u; ++c) A.wrow_chain[c] = (r >> 3) * cs_h * 512u + 64u * (r & 7u) + 16u * (c ^ rx) + 8u * h;
+#pragma unroll
+  for (uint32_t u = 0; u < 2u; ++u) {
+    A.wtr_nat[u] = h * cs_h * 512u + 64u * q + 16u * (cp ^ (2u * h + u)) + 8u * (p & 1u);
+    A.wtr_chain[u] = 64u * (4u * h + q) + 16u * (cp ^ (2u * u + h)) + 8u * (p & 1u);
+    A.t_row[u] = wave_base + 64u * r + 16u * ((2u * u + h) ^ rx);
+    A.t_tr[u] = wave_base + 512u * h + 64u * q + 16u * (cp ^ (2u * h + u)) + 8u * (p & 1u);
+  }
+#pragma unroll
+  for (uint32_t c = 0; c < 4u; ++c) A.t_st[c] = wave_base + 64u * r + 16u * (c ^ rx) + 8u * h;
+  A.x_st = wave_base + 64u * (lane >> 2) + 16u * ((lane & 3u) ^ ((lane >> 4) & 3u));
+  return A;
+}
+// Through an empty asm at the top of every tile: the values stay where they are, but hipcc may not fold them with the constants
+// into ~150 loop-invariant sums held in registers across the loop.
+__device__ __forceinline__ void lane_addr_pin(LaneAddr& A) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(A.wrow_nat[i]), "+v"(A.wtr_nat[i]), "+v"(A.wtr_chain[i]), "+v"(A.t_row[i]), "+v"(A.t_tr[i]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(A.wrow_chain[i]), "+v"(A.t_st[i]));
+  asm volatile("" : "+v"(A.x_st));
+}
+
 struct WImg {
   uint32_t base;        // byte offset in the workgroup's LDS
   uint32_t cs;          // C_pad / 32: subtiles per 8-row group
 };
-__device__ __forceinline__ uint32_t w_off(uint32_t row, uint32_t ch, uint32_t cs) {
-  return ((row >> 3) * cs + (ch >> 2)) * 512u + 64u * (row & 7u) + 16u * ((ch & 3u) ^ ((row >> 2) & 3u));
-}
-enum KOrder { K_NAT = 0, K_CHAIN = 1 };      // NAT k = 16 s + 8 h + j;  CHAIN k = 16 s + 8 (j >> 2) + 4 h + (j & 3)
+enum KOrder { K_NAT = 0, K_CHAIN = 1 };
 
-// A = M: lane (r, h) element j = M[32 t + r][k(s, h, j)]
+// A = M: lane (r, h) element j = M[32 t + r][k(s, h, j)].  NAT: the W_in image (cs = cs_in); CHAIN: W_h / W_out (cs = cs_h)
 template <int ORDER>
-__device__ __forceinline__ half8 w_row_frag(const unsigned char* lds, const WImg& w, uint32_t t, uint32_t s, uint32_t lane) {
-  const uint32_t row = 32u * t + (lane & 31u), h = lane >> 5;
-  if (ORDER == K_NAT) return as_half8(lds_read16(lds, w.base + w_off(row, 2u * s + h, w.cs)));
-  return as_half8(lds_read8(lds, w.base + w_off(row, 2u * s, w.cs) + 8u * h), lds_read8(lds, w.base + w_off(row, 2u * s + 1u, w.cs) + 8u * h));
+__device__ __forceinline__ half8 w_row_frag(const unsigned char* lds, const LaneAddr& A, const WImg& w, uint32_t t, uint32_t s) {
+  const uint32_t c0 = w.base + (4u * t * w.cs + (s >> 1)) * 512u;
+  if (ORDER == K_NAT) return as_half8(lds_read16(lds, A.wrow_nat[s & 1u] + c0));
+  return as_half8(lds_read8(lds, A.wrow_chain[2u * (s & 1u)] + c0), lds_read8(lds, A.wrow_chain[2u * (s & 1u) + 1u] + c0));
 }
-// A = M^T: lane (r, h) element j = M[k(s, h, j)][32 t + r]; two transposing reads
+// A = M^T: lane (r, h) element j = M[k(s, h, j)][32 t + r]; two transposing reads.  NAT: the W_out image (cs = cs_h); CHAIN: any
 template <int ORDER>
-__device__ __forceinline__ half8 w_tr_frag(const unsigned char* lds, const WImg& w, uint32_t t, uint32_t s, uint32_t lane) {
-  const uint32_t g = lane >> 4, wl = lane & 15u, h = g >> 1, gh = g & 1u, q = wl >> 2, p = wl & 3u;
-  const uint32_t ch = 4u * t + 2u * gh + (p >> 1);
-  uint32_t o[2];
-#pragma unroll
-  for (uint32_t u = 0; u < 2u; ++u) {
-    const uint32_t krow = ORDER == K_NAT ? (16u * s + 8u * h + 4u * u + q) : (16u * s + 8u * u + 4u * h + q);
-    o[u] = w.base + w_off(krow, ch, w.cs) + 8u * (p & 1u);
+__device__ __forceinline__ half8 w_tr_frag(const unsigned char* lds, const LaneAddr& A, const WImg& w, uint32_t t, uint32_t s) {
+  if (ORDER == K_NAT) {
+    const uint32_t c0 = w.base + (2u * s * w.cs + t) * 512u;
+    return as_half8(lds_read_tr(lds, A.wtr_nat[0] + c0), lds_read_tr(lds, A.wtr_nat[1] + c0 + 256u));
   }
-  return as_half8(lds_read_tr(lds, o[0]), lds_read_tr(lds, o[1]));
+  const uint32_t c0 = w.base + (2u * s * w.cs + t) * 512u;
+  return as_half8(lds_read_tr(lds, A.wtr_chain[0] + c0), lds_read_tr(lds, A.wtr_chain[1] + c0 + w.cs * 512u));
 }
 
 __device__ __forceinline__ void lds_zero16(unsigned char* p, uint32_t bytes) {   // bytes % 16 == 0, whole workgroup
@@ -163,32 +216,23 @@ __device__ __forceinline__ void w_image_build(unsigned char* lds, const WImg& w,
   }
 }
 
-// ---- 32 x 32 tiles of f16 (wave-private, 2 KB) ---------------------------------------------------------------------------
-// T[row][col], 64-byte rows, chunk ch (8 elements) of a row at 64 row + 16 (ch ^ ((row >> 2) & 3)).
-constexpr uint32_t TILE_BYTES = 2048u;
-__device__ __forceinline__ uint32_t t_off(uint32_t row, uint32_t ch) { return 64u * row + 16u * (ch ^ ((row >> 2) & 3u)); }
-
+// ---- 32 x 32 tiles of f16 (wave-private, 2 KB); `slot` = byte offset from the wave's area ---------------------------------------
 // the two K-step fragments (CHAIN order) of an accumulator tile -> T[point][feature]: lane (p, h) stores registers 4g .. 4g+3
 // (features 8g + 4h ..) as 8 bytes at T[p][8g + 4h]; 4 ds_write_b64
-__device__ __forceinline__ void t_store_acc(unsigned char* lds, uint32_t slot, const half8& f0, const half8& f1, uint32_t lane) {
-  const uint32_t p = lane & 31u, h = lane >> 5;
+__device__ __forceinline__ void t_store_acc(unsigned char* lds, const LaneAddr& A, uint32_t slot, const half8& f0, const half8& f1) {
   const uint4 v0 = as_uint4(f0), v1 = as_uint4(f1);
-  lds_write8(lds, slot + t_off(p, 0u) + 8u * h, make_uint2(v0.x, v0.y));
-  lds_write8(lds, slot + t_off(p, 1u) + 8u * h, make_uint2(v0.z, v0.w));
-  lds_write8(lds, slot + t_off(p, 2u) + 8u * h, make_uint2(v1.x, v1.y));
-  lds_write8(lds, slot + t_off(p, 3u) + 8u * h, make_uint2(v1.z, v1.w));
+  lds_write8(lds, A.t_st[0] + slot, make_uint2(v0.x, v0.y));
+  lds_write8(lds, A.t_st[1] + slot, make_uint2(v0.z, v0.w));
+  lds_write8(lds, A.t_st[2] + slot, make_uint2(v1.x, v1.y));
+  lds_write8(lds, A.t_st[3] + slot, make_uint2(v1.z, v1.w));
 }
 // row-transposed operand of a stored tile: lane (c, h) element j = T[row 16 s + 8 h + j][column c]
-__device__ __forceinline__ half8 t_tr_frag(const unsigned char* lds, uint32_t slot, uint32_t s, uint32_t lane) {
-  const uint32_t g = lane >> 4, wl = lane & 15u, h = g >> 1, gh = g & 1u, q = wl >> 2, p = wl & 3u;
-  uint32_t o[2];
-#pragma unroll
-  for (uint32_t u = 0; u < 2u; ++u) o[u] = slot + t_off(16u * s + 8u * h + 4u * u + q, 2u * gh + (p >> 1)) + 8u * (p & 1u);
-  return as_half8(lds_read_tr(lds, o[0]), lds_read_tr(lds, o[1]));
+__device__ __forceinline__ half8 t_tr_frag(const unsigned char* lds, const LaneAddr& A, uint32_t slot, uint32_t s) {
+  return as_half8(lds_read_tr(lds, A.t_tr[0] + slot + 1024u * s), lds_read_tr(lds, A.t_tr[1] + slot + 1024u * s + 256u));
 }
 // row-wise operand: lane (row, h) element j = T[row][16 s + 8 h + j]
-__device__ __forceinline__ half8 t_row_frag(const unsigned char* lds, uint32_t slot, uint32_t s, uint32_t lane) {
-  return as_half8(lds_read16(lds, slot + t_off(lane & 31u, 2u * s + (lane >> 5))));
+__device__ __forceinline__ half8 t_row_frag(const unsigned char* lds, const LaneAddr& A, uint32_t slot, uint32_t s) {
+  return as_half8(lds_read16(lds, A.t_row[s] + slot));
 }
 
 // ---- the tile's input rows: f16 [rows][ld] in memory (two segments) -> IT images T_c[point][column 32 c ..] --------------------
@@ -221,11 +265,11 @@ __device__ __forceinline__ void x_tile_issue(XRegs<IT>& xr, const _Float16* __re
   }
 }
 template <int IT>
-__device__ __forceinline__ void x_tile_commit(const XRegs<IT>& xr, unsigned char* lds, uint32_t ximg, uint32_t lane) {
+__device__ __forceinline__ void x_tile_commit(const XRegs<IT>& xr, unsigned char* lds, const LaneAddr& A, uint32_t ximg) {
 #pragma unroll
   for (int c = 0; c < IT; ++c)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) lds_write16(lds, ximg + TILE_BYTES * c + t_off((lane >> 2) + 16u * i, lane & 3u), xr.v[c][i]);
+    for (int i = 0; i < 2; ++i) lds_write16(lds, A.x_st + ximg + TILE_BYTES * c + 1024u * i, xr.v[c][i]);
 }
 
 // ---- dY: fp32 rows [rows][lddy] -> the COLUMN layout: lane (col, hh = l >> 5), register 8 s + j = dy[row 16 s + 8 hh + j][col]
@@ -245,13 +289,13 @@ __device__ __forceinline__ void dy_issue(DyRegs& d, rsrc_t rdy, const uint32_t* 
   for (int i = 0; i < 16; ++i) d.v[i] = sp::buf_load1(rdy, col < n_out ? off[i] + 4u * col : BUF_OOB);
 }
 // times the loss scale, rounded to f16, into the image U[output column][point] (one 16-byte store per K-step)
-__device__ __forceinline__ void dy_commit(const DyRegs& d, float scale, unsigned char* lds, uint32_t slot, uint32_t lane) {
+__device__ __forceinline__ void dy_commit(const DyRegs& d, float scale, unsigned char* lds, const LaneAddr& A, uint32_t slot) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     half8 f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (_Float16)(d.v[8 * s + j] * scale);
-    lds_write16(lds, slot + t_off(lane & 31u, 2u * s + (lane >> 5)), as_uint4(f));
+    lds_write16(lds, A.t_row[s] + slot, as_uint4(f));
   }
 }
 
