@@ -107,6 +107,14 @@ def kernel_cost(entry, kernel, units, info, wl):
         chain = (m_out + m_hid) + (m_in if info["dx"] else 0)                       # dH chain, dX
         wgrad = (m_out + m_hid) if info["dw"] else 0                                # dW_out, dW_hidden (dW_in: mlp_dwin_kernel)
         return ("mfma", 2 * units * (chain + wgrad), 2 * units * ((recompute + chain) * pf + wgrad * pw))
+    # half rows (ABI v12, BASELINE configs[4]): f16 rows in, fp32 rows out, ONE backward kernel per network -- streaming kernels by
+    # design (64 kFLOP per point against ~600 B): their bound is HBM.  Algorithmic bytes: the f16 input row, the fp32 output /
+    # output-gradient row, the fp32 input-gradient row written (a read-add-write launch's read is the implementation's)
+    if k == "mlp_half_fwd_kernel":
+        return ("hbm", units * (2 * info["n_in"] + 4 * info["n_out"]))
+    if k == "mlp_half_bwd_kernel":
+        n_dx = max(info["n_in"] - info.get("dx_from", 0), 0) if info["dx"] else 0
+        return ("hbm", units * (2 * info["n_in"] + 4 * info["n_out"] + 4 * n_dx))
     if k == "mlp_dwin_kernel":
         # a STREAMING kernel (x and dH_1 read once, 96-128 accumulator registers, no reuse): its honest bound is HBM
         return ("hbm", units * (info["n_in"] + info["nn"]) * 4)

@@ -190,7 +190,21 @@ class MapStep:
         # once per step on the side stream under the ray branch's sampling / encoding) instead of building them per workgroup:
         # -10..17 us per backward launch and -2..6 us per forward launch since the copy-in keeps eight requests in flight.
         # mapper.prepared_images = False keeps the per-workgroup build; the split-row form takes fp32 weights
-        self.use_prep = bool(getattr(m, "prepared_images", os.environ.get("DNS_PREPARED_IMAGES", "1") != "0")) and not self.sr
+        # ---- HALF ROWS (ABI v12): networks that ask for tcnn's own precision (cfg['model']['mlp']['dtype'] = 'fp16', BASELINE
+        # configs[4]) run on the native f16 kernels -- the encoder and the feature block write plain f16 rows, every network launch
+        # reads them, ONE backward kernel per network forms all gradients (no dH_1 workspace, no dns_mlp_dwin), gradients carry
+        # tcnn's static loss scale (mapper.loss_scale, default 128).  mapper.half_rows = False / DNS_HALF_ROWS=0 keeps round 4's
+        # fp16-OPERAND mode of the split-operand kernels (per-point scales on fp32 rows).  The in-step 2-D branch (stem features)
+        # and kept hidden activations are not wired to it.
+        self.half = (bool(self.fp16) and bool(getattr(m, "half_rows", os.environ.get("DNS_HALF_ROWS", "1") != "0")) and not self.stem
+                     and not keep_hidden and not self.sr and ld % 16 == 0 and self.pe_dim % 8 == 0 and self.n_feat % 8 == 0
+                     and (self.pe_dim + self.n_feat) % 16 == 0)
+        self.loss_scale = float(getattr(m, "loss_scale", ops.HALF_LOSS_SCALE))
+        if self.half:
+            self.xh = torch.empty(P, ld, device=dev, dtype=torch.float16)
+            self.feath = torch.empty(P, self.n_feat, device=dev, dtype=torch.float16)
+        self.use_prep = (bool(getattr(m, "prepared_images", os.environ.get("DNS_PREPARED_IMAGES", "1") != "0")) and not self.sr
+                         and not self.half)
         self._blobs, self._prep_jobs = {}, []
         if self.use_prep:
             raw_lib = ops.lib._raw
@@ -319,6 +333,8 @@ class MapStep:
             self.lat_nx, self.lat_halo = lhi - la, 1 if lhi > lb else 0
             Pl = self.Pl = self.lat_nx * n * n
             self.bufl, self.occ, self.d_occ, self.d_bufl = f(Pl, ld), f(Pl, 1), f(Pl, 1), f(Pl, ld)
+            if self.half:
+                self.xhl = torch.empty(Pl, ld, device=dev, dtype=torch.float16)
             if self.sr:
                 np_ = self.sr_planes
                 self.xsl, self.xexpl = torch.empty(Pl, np_ * ld, device=dev, dtype=torch.float16), torch.empty(Pl, device=dev, dtype=torch.int32)
@@ -383,7 +399,12 @@ class MapStep:
         meta = C.byref(self.meta.c)
         grid_l = _V(self.bufl.data_ptr() + 4 * pe)
         n_in, _, nn, nl = self.shp_c
-        if self.sr:
+        if self.half:
+            check(lib.dns_encode_fwd_split(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, None, 0, ptr(self.xhl), ld,
+                                           None, ops.SPLIT_PLAIN, None, st), "dns_encode_fwd_split")
+            check(lib.dns_mlp_fwd_half(ptr(self.xhl), ld, None, 0, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
+                                       None, None, 0, 0, st), "dns_mlp_fwd_half")
+        elif self.sr:
             check(lib.dns_encode_fwd_split(ptr(pts), None, Pl, self.n_bins, ptr(self.p_table), meta, None, ptr(self.bufl), ld,
                                            ptr(self.xsl), self.sr_planes * ld, ptr(self.xexpl), self.sr_flags, None, st), "dns_encode_fwd_split")
             check(lib.dns_mlp_fwd_split(C.byref(self.rows_l), None, 0, ptr(self.p_coarse), n_in, 1, nn, nl, ptr(self.occ), 1, Pl,
@@ -401,7 +422,12 @@ class MapStep:
         check(lib.dns_tv_bwd(ptr(self.occ_x), 1, self.lat_nx, self.n_lat, self.lat_halo, self.sp, ptr(self.w_sm), ptr(self.d_occ_x), st),
               "dns_tv_bwd")
         torch.index_select(self.d_occ_x, 0, self.lat_order_l, out=self.d_occ)
-        if self.sr:
+        if self.half:
+            # (the lattice points carry no pose: only the grid columns' input gradient has a consumer, the table scatter)
+            check(lib.dns_mlp_bwd_half(ptr(self.xhl), ld, None, 0, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
+                                       ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), Pl, None, None, 0, ops.MLP_DX_FROM(pe),
+                                       self.loss_scale, st), "dns_mlp_bwd_half")
+        elif self.sr:
             check(lib.dns_mlp_bwd_split(C.byref(self.rows_l), None, 0, ptr(self.d_occ), 1, ptr(self.p_coarse), n_in, 1, nn, nl,
                                         ptr(self.d_bufl), ld, None, 0, ptr(cur.g_coarse), ptr(self.ws_mlp_l), Pl, None, None, 0,
                                         self.fp16, st), "dns_mlp_bwd_split")
@@ -537,7 +563,11 @@ class MapStep:
         meta = C.byref(self.meta.c)
         grid = _V(self.buf.data_ptr() + 4 * pe)
         sr = self.sr
-        if sr:
+        half = self.half
+        if half:
+            check(lib.dns_encode_fwd_split(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), None, 0,
+                                           ptr(self.xh), ld, None, ops.SPLIT_PLAIN, ptr(self.dydx), st), "dns_encode_fwd_split")
+        elif sr:
             check(lib.dns_encode_fwd_split(ptr(self.pts), self.b6, P, self.n_bins, ptr(self.p_table), meta, ptr(self.x3), ptr(self.buf),
                                            ld, ptr(self.xs), self.sr_planes * ld, ptr(self.xexp), self.sr_flags, ptr(self.dydx), st),
                   "dns_encode_fwd_split")
@@ -565,6 +595,11 @@ class MapStep:
 
         def fwd(x2, n_in1, params, shape, y, ri, tg, n_slots, stride, hs):
             n_in, n_out, nn, nl = shape
+            if half:                                   # x2: the f16 feature block (self.feath) where the fp32 paths take self.feat
+                check(lib.dns_mlp_fwd_half(ptr(self.xh), ld, None if x2 is None else ptr(self.feath), self.n_feat, n_in1, ptr(params),
+                                           n_in, n_out, nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride,
+                                           0 if x2 is None else self.live, st), "dns_mlp_fwd_half")
+                return
             if sr:
                 check(lib.dns_mlp_fwd_split(rows_x, None if x2 is None else rows_f, n_in1, ptr(params), n_in, n_out, nn, nl, ptr(y),
                                             y.stride(0), n_slots, ptr(ri), ptr(tg), stride, fp16, st), "dns_mlp_fwd_split")
@@ -580,7 +615,11 @@ class MapStep:
         fine, row_index, tile_group = cur.fine, cur.row_index, cur.tile_group     # zeroed / routed by _prepare
         fwd(None, 0, self.p_pool, self.shp_f, fine, row_index, tile_group, self.n_slots, self.p_pool.shape[-1], self.h_f)
         # (latents | truncated 2-D code) for the colour / logit networks, occupancy into the compositing input (:553-556, :622-627)
-        if sr or self.stem:
+        if half:
+            check(lib.dns_feature_block_split(ptr(fine), self.hid + 1, self.hid, ptr(self.features), self.n_feat - self.hid, 1, 0,
+                                              ptr(self.z), ptr(self.gt_depth), N, S, None, 0, ptr(self.feath), self.n_feat, None,
+                                              ops.SPLIT_PLAIN, ptr(self.raw), st), "dns_feature_block_split")
+        elif sr or self.stem:
             code, n_ref, Pf_ = (self.mlat, self.R, self.Pf) if self.stem else (self.features, 1, 0)
             check(lib.dns_feature_block_split(ptr(fine), self.hid + 1, self.hid, ptr(code), self.n_feat - self.hid, n_ref, Pf_,
                                               ptr(self.z), ptr(self.gt_depth), N, S, ptr(self.feat), self.n_feat,
@@ -629,7 +668,7 @@ class MapStep:
         # dW_in of every network on the SIDE stream (2.02 -> 1.90 ms per step): the streaming kernel is memory-bound and needs only
         # what its backward kernel left in the workspace, the next network's backward kernel is vector-bound -- the pair fills the
         # machine where either alone does not
-        fork_dwin = on_side
+        fork_dwin = on_side and not half               # (half rows: dW_in is formed inside the ONE backward kernel)
         side_st = _V(self.side.cuda_stream)
         nws = [0]
 
@@ -638,6 +677,12 @@ class MapStep:
             live = 0 if x2 is None else self.live
             ws = self.ws_mlp4[nws[0]] if fork_dwin else self.ws_mlp
             nws[0] += 1
+            if half:
+                check(lib.dns_mlp_bwd_half(ptr(self.xh), ld, None if x2 is None else ptr(self.feath), self.n_feat, n_in1, ptr(dy),
+                                           dy.stride(0), ptr(params), n_in, n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2),
+                                           0 if d_x2 is None else d_x2.stride(0), ptr(d_p), n_slots, ptr(ri), ptr(tg), stride,
+                                           acc | live, self.loss_scale, st), "dns_mlp_bwd_half")
+                return
             if sr:
                 check(lib.dns_mlp_bwd_split(rows_x, None if x2 is None else rows_f, n_in1, ptr(dy), dy.stride(0), ptr(params), n_in,
                                             n_out, nn, nl, ptr(self.d_buf), ld, ptr(d_x2), 0 if d_x2 is None else d_x2.stride(0),

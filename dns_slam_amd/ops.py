@@ -67,6 +67,9 @@ class _TimedLib:
              "dns_mlp_dwin": lambda a: {"n_in": _TimedLib._live(a[5], a[14]), "n_out": 0, "nn": a[6], "nl": a[7]},
              "dns_mlp_bwd": lambda a: {"n_in": _TimedLib._live(a[8], a[23]), "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]),
                                        "dw": bool(a[16])},
+             "dns_mlp_fwd_half": lambda a: {"n_in": _TimedLib._live(a[6], a[16]), "n_out": a[7], "nn": a[8], "nl": a[9]},
+             "dns_mlp_bwd_half": lambda a: {"n_in": _TimedLib._live(a[8], a[21]), "n_out": a[9], "nn": a[10], "nl": a[11], "dx": bool(a[12]),
+                                            "dw": bool(a[16]), "dx_from": (int(a[21]) >> 24) & 0x7f, "acc": int(a[21]) & 3},
              "dns_mlp_fwd_split": lambda a: {"n_in": a[4], "n_out": a[5], "nn": a[6], "nl": a[7]},
              "dns_mlp_bwd_split": lambda a: {"n_in": a[6], "n_out": a[7], "nn": a[8], "nl": a[9], "dx": bool(a[10]), "dw": bool(a[14])}}
 
@@ -76,7 +79,7 @@ class _TimedLib:
                   "dns_rays_from_pixels": 12, "dns_mlp_dwin": 10, "dns_feature_block": (7, 8), "dns_loss_sums": (1, 2),
                   "dns_loss_bwd": (1, 2), "dns_loss_rays": (1, 2), "dns_loss_finalize_bwd": (1, 2), "dns_raw_bwd": 2, "dns_rgb_sigmoid": 1, "dns_class_slots": (1, 2),
                   "dns_hashgrid_indices": 1, "dns_sample_along_rays": 2, "dns_feature_gather": (4, 5),
-                  "dns_encode_fwd_split": 2, "dns_mlp_fwd_split": 10, "dns_mlp_bwd_split": 16, "dns_feature_block_split": (9, 10),
+                  "dns_encode_fwd_split": 2, "dns_mlp_fwd_half": 12, "dns_mlp_bwd_half": 17, "dns_mlp_fwd_split": 10, "dns_mlp_bwd_split": 16, "dns_feature_block_split": (9, 10),
                   "dns_composite_fwd_ex": 3, "dns_composite_bwd_ex": 3, "dns_loss_bwd_points": (1, 2)}
 
     def arm(self, kernels=False):

@@ -323,8 +323,8 @@ def test_cfg2_fullsize_matches_oracle():
 @pytest.mark.parametrize("workload,combos", [
     ("cfg2", ((False, False), (False, True), (False, True), (True, False), (True, True), (True, True))),
     ("cfg3", ((False, True), (True, False), (True, True))),             # the 2-D code through the truncation mask (feature block)
-    ("cfg5_fp16", ((False, True), (True, True)))])                      # 8192 x 128, T = 2^20, fp16-operand networks
-def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(workload, combos):
+    ("cfg5_fp16", ((False, True), (True, True, "0"), (True, True, "1")))])   # 8192 x 128, T = 2^20: fp16-operand networks | half rows
+def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(workload, combos, monkeypatch):
     """Mapper.prefetch_draws (the benchmark's default with two streams: iteration k+1's pixel / jitter / lattice draws are
     enqueued on the side stream during iteration k): same generator order, so the losses of 16 full-size iterations
     launched WITHOUT any host synchronisation equal the unprefetched run's up to the run-to-run noise of the float
@@ -332,9 +332,16 @@ def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(worklo
     recycled while the main stream still read them) moved the losses by 2e-3 within four iterations when measured."""
     import bench
     from dns_slam_amd import dist as dd
+    from util import REPORT
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
     runs = []
-    for fused, prefetch in combos:
+    tols = []
+    for fused, prefetch, *half in combos:
+        # (cfg5_fp16: the fixed launch sequence once on round 4's fp16-OPERAND kernels -- the autograd path's arithmetic -- and once
+        #  on the HALF-ROWS kernels, ABI v12: f16 rows, static loss scale 128, i.e. a different rounding of every activation and
+        #  gradient -- same draws, same trajectory to a few 1e-3)
+        monkeypatch.setenv("DNS_HALF_ROWS", half[0] if half else "1")
+        tols.append(1e-2 if half and half[0] == "1" else 5e-4)
         # the autograd-driven step and the fixed launch sequence (fused_step.MapStep: its next step's draws, depth maxima and
         # decoder routing are prepared on the side stream too) make the same generator calls in the same order
         cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS[workload], DEV, seed=100, dist_ctx=dd.DistCtx(),
@@ -347,6 +354,7 @@ def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(worklo
         torch.cuda.synchronize()
         runs.append(torch.stack(losses).cpu())
     assert len(set(runs[0].tolist())) == 16                       # sixteen different batches, not one buffer read sixteen times
-    for r in runs[1:]:
+    for r, tol in zip(runs[1:], tols[1:]):
         err = float(((r - runs[0]).abs() / runs[0].abs()).max())
-        assert err <= 5e-4, f"prefetched draws / the fixed launch sequence changed the loss trajectory: max relative difference {err:.2e}"
+        REPORT.append((f"{workload}: loss trajectory of 16 iterations vs the autograd step (tolerance {tol:g})", err, err / tol, tol))
+        assert err <= tol, f"prefetched draws / the fixed launch sequence changed the loss trajectory: max relative difference {err:.2e}"
