@@ -28,6 +28,9 @@ ENTRY = {  # C-ABI entry point -> kernels it launches
     "dns_merge_dy": ["merge_dy_kernel"], "dns_add_ref_sum": ["add_ref_sum_kernel"], "dns_refer_poses": ["refer_poses_kernel"],
     "dns_draw_finish": ["draw_finish_kernel"], "dns_loss_finalize": ["loss_finalize_kernel"],
     "dns_loss_rays": ["loss_point_sums_kernel", "loss_rays_fused_kernel"],
+    # ABI v12 (round 5): half rows.  (x rows are 16 B / lane reads -> FETCH doubled like the other MLP kernels; their dY rows are
+    # dword reads, so the doubled figure is an UPPER bound for these two)
+    "dns_mlp_fwd_half": ["mlp_half_fwd_kernel"], "dns_mlp_bwd_half": ["mlp_half_bwd_kernel"],
 }
 GATHER = ("encode_fwd_kernel", "encode_fwd_split_kernel", "encode_bwd_kernel", "hashgrid_bwd_binned_kernel", "feature_gather_frames_kernel",
           "hashgrid_bwd_pairbins_kernel", "hashgrid_bwd_pairlist_kernel")
