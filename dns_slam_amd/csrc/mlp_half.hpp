@@ -299,6 +299,22 @@ __device__ __forceinline__ void dy_commit(const DyRegs& d, float scale, unsigned
   }
 }
 
+// n_out = 33 (hidden + 1: the coarse and the fine networks -- every MT = 2 launch of the step): the second 32-column chunk of dY
+// holds ONE live column.  Loaded as that column alone -- lane = point, one dword -- instead of 16 dword loads whose 31 other lanes
+// read nothing, and written as row 0 of a zeroed U_1 image: 17 registers and loads per tile instead of 32.
+__device__ __forceinline__ void dy_issue_col32(float& v, rsrc_t rdy, const uint32_t* __restrict__ dyoff, uint32_t lane) {
+  v = sp::buf_load1(rdy, dyoff[lane & 31u] + 4u * 32u);            // (a padding slot's offset is BUF_OOB: + 128 stays out of range)
+}
+__device__ __forceinline__ void dy_commit_col32(float v, float scale, unsigned char* lds, uint32_t wave_base, uint32_t slot, uint32_t lane) {
+  // rows 1 .. 31 of U_1 are zero, row 0 = the column: the tile is cleared (two 16-byte stores per lane) and row 0 written behind it
+  // (a wave's LDS instructions execute in order); the clear is needed every tile where the staging tile of the dX stores lies over it
+  const uint32_t base = wave_base + slot;
+  lds_write16(lds, base + 32u * lane, make_uint4(0u, 0u, 0u, 0u));
+  lds_write16(lds, base + 32u * lane + 16u, make_uint4(0u, 0u, 0u, 0u));
+  const _Float16 hv = (_Float16)(v * scale);
+  if (lane < 32u) *reinterpret_cast<_Float16*>(lds + base + t_off(0u, lane >> 3) + 2u * (lane & 7u)) = hv;
+}
+
 // ---- kernel arguments ------------------------------------------------------------------------------------------------------
 struct HFwdArgs {
   const _Float16* x;
