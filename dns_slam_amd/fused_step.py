@@ -39,6 +39,17 @@ from .common import get_quad_from_c2w, get_rotation_from_quad
 _V = C.c_void_p
 
 
+def _morton2(row, col):
+    """Bit-interleaved (row, col) of int64 tensors below 2^16 each."""
+    def spread(v):
+        v = v & 0xffff
+        v = (v | (v << 8)) & 0x00ff00ff
+        v = (v | (v << 4)) & 0x0f0f0f0f
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+    return spread(col) | (spread(row) << 1)
+
+
 class _Set:
     """What one step's preparation writes: the gradient buffer (zeroed), the fine network's output (zeroed), the draws and what
     derives from them alone (per-frame depth maximum, slot -> row table of the per-class routing)."""
@@ -77,6 +88,7 @@ class MapStep:
             fs = self.features
             self.features = fs.reshape(K_, self.npf_g, *fs.shape[1:])[:, self.ray_a:self.ray_b].reshape(-1, *fs.shape[1:]).contiguous()
         self.lambda_lt, self.smooth = float(lambda_lt), bool(smooth)
+        self.morton = (bool(getattr(m, "morton_draws", os.environ.get("DNS_MORTON_DRAWS", "0") == "1")) and m.label_layout == "per_ray")
         self.betas, self.eps = betas, eps
         K = self.K = m.n_target_frame
         dec, pool = m.decoder, m.fine_decoders
@@ -180,7 +192,6 @@ class MapStep:
         # time +-0: they are not bound by their input handling; cfg2 step 1.89 -> 2.04 ms) and with half-width networks the
         # forward's gain (0.60 -> 0.49 ms at cfg5_fp16) is eaten by the encoder writing a second row format (0.40 -> 0.51):
         # 6.19 -> 6.34 ms.  OFF by default; DNS_SPLIT_ROWS=1 / split_rows=True turns it on (tests/test_gpu_split_rows.py).
-        import os
         if split_rows is None:
             split_rows = os.environ.get("DNS_SPLIT_ROWS", "0") == "1"
         self.sr = bool(split_rows) and ld % 16 == 0 and self.pe_dim % 16 == 0 and self.n_feat % 16 == 0 and not keep_hidden
@@ -465,6 +476,16 @@ class MapStep:
             check(lib.dns_draw_finish(ptr(i1), ptr(u), ptr(prep["counts_f64"]), ptr(prep["counts_m1"]), ptr(prep["starts_flat"]),
                                       ptr(prep["sorted_flat"]), ptr(prep["depth"]), ptr(prep["label"]), K, n1, n2, prep["HW"],
                                       ptr(pix), ptr(labels), ptr(dmax), stream), "dns_draw_finish")
+            if self.morton:
+                # VERDICT r4 item 7 (an option, off by default; label_layout "per_ray" only -- the reference-tiled layout routes point k
+                # by labels[k mod N], a function of the ray ORDER): every frame's drawn pixels in Morton order of (row, col), so that
+                # neighbouring rays -- and with them neighbouring samples -- share hash-table lines.  The draw is the same SET; three torch
+                # launches per step on the stream that prepares the next step's set (off the critical path with prefetch_draws).
+                p2 = pix.view(K, npf_g)
+                code = _morton2(torch.div(p2, m.W, rounding_mode="floor"), p2 % m.W)
+                order = torch.argsort(code, dim=1)
+                pix = torch.gather(p2, 1, order).reshape(-1).contiguous()
+                labels = torch.gather(labels.view(K, npf_g), 1, order).reshape(-1).contiguous()
             d = {"pix": pix, "jitter": m.draw_jitter(), "r6": torch.rand(6, device=self.dev) if self.smooth else None}
         else:                                          # given draws (tests): the same quantities with torch ops
             d = dict(draws)                                # ('pix' = the WHOLE drawn list in union mode, like the generator's)

@@ -704,3 +704,35 @@ def test_track_step_fused_kernel_equals_the_launch_sequence(nn, nl, nu, ns, code
         for i, j in ((0, 0), (1, 1), (2, 2), (3, 6)):
             assert abs(float(out[i]) - float(ref[4][j])) <= 2e-5 * abs(float(ref[4][j])) + 1e-7, (mode, i, float(out[i]), float(ref[4][j]))
     assert float((ref[3].reshape(-1) - c2w[:3, 3].float()).abs().max()) > 0              # the pose did move
+
+
+def test_map_step_morton_ordered_draws_are_the_same_draw():
+    """mapper.morton_draws (label_layout 'per_ray' only, off by default): every frame's drawn pixel list in
+    Morton order of (row, col) -- the same SET of pixels with their labels, so the step's losses equal those of the draw-order
+    list up to the order of the sums; under the reference-tiled layout the option does nothing."""
+    from dns_slam_amd.fused_step import MapStep
+    out = {}
+    for layout, morton in (("per_ray", False), ("per_ray", True), ("reference_tiled", True)):
+        cfg, bound, cam, frames, dec, mapper = _setup(32, 1, layout=layout)
+        mapper.static_shapes, mapper.is_BA, mapper.overlap_smooth, mapper.prefetch_draws = True, True, False, False
+        mapper.morton_draws = morton
+        _, ql, Tl = mapper.set_optimizer(frames, fused=True)
+        ms = MapStep(mapper, frames, ql, Tl)
+        assert ms.morton == (morton and layout == "per_ray")
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        ms.step()
+        K, npf = ms.K, ms.npf
+        pix = ms.cur.draws["pix"].view(K, npf).clone()
+        out[(layout, morton)] = (pix, float(ms.losses()[0]), ms.gt_label.view(K, npf).clone())
+    p0, l0, lab0 = out[("per_ray", False)]
+    p1, l1, lab1 = out[("per_ray", True)]
+    assert torch.equal(torch.sort(p0, 1)[0], torch.sort(p1, 1)[0]) and not torch.equal(p0, p1)
+    W = mapper.W
+    code = lambda p: sum((((p // W) >> b) & 1) << (2 * b + 1) | (((p % W) >> b) & 1) << (2 * b) for b in range(10))
+    c1 = code(p1)
+    assert bool((c1[:, 1:] >= c1[:, :-1]).all()), "not in Morton order"
+    # the labels travel with their pixels
+    o0, o1 = torch.argsort(p0, dim=1, stable=True), torch.argsort(p1, dim=1, stable=True)
+    assert torch.equal(torch.gather(lab0, 1, o0), torch.gather(lab1, 1, o1))
+    assert abs(l0 - l1) <= 1e-4 * abs(l0)
