@@ -51,8 +51,9 @@ WORKLOADS = {
                       "2x64 MLPs"),
     "cfg5_fp16": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
                       mlp_dtype="fp16",
-                      desc="BASELINE configs[4]: scene0000 bound, 8192 rays x 128 samples, T=2^20, 2x64 MLPs with fp16 MFMA "
-                           "operands / fp32 accumulate (tcnn's precision); encodings, losses, weight gradients fp32"),
+                      desc="BASELINE configs[4]: scene0000 bound, 8192 rays x 128 samples, T=2^20, 2x64 MLPs in tcnn's own arithmetic "
+                           "(HALF ROWS, ABI v12: f16 activations and weight operands on v_mfma_f32_32x32x16_f16, fp32 accumulate, static "
+                           "loss scale 128, fp32 master weights and weight gradients); encodings computed in fp32, losses fp32"),
 }
 
 
@@ -717,7 +718,7 @@ def main():
         "metric": "ray-samples/s", "value": value, "unit": "ray-samples/s", "n_gpus": ctx.world_size,
         "rccl_ranks": ctx.group_size(), "dist_backend": ctx.backend_name(),
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "step_ms_spread": spread, "higher_is_better": True,
-        "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 MFMA operands, f32 accumulate (MLPs); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
+        "scaling": "strong" if union else "weak", "vs_baseline": None, "dtype": ("f16 activations and MFMA operands, f32 accumulate, loss scale 128 (MLPs: half rows); f32 elsewhere" if wl.get("mlp_dtype") == "fp16" else
                   "f32 (MLP products as 3 x f16 split-operand MFMA / 6 x bf16 for weight gradients, f32 accumulate: error <= fp32 fma chain)"), "data": "synthetic", "hip_graph": graphed, "streams": 2 if overlap else 1, "launch_mode": "hipGraph replay" if graphed else "eager",
         "step_driver": "fixed launch sequence (fused_step.MapStep)" if getattr(mapper, "map_step", None) is not None else "torch.autograd",
         "launch_trial_ms": trial, "final_loss": final_loss,

@@ -9,7 +9,9 @@ reference class works against this one.  Differences, all inside the module bodi
     the returned ``(pe, grid)`` are views of it, and ``Coarse`` re-uses the buffer instead of ``torch.cat``.
   * MLPs compute in fp32 on the matrix cores (tcnn: fp16) -- SURVEY D11.
   * extra cfg keys ``cfg['mlp'] = {'n_neurons': 32|64, 'n_hidden_layers': 1|2, 'dtype': 'fp32'|'fp16'}`` (default = the
-    reference's 1x32; fp32 is the parity path, 'fp16' computes the matrix products with fp16 operands like tcnn).
+    reference's 1x32; fp32 is the parity path; 'fp16' = tcnn's own precision, BASELINE configs[4]: through ``fused_step.MapStep``
+    the networks then run on the HALF-ROWS kernels of ABI v12 -- f16 rows, f16 weight operands, fp32 accumulation, static loss
+    scale ``mapper.loss_scale`` (128) --, through the autograd ops on the fp32-grade kernels with single f16 operands).
 """
 import torch
 from torch import nn
