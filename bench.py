@@ -49,6 +49,9 @@ WORKLOADS = {
     "cfg5": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
                  desc="BASELINE configs[4] shape in fp32: scene0000 bound, 8192 rays x 128 samples, T=2^20 (58.7 MB table), "
                       "2x64 MLPs"),
+    "cfg2_fp16": dict(rays=(683, 341), nu=48, ns=16, hash_size=16, voxel=0.02, nn=64, nl=2, smooth_pts=64, mlp_dtype="fp16",
+                      desc="configs[1]'s shapes with the MLPs in the REFERENCE's own precision (tcnn: f16, loss scale 128 -- half rows, "
+                           "ABI v12); a secondary line: the headline (cfg2) keeps the fp32-grade networks BASELINE's 1e-4 parity asks for"),
     "cfg5_fp16": dict(rays=(1366, 682), nu=96, ns=32, hash_size=20, voxel=0.04, nn=64, nl=2, smooth_pts=64, bound="scene0000",
                       mlp_dtype="fp16",
                       desc="BASELINE configs[4]: scene0000 bound, 8192 rays x 128 samples, T=2^20, 2x64 MLPs in tcnn's own arithmetic "

@@ -341,7 +341,10 @@ def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(worklo
         #  on the HALF-ROWS kernels, ABI v12: f16 rows, static loss scale 128, i.e. a different rounding of every activation and
         #  gradient -- same draws, same trajectory to a few 1e-3)
         monkeypatch.setenv("DNS_HALF_ROWS", half[0] if half else "1")
-        tols.append(1e-2 if half and half[0] == "1" else 5e-4)
+        # (1e-3: the float atomics of the table scatter make every run's trajectory its own -- 16 Adam steps amplify their last-bit
+        #  noise to 1e-5 .. 1e-4 typically, 5.7e-4 seen once in a full-suite run; the missing-dependency bug this test exists for
+        #  moved the losses by 2e-3 within four iterations.  Half rows against the autograd step's fp16-operand kernels: 2.3e-4 seen)
+        tols.append(2e-3 if half and half[0] == "1" else 1e-3)
         # the autograd-driven step and the fixed launch sequence (fused_step.MapStep: its next step's draws, depth maxima and
         # decoder routing are prepared on the side stream too) make the same generator calls in the same order
         cfg, bound, cam, frames, mapper, step = bench.build(bench.WORKLOADS[workload], DEV, seed=100, dist_ctx=dd.DistCtx(),
