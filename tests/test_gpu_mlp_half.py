@@ -262,3 +262,52 @@ def test_half_row_writers_round_the_fp32_rows():
         check(ops.lib.dns_feature_block_split(ptr(fine), hid + 1, hid, ptr(cd), Cn, 1, 0, ptr(z), ptr(gd_), N, S, None, 0, ptr(fh), F,
                                               None, ops.SPLIT_PLAIN, ptr(raw2), stream_ptr()), "dns_feature_block_split")
         assert torch.equal(fh, feat.half()) and torch.equal(raw, raw2)
+
+
+def test_map_step_on_half_rows_tracks_the_fp16_operand_and_fp32_steps(monkeypatch):
+    """fused_step.MapStep with fp16 networks (BASELINE configs[4]) on the half-rows kernels: on the SAME draws its loss terms and
+    every gradient segment agree with the same step on round 4's fp16-operand kernels (both round operands to f16; the scale
+    bookkeeping differs: static 128 vs per-point) and with the fp32-grade step to the stated, looser tolerance; it trains."""
+    from dns_slam_amd import synthetic
+    from dns_slam_amd.decoder import Decoder
+    from dns_slam_amd.mapping import Mapper
+    from dns_slam_amd.fused_step import MapStep
+    from util import randomise_
+    res = {}
+    for mode in ("fp32", "operand", "half"):
+        monkeypatch.setenv("DNS_HALF_ROWS", "1" if mode == "half" else "0")
+        cam = synthetic.camera(H=60, W=80, fx=60.0, fy=60.0)
+        bound, cam, frames = synthetic.make_scene(4, cam=cam, seed=0)
+        cfg = synthetic.default_cfg(n_pixels=360, n_samples_ray=32, n_surface_ray=15, n_frames=4, hash_size=14, voxel_size=0.08,
+                                    n_neurons=64, n_hidden_layers=2, smooth_pts=12, mlp_dtype="fp32" if mode == "fp32" else "fp16")
+        dec = Decoder(cfg["model"], bound, n_class=8).to(DEV)
+        mapper = Mapper(cfg, dec, bound, cam, device=DEV)
+        mapper.set_decoder(frames)
+        randomise_(dec, 11, scale=1.0)
+        with torch.no_grad():
+            dec.pe_fn.grid_fn.params.mul_(2000.0)
+        randomise_([mapper.fine_decoders.pool], 12)
+        mapper.static_shapes, mapper.is_BA, mapper.overlap_smooth, mapper.prefetch_draws = True, True, True, True
+        _, ql, Tl = mapper.set_optimizer(frames, fused=True)
+        ms = MapStep(mapper, frames, ql, Tl)
+        assert ms.half == (mode == "half") and bool(ms.fp16) == (mode != "fp32")
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        ms.step()
+        torch.cuda.synchronize()
+        names = ("color", "logit", "pool", "table", "coarse", "quat", "trans")
+        first = {"loss": float(ms.losses()[0]), "terms": {k: float(v) for k, v in ms.losses()[1].items()},
+                 "g": {n: getattr(ms.cur, "g_" + n).clone() for n in names}}
+        for _ in range(11):
+            ms.step()
+        res[mode] = (first, float(ms.losses()[0]))
+    rel = lambda a, b: float((a.double() - b.double()).pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt().clamp_min(1e-30))
+    h, o, f = res["half"][0], res["operand"][0], res["fp32"][0]
+    assert abs(h["loss"] - o["loss"]) <= 2e-3 * abs(o["loss"]) and abs(h["loss"] - f["loss"]) <= 2e-2 * abs(f["loss"])
+    for k in h["terms"]:
+        assert abs(h["terms"][k] - o["terms"][k]) <= 5e-3 * max(abs(o["terms"][k]), 1e-3), k
+    for n in h["g"]:
+        assert rel(h["g"][n], o["g"][n]) <= 2e-2, (n, rel(h["g"][n], o["g"][n]))
+        assert rel(h["g"][n], f["g"][n]) <= 1e-1, (n, rel(h["g"][n], f["g"][n]))
+    assert res["half"][1] < 0.9 * h["loss"], "the half-rows step does not train"
+    assert abs(res["half"][1] - res["fp32"][1]) <= 0.1 * abs(res["fp32"][1])
