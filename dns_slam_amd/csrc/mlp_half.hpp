@@ -40,6 +40,13 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 // phase boundary: nothing is scheduled across it (with 512 registers to fill hipcc otherwise hoists the next phases' loads and
 // fragment reads over the current one and spills the weight-gradient accumulators it was given the room for)
+// Between the batch of LDS reads that feeds a chain of matrix instructions and the chain: left to itself hipcc (at its register
+// limit) sinks every fragment read to just in front of the instruction that uses it -- read, s_waitcnt lgkmcnt(0), matrix
+// instruction, 60-odd times per tile, each wait the full LDS round trip of a wave that is alone on its SIMD (counters: 40 % of
+// the wave's cycles in s_waitcnt).  With the reads issued first the waits in front of the matrix instructions become counted
+// lgkmcnt(N): the fragments stream in underneath the chain.
+__device__ __forceinline__ void reads_issued() { __builtin_amdgcn_sched_barrier(0); }
+
 __device__ __forceinline__ void phase_fence() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
