@@ -26,7 +26,10 @@ namespace dns {
 // lane stride cost 3.4x the bytes in HBM writes).  The tile is used TWICE -- OneBlob columns, flush, then grid columns,
 // flush -- so it holds max(pe_dim, g_dim) + 1 floats per point (25 KB instead of 41 KB): LDS, not registers (68 VGPRs),
 // is what limits this gather kernel's occupancy, and 12 waves per CU hide the table-gather latency better than 6.
-template <bool TILED>
+// HALF (with TILED; ABI v12, DNS_SPLIT_PLAIN): the row leaves as plain f16 -- the flush converts eight tile values to one
+// 16-byte store; pe_out / grid_out then point at halfs and ld_pe / ld_grid count halfs.  (The scaled split-row writer below
+// evaluates OneBlob twice and flushes in four steps: 98.6 us against this kernel's 84 at 262 144 points.)
+template <bool TILED, bool HALF = false>
 __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict__ in, Bound6 bd, int normalise,
                                                          uint32_t P, uint32_t n_bins,
                                                          const float2* __restrict__ table, GridLevels lv,
@@ -54,7 +57,22 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
     float* out = out_base + (size_t)p0 * ld;
     // (row, column) advance incrementally (an integer division per element was a visible cost); 16-byte global accesses
     // where the rows allow it (the LDS tile's odd row stride keeps its side at dwords)
-    if (((nc | ld) & 3u) == 0 && ((((uintptr_t)out_base) & 15u) == 0)) {
+    if constexpr (HALF) {                              // nc, ld multiples of 8, out_base 16-byte aligned (host-checked)
+      _Float16* outh = reinterpret_cast<_Float16*>(out_base) + (size_t)p0 * ld;
+      const uint32_t nq = nc >> 3, dr = blockDim.x / nq, dc = blockDim.x - dr * nq;
+      uint32_t r = threadIdx.x / nq, c = threadIdx.x - r * nq;
+      for (uint32_t i = threadIdx.x; i < rows * nq; i += blockDim.x) {
+        const float* t = tile + r * ldt + 8 * c;
+        typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+        half8v h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = (_Float16)t[k];
+        *reinterpret_cast<half8v*>(outh + (size_t)r * ld + 8 * c) = h;
+        r += dr;
+        c += dc;
+        if (c >= nq) { c -= nq; ++r; }
+      }
+    } else if (((nc | ld) & 3u) == 0 && ((((uintptr_t)out_base) & 15u) == 0)) {
       const uint32_t nq = nc >> 2, dr = blockDim.x / nq, dc = blockDim.x - dr * nq;
       uint32_t r = threadIdx.x / nq, c = threadIdx.x - r * nq;
       for (uint32_t i = threadIdx.x; i < rows * nq; i += blockDim.x) {
@@ -1730,7 +1748,8 @@ static int encode_init_attrs() {
       // (+ the job prefix of balanced dense lists: 4 (n_lists + 1) bytes behind the bins; with DNS_LIST_SHIFT=13 the bins alone
       //  are the whole 128 KB -- ADVICE r4)
       hipFuncSetAttribute((const void*)hashgrid_bwd_pairbins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) != hipSuccess ||
-      hipFuncSetAttribute((const void*)encode_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * 64 + 1) * (int)sizeof(float)) != hipSuccess) {
+      hipFuncSetAttribute((const void*)encode_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * 64 + 1) * (int)sizeof(float)) != hipSuccess ||
+      hipFuncSetAttribute((const void*)encode_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * 64 + 1) * (int)sizeof(float)) != hipSuccess) {
     set_error("dns_init: hipFuncSetAttribute failed for the hash-grid scatter kernels");
     return DNS_E_LAUNCH;
   }
@@ -1796,6 +1815,14 @@ extern "C" int dns_encode_fwd_split(const float* in, const double* bound, uint32
   GridLevels lv = to_levels(meta);
   const uint32_t blocks = (P + 127) / 128;
   const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
+  if (plain && !f32_out) {
+    // half rows alone: the one-pass tiled encoder with an f16 flush (pe_out / grid_out / their strides in halfs)
+    _Float16* xh = reinterpret_cast<_Float16*>(xs_out);
+    DNS_LAUNCH((encode_fwd_kernel<true, true>), dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
+               n_bins, (const float2*)table, lv, x_out, reinterpret_cast<float*>(xh), ldxs, reinterpret_cast<float*>(xh + pe_dim), ldxs,
+               (float2*)dy_dx);
+    return check_launch("dns_encode_fwd_split");
+  }
   DNS_LAUNCH(encode_fwd_split_kernel, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
              n_bins, (const float2*)table, lv, x_out, f32_out, ld32, (uint32_t*)xs_out, ldxs / 2, xexp, (hi_only ? 1 : 0) | (plain ? 2 : 0),
              (float2*)dy_dx);
