@@ -1,5 +1,6 @@
 // Forward kernel, dW_in kernel and the host-side launchers of the split-operand MLP (device helpers: mlp_split.hpp; the
 // backward kernel: mlp_split_bwd.inc, one translation unit per (n_neurons, n_hidden_layers)).
+#include <cstdlib>
 #include "mlp_split.hpp"
 
 namespace dns {
@@ -243,7 +244,10 @@ int launch_mlp_dwin(const float* x, uint32_t ldx, const float* x2, uint32_t ldx2
   DwinArgs d;
   d.dh1 = ws; d.x = x; d.ldx = ldx; d.seg = {x2, ldx2, x2 ? n_in1 : n_in}; d.n_in = n_in; d.n_in_w = n_in_w ? n_in_w : n_in; d.d_params = d_params; d.n_slots = n_slots;
   d.row_index = row_index; d.tile_group = tile_group; d.param_stride = param_stride;
-  uint32_t tpb2 = (n_btiles + 511u) / 512u;      // two workgroups per CU
+  // two workgroups per CU (DNS_DWIN_BLOCKS: measurement knob -- every workgroup ends in 6-8 tiles of float atomics onto the SAME
+  // dW_in addresses, so fewer workgroups = fewer atomics, more = more loads in flight)
+  static const uint32_t dwin_blocks = [] { const char* e = getenv("DNS_DWIN_BLOCKS"); const long n = e ? atol(e) : 0; return (uint32_t)(n >= 64 && n <= 4096 ? n : 512); }();
+  uint32_t tpb2 = (n_btiles + dwin_blocks - 1u) / dwin_blocks;
   if (tpb2 < 1) tpb2 = 1;
   d.tiles_per_block = tpb2;
   const uint32_t blocks2 = (n_btiles + tpb2 - 1) / tpb2;
