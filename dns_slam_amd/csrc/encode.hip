@@ -14,6 +14,8 @@
 #include <type_traits>
 #include "common.hpp"
 #include "split_rows.hpp"
+#include <cstdlib>
+#include <cstring>
 #include "dev_encode.hpp"
 
 namespace dns {
@@ -35,11 +37,15 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
                                                          const float2* __restrict__ table, GridLevels lv,
                                                          float* __restrict__ x_out, float* __restrict__ pe_out,
                                                          uint32_t ld_pe, float* __restrict__ grid_out,
-                                                         uint32_t ld_grid, float2* __restrict__ dydx) {
+                                                         uint32_t ld_grid, float2* __restrict__ dydx, uint32_t pe_ph,
+                                                         uint32_t g_ph) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
-  const uint32_t ldt = max(pe_dim, g_dim) + 1;
+  // (TILED) the tile is used pe_ph + g_ph times: OneBlob in 1 or 3 phases (all axes / one axis each), the grid in g_ph groups of
+  // levels -- every phase ends in a flush, so the tile holds the widest PHASE + 1 floats per point
+  const uint32_t lpp = lv.n_levels / g_ph;                // levels per grid phase (host: g_ph divides n_levels)
+  const uint32_t ldt = max(pe_dim / pe_ph, 2u * lpp) + 1;
   const bool live = p < P;
   float x[3] = {0.f, 0.f, 0.f};
   if (live) load_point(in, bd, normalise != 0, p, x);
@@ -49,6 +55,9 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
     x_out[(size_t)p * 3 + 2] = x[2];
   }
   float* trow = tile + threadIdx.x * ldt;
+  auto col_ptr = [](float* base, uint32_t col) -> float* {           // column `col` of an output row (HALF: the row holds halfs)
+    return HALF ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(base) + col) : base + col;
+  };
   // rows [p0, p0 + rows) x columns [c0, c0 + nc) of the row-major output with leading dimension ld, from the tile
   auto flush = [&](float* out_base, uint32_t ld, uint32_t nc) {
     __syncthreads();
@@ -95,39 +104,42 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
     __syncthreads();
   };
   if (pe_out) {
-    if (live) {
-      const float n = (float)n_bins;
-      float* row = TILED ? trow : pe_out + (size_t)p * ld_pe;
+    const float n = (float)n_bins;
+    float* row = TILED ? trow : pe_out + (size_t)p * ld_pe;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t c0 = (TILED && pe_ph == 3u) ? 0u : a * n_bins;      // the axis' first tile / row column
+      if (live) {
         const float xa = x[a];
         if (n_bins >= 8u && fabsf(xa) < 4.0f) {            // windows of different images cannot overlap
-          for (uint32_t b = 0; b < n_bins; ++b) row[a * n_bins + b] = 0.f;
-          oneblob_windows<false>(n_bins, n, xa, [&](uint32_t j, float v) { row[a * n_bins + j] = v; });
-          continue;
-        }
-        float first = 0.f, left = 0.f;
-        for (uint32_t b = 0; b <= n_bins; ++b) {
-          float g;
-          if (b < n_bins) {
-            const float d = (float)b / n - xa;
-            g = quartic_cdf(d, n) + quartic_cdf(d - 1.0f, n) + quartic_cdf(d + 1.0f, n);
-            if (b == 0) first = g;
-          } else {
-            g = first + 1.0f;  // right edge of the last bin wraps (tcnn kernel_one_blob)
+          for (uint32_t b = 0; b < n_bins; ++b) row[c0 + b] = 0.f;
+          oneblob_windows<false>(n_bins, n, xa, [&](uint32_t j, float v) { row[c0 + j] = v; });
+        } else {
+          float first = 0.f, left = 0.f;
+          for (uint32_t b = 0; b <= n_bins; ++b) {
+            float g;
+            if (b < n_bins) {
+              const float d = (float)b / n - xa;
+              g = quartic_cdf(d, n) + quartic_cdf(d - 1.0f, n) + quartic_cdf(d + 1.0f, n);
+              if (b == 0) first = g;
+            } else {
+              g = first + 1.0f;  // right edge of the last bin wraps (tcnn kernel_one_blob)
+            }
+            if (b > 0) row[c0 + b - 1] = g - left;
+            left = g;
           }
-          if (b > 0) row[a * n_bins + b - 1] = g - left;
-          left = g;
         }
       }
+      if (TILED && pe_ph == 3u) flush(col_ptr(pe_out, a * n_bins), ld_pe, n_bins);
     }
-    if (TILED) flush(pe_out, ld_pe, pe_dim);
+    if (TILED && pe_ph != 3u) flush(pe_out, ld_pe, pe_dim);
   }
   if (grid_out) {
+    for (uint32_t ph = 0; ph < g_ph; ++ph) {
     if (live) {
-      float* row = TILED ? trow : grid_out + (size_t)p * ld_grid;
+      float* row = TILED ? trow - 2u * lpp * ph : grid_out + (size_t)p * ld_grid;     // (TILED: level l's pair at tile column 2 (l - lpp ph))
 #pragma unroll 4
-      for (uint32_t l = 0; l < lv.n_levels; ++l) {
+      for (uint32_t l = lpp * ph; l < lpp * (ph + 1u); ++l) {
         const float s = lv.scale[l];
         const uint32_t res = lv.resolution[l], size = lv.size[l], hashed = lv.hashed[l];
         const float2* __restrict__ t = table + lv.offset[l];
@@ -171,7 +183,8 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
         }
       }
     }
-    if (TILED) flush(grid_out, ld_grid, g_dim);
+    if (TILED) flush(col_ptr(grid_out, 2u * lpp * ph), ld_grid, 2u * lpp);
+    }
   }
 }
 // The same encoding written in the SPLIT-ROW format of split_rows.hpp (and, optionally, as fp32 rows as well): what the MLP
@@ -1741,6 +1754,21 @@ static ScatterWs scatter_ws(uint32_t P, const GridLevels& lv, uint32_t flags, ui
   return w;
 }
 
+// How many times the tiled encoder uses its LDS tile (encode_fwd_kernel): OneBlob in 1 or 3 phases, the grid in g_ph groups of
+// levels.  The tile -- not the 68 registers -- sets this gather kernel's occupancy.  DNS_ENC_PHASES = "pe_ph,g_ph" (measurement knob).
+static void encode_tile_phases(uint32_t n_bins, uint32_t n_levels, bool with_pe, uint32_t& pe_ph, uint32_t& g_ph) {
+  static const int env_pe = [] { const char* e = getenv("DNS_ENC_PHASES"); return e ? atoi(e) : 0; }();
+  static const int env_g = [] { const char* e = getenv("DNS_ENC_PHASES"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+  // default 3 + 2 phases (a 17-float tile row, 8.7 KB per workgroup, where one OneBlob phase + one grid phase needs 49 floats, 25 KB:
+  // the registers then allow 14 workgroups per CU instead of the tile's 6): 262 144 points along rays 97.1 -> 91.3 us, uniformly
+  // random points 155 -> 132 us, the cfg2 step 1.532 -> 1.526 ms (round 5; "3,8": 90.5 / 135.8, "1,2": 95.7 / 153)
+  pe_ph = (env_pe == 3 || env_pe == 1) ? (uint32_t)env_pe : 3u;
+  g_ph = env_g >= 1 ? (uint32_t)env_g : 2u;
+  if (!with_pe) pe_ph = 1u;
+  if (n_levels == 0u || n_levels % g_ph != 0u || ((2u * n_levels / g_ph) % 8u) != 0u) g_ph = 1u;   // (flush granularity: 8 columns)
+  if (pe_ph == 3u && (n_bins % 8u) != 0u) pe_ph = 1u;
+}
+
 static int encode_init_attrs() {
   const int bytes = 8192 * 2 * (int)sizeof(unsigned long long);   // one 8192-row chunk of 64-bit bins: 128 KB
   if (hipFuncSetAttribute((const void*)hashgrid_bwd_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
@@ -1783,14 +1811,17 @@ extern "C" int dns_encode_fwd(const float* in, const double* bound, uint32_t P, 
   const bool tiled = (pe_out && grid_out && ld_pe == pe_dim + g_dim && ld_grid == ld_pe && grid_out == pe_out + pe_dim) ||
                      (pe_out && !grid_out && pe_dim > 0);
   if (tiled) {
-    const size_t lds_bytes = (size_t)128 * ((pe_dim > g_dim ? pe_dim : g_dim) + 1) * sizeof(float);
+    uint32_t pe_ph, g_ph;
+    encode_tile_phases(n_bins, grid_out ? meta->n_levels : 0, pe_out != nullptr, pe_ph, g_ph);
+    const uint32_t w_pe = pe_out ? pe_dim / pe_ph : 0, w_g = grid_out ? g_dim / g_ph : 0;
+    const size_t lds_bytes = (size_t)128 * ((w_pe > w_g ? w_pe : w_g) + 1) * sizeof(float);
     DNS_LAUNCH(encode_fwd_kernel<true>, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound),
                        bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid,
-                       (float2*)dy_dx);
+                       (float2*)dy_dx, pe_ph, g_ph);
   } else {
     DNS_LAUNCH(encode_fwd_kernel<false>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, in, make_bound(bound),
                        bound ? 1 : 0, P, n_bins, (const float2*)table, lv, x_out, pe_out, ld_pe, grid_out, ld_grid,
-                       (float2*)dy_dx);
+                       (float2*)dy_dx, 1u, 1u);
   }
   return check_launch("dns_encode_fwd");
 }
@@ -1818,9 +1849,13 @@ extern "C" int dns_encode_fwd_split(const float* in, const double* bound, uint32
   if (plain && !f32_out) {
     // half rows alone: the one-pass tiled encoder with an f16 flush (pe_out / grid_out / their strides in halfs)
     _Float16* xh = reinterpret_cast<_Float16*>(xs_out);
-    DNS_LAUNCH((encode_fwd_kernel<true, true>), dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
+    uint32_t pe_ph, g_ph;
+    encode_tile_phases(n_bins, meta->n_levels, true, pe_ph, g_ph);
+    const uint32_t w_pe = pe_dim / pe_ph, w_g = g_dim / g_ph;
+    const size_t lds_plain = (size_t)128 * ((w_pe > w_g ? w_pe : w_g) + 1) * sizeof(float);
+    DNS_LAUNCH((encode_fwd_kernel<true, true>), dim3(blocks), dim3(128), lds_plain, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
                n_bins, (const float2*)table, lv, x_out, reinterpret_cast<float*>(xh), ldxs, reinterpret_cast<float*>(xh + pe_dim), ldxs,
-               (float2*)dy_dx);
+               (float2*)dy_dx, pe_ph, g_ph);
     return check_launch("dns_encode_fwd_split");
   }
   DNS_LAUNCH(encode_fwd_split_kernel, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
