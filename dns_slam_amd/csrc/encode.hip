@@ -357,15 +357,17 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ d_pe, uint32_t ld_dpe,
                                                          const float* __restrict__ d_grid, uint32_t ld_dgrid,
                                                          float* __restrict__ d_table, float* __restrict__ d_x,
-                                                         const float2* __restrict__ dydx) {
+                                                         const float2* __restrict__ dydx, uint32_t pe_ph, uint32_t g_ph) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
+  const uint32_t lpp = lv.n_levels / g_ph;                // levels per grid phase (TILED; host: g_ph divides n_levels)
   // TILED: the workgroup's gradient rows come in through an LDS tile (coalesced row reads instead of one 320-byte-strided
   // row per lane), in TWO phases like the forward -- OneBlob columns, then grid columns -- so that the tile holds
   // max(pe_dim, g_dim) + 1 floats per point (25 KB, 12 waves per CU) instead of the whole row (41 KB, 6 waves): this
   // kernel is latency-bound (dependent LDS reads, 8-byte gathers), occupancy is what it lacked.
-  const uint32_t ldt = max(pe_dim, g_dim) + 1;
+  // (round 5: pe_ph = 3 / g_ph = 2 phases -- one OneBlob axis / half the levels at a time, 17 floats per point: see encode_fwd_kernel)
+  const uint32_t ldt = max(pe_dim / pe_ph, 2u * lpp) + 1;
   const bool live = p < P;
   auto stage = [&](uint32_t col0, uint32_t nc) {         // columns [col0, col0 + nc) of the workgroup's rows -> tile
     __syncthreads();
@@ -401,13 +403,15 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
     x[1] = xin[(size_t)p * 3 + 1];
     x[2] = xin[(size_t)p * 3 + 2];
   }
-  if (TILED) stage(0, pe_dim);
+  const bool pe_split = TILED && pe_ph == 3u;
+  if (TILED && !pe_split) stage(0, pe_dim);
   float dx[3] = {0.f, 0.f, 0.f};
-  if (live && d_pe && d_x) {
-    const float n = (float)n_bins;
-    const float* row = TILED ? tile + threadIdx.x * ldt : d_pe + (size_t)p * ld_dpe;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+  for (int a = 0; a < 3; ++a) {
+    if (pe_split) stage(a * n_bins, n_bins);               // (uniform: every thread of the workgroup)
+    if (live && d_pe && d_x) {
+      const float n = (float)n_bins;
+      const float* row = TILED ? tile + threadIdx.x * ldt - (pe_split ? a * n_bins : 0u) : d_pe + (size_t)p * ld_dpe;
       const float xa = x[a];
       if (n_bins >= 8u && fabsf(xa) < 4.0f) {
         float accw = 0.f;
@@ -431,13 +435,15 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
       dx[a] += acc;
     }
   }
-  if (TILED) stage(pe_dim, g_dim);
+  for (uint32_t ph = 0; ph < (TILED ? g_ph : 1u); ++ph) {
+  const uint32_t l_lo = TILED ? lpp * ph : 0u, l_hi = TILED ? lpp * (ph + 1u) : lv.n_levels;
+  if (TILED) stage(pe_dim + 2u * l_lo, 2u * (l_hi - l_lo));
   if (live && d_grid && dydx && d_x && !d_table) {
     // the forward kept d(features)/dx: a streaming dot product, no gather (coalesced 8-byte reads, lane = point).
     // (Requesting all 48 values before the first staging barrier was measured: 96 more registers, 0.102 -> 0.113 ms.)
-    const float* row = TILED ? tile + threadIdx.x * ldt : d_grid + (size_t)p * ld_dgrid;
+    const float* row = TILED ? tile + threadIdx.x * ldt - 2u * l_lo : d_grid + (size_t)p * ld_dgrid;
 #pragma unroll 4
-    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+    for (uint32_t l = l_lo; l < l_hi; ++l) {
       const float g0 = row[2 * l], g1 = row[2 * l + 1];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -446,9 +452,9 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
       }
     }
   } else if (live && d_grid) {
-    const float* row = TILED ? tile + threadIdx.x * ldt : d_grid + (size_t)p * ld_dgrid;
+    const float* row = TILED ? tile + threadIdx.x * ldt - 2u * l_lo : d_grid + (size_t)p * ld_dgrid;
 #pragma unroll 2
-    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+    for (uint32_t l = l_lo; l < l_hi; ++l) {
       const float g0 = row[2 * l], g1 = row[2 * l + 1];
       const float s = lv.scale[l];
       const uint32_t res = lv.resolution[l], size = lv.size[l], hashed = lv.hashed[l];
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
       }
     }
   }
+  }   // grid phases
   if (live && d_x) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -1894,14 +1901,17 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     const bool tiled = d_pe && d_grid && d_x && ld_dpe == ld_dgrid && d_grid == d_pe + 3 * n_bins &&
                        ld_dpe == 3 * n_bins + 2 * lv.n_levels;
     if (tiled) {
-      DNS_LAUNCH(encode_bwd_kernel<true>, dim3(blocks128), dim3(128),
-                         (size_t)128 * ((3 * n_bins > 2 * lv.n_levels ? 3 * n_bins : 2 * lv.n_levels) + 1) * sizeof(float), st, x,
+      uint32_t pe_ph, g_ph;
+      encode_tile_phases(n_bins, lv.n_levels, true, pe_ph, g_ph);
+      if ((n_bins % 4u) != 0u) pe_ph = 1u;              // (the staging reads 16 bytes at a time)
+      const uint32_t w_pe = 3 * n_bins / pe_ph, w_g = 2 * lv.n_levels / g_ph;
+      DNS_LAUNCH(encode_bwd_kernel<true>, dim3(blocks128), dim3(128), (size_t)128 * ((w_pe > w_g ? w_pe : w_g) + 1) * sizeof(float), st, x,
                          make_bound(bound), bound ? 1 : 0, P, n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid,
-                         d_table_direct, d_x, (const float2*)dy_dx);
+                         d_table_direct, d_x, (const float2*)dy_dx, pe_ph, g_ph);
     } else {
       DNS_LAUNCH(encode_bwd_kernel<false>, dim3(blocks128), dim3(128), 0, st, x, make_bound(bound), bound ? 1 : 0, P,
                          n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid, d_table_direct, d_x,
-                         (const float2*)dy_dx);
+                         (const float2*)dy_dx, 1u, 1u);
     }
   }
   if (binned) {
