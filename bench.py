@@ -802,11 +802,11 @@ def main():
             raise RuntimeError("skipped")
         wl16 = WORKLOADS["cfg2_fp16"]
         _, _, _, _, mapper16, step16 = build(wl16, device, seed=1000, dist_ctx=ctx, overlap=True, graph=False)
-        for _ in range(20):
+        for _ in range(50):
             step16()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n16 = 100
+        n16 = 200
         for _ in range(n16):
             step16()
         torch.cuda.synchronize()
