@@ -69,14 +69,20 @@ __global__ __launch_bounds__(256, 2) void mlp_half_fwd_kernel(HFwdArgs a) {
     if (grp != cur_group) {
       __syncthreads();
       if (grp >= 0) {
-        lds_zero16(lds, img_bytes);
-        __syncthreads();
         const float* pw = a.params + (size_t)grp * a.param_stride;
         const float* wh = pw + NN * a.n_in_w;
         const float* wout = wh + (NL - 1) * NN * NN;
-        w_image_build(lds, w_in, pw, NN, n_in, a.n_in_w);
-        if constexpr (NL == 2) w_image_build(lds, w_h, wh, NN, NN, NN);
-        w_image_build(lds, w_out, wout, n_out, NN, NN);
+        WQuads<NN * 128 / 1024> q_in;                  // n_in <= 128
+        WQuads<NN * NN / 1024> q_h;
+        WQuads<64 * NN / 1024> q_out;                  // n_out <= 64
+        w_image_load(q_in, pw, NN, n_in, a.n_in_w);
+        if constexpr (NL == 2) w_image_load(q_h, wh, NN, NN, NN);
+        w_image_load(q_out, wout, n_out, NN, NN);
+        lds_zero16(lds, img_bytes);
+        __syncthreads();
+        w_image_store(q_in, lds, w_in, NN, n_in);
+        if constexpr (NL == 2) w_image_store(q_h, lds, w_h, NN, NN);
+        w_image_store(q_out, lds, w_out, n_out, NN);
       }
       cur_group = grp;
       __syncthreads();

@@ -223,6 +223,43 @@ __device__ __forceinline__ void w_image_build(unsigned char* lds, const WImg& w,
   }
 }
 
+// The same in two steps, for a prologue that is a large share of a small launch (the forward kernel: 10.7 us at one tile per
+// wave): ALL of a weight set's loads are put in flight first (w_image_load; the rolled loop above is a dependent load -> convert
+// -> store chain per trip), the image area is cleared while they fly, then the values are converted and stored (w_image_store).
+// MAXQ >= R C / 4 / blockDim.x.
+template <int MAXQ>
+struct WQuads {
+  float4 v[MAXQ];
+};
+template <int MAXQ>
+__device__ __forceinline__ void w_image_load(WQuads<MAXQ>& q, const float* __restrict__ M, uint32_t R, uint32_t C, uint32_t ld) {
+  const uint32_t qpr = C >> 2, nq = R * qpr;
+  const bool vec = ((((uintptr_t)M) & 15u) == 0) && ((ld & 3u) == 0);
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    const uint32_t e = min(threadIdx.x + (uint32_t)j * blockDim.x, nq - 1u);      // (past the end: the last quad again, not stored)
+    const uint32_t row = e / qpr, c4 = (e - row * qpr) * 4u;
+    const float* src = M + (size_t)row * ld + c4;
+    if (vec) q.v[j] = *reinterpret_cast<const float4*>(src);
+    else q.v[j] = make_float4(src[0], src[1], src[2], src[3]);
+  }
+}
+template <int MAXQ>
+__device__ __forceinline__ void w_image_store(const WQuads<MAXQ>& q, unsigned char* lds, const WImg& w, uint32_t R, uint32_t C) {
+  const uint32_t qpr = C >> 2, nq = R * qpr;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    const uint32_t e = threadIdx.x + (uint32_t)j * blockDim.x;
+    if (e < nq) {
+      const uint32_t row = e / qpr, c4 = (e - row * qpr) * 4u;
+      typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+      half4v hv;
+      hv[0] = (_Float16)q.v[j].x; hv[1] = (_Float16)q.v[j].y; hv[2] = (_Float16)q.v[j].z; hv[3] = (_Float16)q.v[j].w;
+      lds_write8(lds, w.base + w_off(row, c4 >> 3, w.cs) + 2u * (c4 & 7u), *reinterpret_cast<const uint2*>(&hv));
+    }
+  }
+}
+
 // ---- 32 x 32 tiles of f16 (wave-private, 2 KB); `slot` = byte offset from the wave's area ---------------------------------------
 // the two K-step fragments (CHAIN order) of an accumulator tile -> T[point][feature]: lane (p, h) stores registers 4g .. 4g+3
 // (features 8g + 4h ..) as 8 bytes at T[p][8g + 4h]; 4 ds_write_b64
