@@ -561,7 +561,9 @@ class Mapper:
                                fp16=getattr(self.fine_decoders, "fp16", False))
 
     # ------------------------------------------------------------------ slams/mapping.py:603-635
-    def renderer(self, samples, strict=True):
+    def renderer(self, samples, strict=True, need_coarse=True):
+        """``need_coarse=False`` (forward-only callers that drop the coarse latents, e.g. ``render_frame``): the coarse network is
+        not run and the sixth return value is None."""
         pts = samples["pts"]
         n_pts, n_samples, _ = pts.shape
         z_vals = samples["z_vals"]
@@ -586,10 +588,13 @@ class Mapper:
                 dec.out_fn.color_decoder.params, dec.out_fn.logit_decoder.params, slot, self.pe_dim,
                 net(dec.coarse_fn.decoder), (self.pe_dim + self.grid_dim, self.hidden_dim + 1, pool.nn_, pool.nl),
                 net(dec.out_fn.color_decoder), net(dec.out_fn.logit_decoder),
-                fp16=getattr(dec.coarse_fn.decoder, "fp16", False), n_groups=max(len(pool), 1))
+                fp16=getattr(dec.coarse_fn.decoder, "fp16", False), n_groups=max(len(pool), 1),
+                need_coarse=need_coarse or torch.is_grad_enabled())
+            if not (need_coarse or torch.is_grad_enabled()):
+                coarse_latents = None
             # values_pts = (sigmoid colour | occupancy)
         else:
-            coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts)
+            coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts) if (need_coarse or torch.is_grad_enabled()) else None
             fine_latents = self.fine_fn(pe, classes=classes, features=grid_pts, strict=strict)
             color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((fine_latents[:, 1:], pixel_pts), -1))
             values_pts = torch.cat((color_pts, fine_latents[:, 0:1]), -1)
@@ -670,16 +675,14 @@ class Mapper:
         for start in range(0, H * W, n_pts_batch):
             end = min(start + n_pts_batch, H * W)
             if features is None:
-                # one read-only block of zeros per chunk SHAPE (a fresh 537 MB fill per 65 536-ray chunk otherwise)
-                code = getattr(self, "_zero_code_rf", None)
-                if code is None or code.shape[0] < end - start or code.shape[1:] != (S, self.hidden_dim):
-                    code = self._zero_code_rf = torch.zeros(min(n_pts_batch, H * W), S, self.hidden_dim, device=dev)
-                code = code[:end - start]
+                # no 2-D code: a code of ZERO columns -- the colour / logit networks run as their live (OneBlob + latent)-input
+                # networks (the reference multiplies a zero code through, :553-557; round 4 read a 537 MB block of zeros per chunk)
+                code = torch.empty(end - start, S, 0, device=dev)
             else:
                 code = features[start:end]
             samples = {"rays_o": rays_o[start:end], "rays_d": rays_d[start:end], "gt_label": gt_label[start:end],
                        "pts": pts[start:end], "z_vals": z[start:end], "features": code}
-            color, depth, _, logits, _, _ = self.renderer(samples, strict=False)
+            color, depth, _, logits, _, _ = self.renderer(samples, strict=False, need_coarse=False)
             colors.append(color), depths.append(depth), labels.append(torch.argmax(logits, dim=-1))
         return torch.cat(colors).reshape(H, W, 3), torch.cat(depths).reshape(H, W), torch.cat(labels).reshape(H, W)
 

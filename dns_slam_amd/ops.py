@@ -474,7 +474,8 @@ class _RenderNetsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg):
-        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count, fp16, n_groups = cfg
+        pe_dim, shp_c, shp_f, shp_col, shp_log, min_count, fp16, n_groups = cfg[:8]
+        need_coarse = cfg[8] if len(cfg) > 8 else True
         fp16 = MLP_FP16_FLAG if fp16 else 0
         require_cuda(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point)
         buf = _row_major_2d(buf.float())
@@ -483,26 +484,35 @@ class _RenderNetsFn(torch.autograd.Function):
         keep = MLP_SAVE_HIDDEN
         st = stream_ptr()
 
-        def run(x, x2, n_in1, params, shape, y, ri, tg, n_slots, stride):
+        def run(x, x2, n_in1, params, shape, y, ri, tg, n_slots, stride, live=0):
             n_in, n_out, nn, nl = shape
             h = torch.empty(nl * n_slots * nn, device=dev, dtype=torch.float32) if keep else None
             check(lib.dns_mlp_fwd(ptr(x), x.stride(0), ptr(x2), 0 if x2 is None else x2.stride(0), n_in1, ptr(params),
-                                  n_in, n_out, nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(h), fp16, st),
+                                  n_in, n_out, nn, nl, ptr(y), y.stride(0), n_slots, ptr(ri), ptr(tg), stride, ptr(h), fp16 | live, st),
                   "dns_mlp_fwd")
             return h
 
-        coarse = torch.empty(P, shp_c[1], device=dev, dtype=torch.float32)
-        h_c = run(buf, None, 0, coarse_p, shp_c, coarse, None, None, P, 0)
+        # (need_coarse = False: the forward-only frame render, slams/mapping.py:638-694 -- the coarse latents feed the latent
+        #  loss alone, mapping.py:893-896, and frame_vis drops them: one of the four networks is not run)
+        coarse = torch.empty(P if need_coarse else 0, shp_c[1], device=dev, dtype=torch.float32)
+        h_c = run(buf, None, 0, coarse_p, shp_c, coarse, None, None, P, 0) if need_coarse else None
         ri, tg, n_slots = group_slots(slot_of_point, n_groups or fine_pool.shape[0], min_count)
         fine = torch.zeros(P, shp_f[1], device=dev, dtype=torch.float32)
         h_f = run(buf, None, 0, fine_pool, shp_f, fine, ri, tg, n_slots, fine_pool.shape[-1])
         feat = torch.cat((fine[:, 1:], pixel), -1)                        # [P, hidden + C]
+        # A code of ZERO columns (forward-only callers without a 2-D code: the reference multiplies a zero code through,
+        # slams/mapping.py:553-557): the colour / logit networks run as their live (pe + hidden)-input networks, DNS_MLP_LIVE_IN
+        live = 0
+        if pe_dim + feat.shape[1] < shp_col[0]:
+            if torch.is_grad_enabled() or (pe_dim + feat.shape[1]) % 8 != 0:
+                raise ValueError("render_nets: a code narrower than the networks' input is a forward-only form (no_grad, multiple of 8)")
+            live = MLP_LIVE_IN(pe_dim + feat.shape[1])
         # raw = (sigmoid(colour) | occupancy) = the compositing kernel's input (slams/mapping.py:622-627): the colour
         # network writes its three columns straight into the [P, 4] rows
         raw = torch.empty(P, 4, device=dev, dtype=torch.float32)
         logit = torch.empty(P, shp_log[1], device=dev, dtype=torch.float32)
-        h_col = run(buf, feat, pe_dim, color_p, shp_col, raw, None, None, P, 0)
-        h_log = run(buf, feat, pe_dim, logit_p, shp_log, logit, None, None, P, 0)
+        h_col = run(buf, feat, pe_dim, color_p, shp_col, raw, None, None, P, 0, live)
+        h_log = run(buf, feat, pe_dim, logit_p, shp_log, logit, None, None, P, 0, live)
         raw.sigmoid_()                                                    # column 3 is not written yet
         raw[:, 3] = fine[:, 0]
         ctx.save_for_backward(buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log, raw)
@@ -513,7 +523,9 @@ class _RenderNetsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_coarse, d_fine, d_raw, d_logit):
         buf, feat, coarse_p, fine_pool, color_p, logit_p, ri, tg, h_c, h_f, h_col, h_log, raw = ctx.saved_tensors
-        pe_dim, shp_c, shp_f, shp_col, shp_log, _, fp16, _ = ctx.cfg
+        pe_dim, shp_c, shp_f, shp_col, shp_log, _, fp16, _ = ctx.cfg[:8]
+        if len(ctx.cfg) > 8 and not ctx.cfg[8]:
+            raise RuntimeError("render_nets(need_coarse=False) is forward-only")
         fp16 = MLP_FP16_FLAG if fp16 else 0
         P, dev = buf.shape[0], buf.device
         st = stream_ptr()
@@ -574,13 +586,13 @@ class _RenderNetsFn(torch.autograd.Function):
 
 
 def render_nets(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, pe_dim, shp_coarse, shp_fine,
-                shp_color, shp_logit, min_count=2, fp16=False, n_groups=None):
+                shp_color, shp_logit, min_count=2, fp16=False, n_groups=None, need_coarse=True):
     """-> (coarse [P, h+1], fine [P, h+1], raw [P, 4] = (sigmoid(colour), fine[:, 0]) -- the compositing input --,
     logits [P, n_class]); shapes are (n_in, n_out, n_neurons, n_hidden_layers) tuples (colour n_out = 3).  n_groups: only
     the first n_groups weight sets of fine_pool are in use (slot_of_point < n_groups) -- pass the whole pool rather than
     a slice of it and autograd has no [capacity, n_params] slice gradient to zero-fill and copy into."""
     cfg = (int(pe_dim), tuple(shp_coarse), tuple(shp_fine), tuple(shp_color), tuple(shp_logit), int(min_count), bool(fp16),
-           None if n_groups is None else int(n_groups))
+           None if n_groups is None else int(n_groups), bool(need_coarse))
     return _RenderNetsFn.apply(buf, pixel, coarse_p, fine_pool, color_p, logit_p, slot_of_point, cfg)
 
 
