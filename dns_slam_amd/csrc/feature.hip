@@ -108,6 +108,73 @@ __global__ __launch_bounds__(256) void feature_gather_frames_kernel(const float*
     out[c] = (1.f - ly) * ((1.f - lx) * f00[c] + lx * f01[c]) + ly * ((1.f - lx) * f10[c] + lx * f11[c]);
 }
 
+// The four-channel form of both kernels above (C % 4 == 0 and 16-byte aligned rows: the stem maps have 64 channels): 16 lanes
+// per (reference, point) pair, one float4 of channels per lane -- a wave works on FOUR pairs, so the projection (the same ~40
+// vector instructions in every lane of a pair) is issued a quarter as often and every tap is one 16-byte load per lane.  The
+// one-lane-per-channel kernels were issue-bound at 64 channels (193 us per cfg3 iteration for 786 432 pairs; the 805 MB of taps
+// come out of L2 / MALL, 201 MB are written).  Same expressions per channel: same values.
+template <bool FRAMES>
+__global__ __launch_bounds__(256) void feature_gather4_kernel(const float* __restrict__ pts, const float* __restrict__ w2c,
+                                                              const float* __restrict__ origin, Mat3 K,
+                                                              const float* __restrict__ feat, uint32_t n_ref_total, uint32_t R,
+                                                              uint32_t Pf, uint32_t C, int h, int w, int H, int W,
+                                                              float* __restrict__ code, uint32_t ld_code,
+                                                              float* __restrict__ rel_out, uint8_t* __restrict__ mask_out) {
+  const uint32_t sub = threadIdx.x & 15u;
+  const uint64_t pair = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (pair >= (uint64_t)n_ref_total * Pf) return;
+  const uint32_t rr = (uint32_t)(pair / Pf), pl = (uint32_t)(pair % Pf);
+  const size_t p = FRAMES ? (size_t)(rr / R) * Pf + pl : (size_t)pl;
+  const float x = pts[p * 3], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
+  const float* m = w2c + 16 * rr;
+  const float cx_ = fmaf(m[3], 1.0f, fmaf(m[2], z, fmaf(m[1], y, m[0] * x)));
+  const float cy_ = -fmaf(m[7], 1.0f, fmaf(m[6], z, fmaf(m[5], y, m[4] * x)));
+  const float cz_ = -fmaf(m[11], 1.0f, fmaf(m[10], z, fmaf(m[9], y, m[8] * x)));
+  const float q0 = fmaf(K.k[2], cz_, fmaf(K.k[1], cy_, K.k[0] * cx_));
+  const float q1 = fmaf(K.k[5], cz_, fmaf(K.k[4], cy_, K.k[3] * cx_));
+  const float q2 = fmaf(K.k[8], cz_, fmaf(K.k[7], cy_, K.k[6] * cx_));
+  const float u = rintf(q0 / (q2 + 1e-5f));
+  const float v = rintf(q1 / (q2 + 1e-5f));
+  const bool ok = (u > 0.f) && (u < (float)(W - 1)) && (v > 0.f) && (v < (float)(H - 1)) && (cz_ > 0.f);
+  if (FRAMES) {
+    if (sub < 3u && rel_out) {
+      const float c = sub == 0 ? x : (sub == 1 ? y : z);
+      rel_out[pair * 3 + sub] = c - origin[rr * 3 + sub];
+    }
+  } else if (sub == 0 && mask_out) {
+    mask_out[pair] = ok ? 1 : 0;
+  }
+  float4* out = reinterpret_cast<float4*>(code + pair * ld_code);
+  const uint32_t C4 = C / 4u;
+  if (!ok) {
+    for (uint32_t c = sub; c < C4; c += 16) out[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float sx_scale = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const float sy_scale = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  const float sx = __fmul_rn(sx_scale, u), sy = __fmul_rn(sy_scale, v);
+  const int x0 = (int)sx, y0 = (int)sy;
+  const float lx = sx - (float)x0, ly = sy - (float)y0;
+  const int x1 = x0 + (x0 < w - 1 ? 1 : 0), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+  const float* f = feat + (size_t)rr * h * w * C;
+  const float4* f00 = reinterpret_cast<const float4*>(f + ((size_t)y0 * w + x0) * C);
+  const float4* f01 = reinterpret_cast<const float4*>(f + ((size_t)y0 * w + x1) * C);
+  const float4* f10 = reinterpret_cast<const float4*>(f + ((size_t)y1 * w + x0) * C);
+  const float4* f11 = reinterpret_cast<const float4*>(f + ((size_t)y1 * w + x1) * C);
+  for (uint32_t c = sub; c < C4; c += 16) {
+    const float4 a = f00[c], b = f01[c], d = f10[c], e = f11[c];
+    float4 o;
+    o.x = (1.f - ly) * ((1.f - lx) * a.x + lx * b.x) + ly * ((1.f - lx) * d.x + lx * e.x);
+    o.y = (1.f - ly) * ((1.f - lx) * a.y + lx * b.y) + ly * ((1.f - lx) * d.y + lx * e.y);
+    o.z = (1.f - ly) * ((1.f - lx) * a.z + lx * b.z) + ly * ((1.f - lx) * d.z + lx * e.z);
+    o.w = (1.f - ly) * ((1.f - lx) * a.w + lx * b.w) + ly * ((1.f - lx) * d.w + lx * e.w);
+    out[c] = o;
+  }
+}
+static bool gather4_ok(const float* feat, const float* code, uint32_t C, uint32_t ld_code) {
+  return C % 4u == 0 && ld_code % 4u == 0 && (((uintptr_t)feat | (uintptr_t)code) & 15) == 0 && getenv("DNS_FEATURE_GATHER_LANES") == nullptr;
+}
+
 // World -> camera matrices of the K x R reference views of an iteration (slams/mapping.py:534-547): reference rr takes the pose
 // of target frame src[rr] >= 0 AS IT STANDS IN THE OPTIMISER (quaternion -> rotation as get_rotation_from_quad,
 // utils/common.py:406-429: two_s = 2 / |q|^2, no normalisation; detached: the code carries no pose gradient through the
@@ -201,8 +268,12 @@ extern "C" int dns_feature_gather_frames(const float* pts, const float* w2c, con
   DNS_REQUIRE((pairs + 3) / 4 < (1ull << 31), "dns_feature_gather_frames: too many points");
   Mat3 Km;
   for (int i = 0; i < 9; ++i) Km.k[i] = K[i];
-  DNS_LAUNCH(feature_gather_frames_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pts, w2c, origin, Km,
-             feat, n_frames * R, R, pts_per_frame, C, h, w, H, W, code, ld_code, rel_out);
+  if (gather4_ok(feat, code, C, ld_code))
+    DNS_LAUNCH(feature_gather4_kernel<true>, dim3((uint32_t)((pairs + 15) / 16)), dim3(256), 0, (hipStream_t)stream, pts, w2c, origin,
+               Km, feat, n_frames * R, R, pts_per_frame, C, h, w, H, W, code, ld_code, rel_out, (uint8_t*)nullptr);
+  else
+    DNS_LAUNCH(feature_gather_frames_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pts, w2c, origin, Km,
+               feat, n_frames * R, R, pts_per_frame, C, h, w, H, W, code, ld_code, rel_out);
   return check_launch("dns_feature_gather_frames");
 }
 
@@ -250,7 +321,11 @@ extern "C" int dns_feature_gather(const float* pts, const float* w2c, const floa
   for (int i = 0; i < 9; ++i) Km.k[i] = K[i];
   const uint64_t pairs = (uint64_t)R * P;
   DNS_REQUIRE((pairs + 3) / 4 < (1ull << 31), "dns_feature_gather: too many points");
-  DNS_LAUNCH(feature_gather_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pts, w2c, Km,
-                     feat, R, P, C, h, w, H, W, code, mask);
+  if (gather4_ok(feat, code, C, C))
+    DNS_LAUNCH(feature_gather4_kernel<false>, dim3((uint32_t)((pairs + 15) / 16)), dim3(256), 0, (hipStream_t)stream, pts, w2c,
+               (const float*)nullptr, Km, feat, R, R, P, C, h, w, H, W, code, C, (float*)nullptr, mask);
+  else
+    DNS_LAUNCH(feature_gather_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pts, w2c, Km,
+               feat, R, P, C, h, w, H, W, code, mask);
   return check_launch("dns_feature_gather");
 }
