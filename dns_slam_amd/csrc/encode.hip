@@ -361,7 +361,7 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
-  const uint32_t lpp = lv.n_levels / g_ph;                // levels per grid phase (TILED; host: g_ph divides n_levels)
+  const uint32_t lpp = g_ph ? lv.n_levels / g_ph : 0u;    // levels per grid phase (TILED; host: g_ph divides n_levels; 0: OneBlob columns only)
   // TILED: the workgroup's gradient rows come in through an LDS tile (coalesced row reads instead of one 320-byte-strided
   // row per lane), in TWO phases like the forward -- OneBlob columns, then grid columns -- so that the tile holds
   // max(pe_dim, g_dim) + 1 floats per point (25 KB, 12 waves per CU) instead of the whole row (41 KB, 6 waves): this
@@ -1900,11 +1900,16 @@ extern "C" int dns_encode_bwd(const float* x, const double* bound, uint32_t P, u
     const uint32_t blocks128 = (P + 127) / 128;
     const bool tiled = d_pe && d_grid && d_x && ld_dpe == ld_dgrid && d_grid == d_pe + 3 * n_bins &&
                        ld_dpe == 3 * n_bins + 2 * lv.n_levels;
-    if (tiled) {
+    // OneBlob columns only (Decoder.merge's relative points: 3 x P rows of a [., 48 + 64] matrix per cfg3 iteration): the same
+    // tile staging without grid phases -- the direct form's lanes each walk their own 448-byte-strided row (190 us for 786 432
+    // rows; through the tile: the rows' 192 bytes come in as coalesced runs)
+    const bool tiled_pe = d_pe && !d_grid && d_x && !d_table_direct && 128u * (3u * n_bins + 1u) * sizeof(float) <= 64u * 1024u;
+    if (tiled || tiled_pe) {
       uint32_t pe_ph, g_ph;
-      encode_tile_phases(n_bins, lv.n_levels, true, pe_ph, g_ph);
+      encode_tile_phases(n_bins, tiled_pe ? 1u : lv.n_levels, true, pe_ph, g_ph);
+      if (tiled_pe) g_ph = 0u;
       if ((n_bins % 4u) != 0u) pe_ph = 1u;              // (the staging reads 16 bytes at a time)
-      const uint32_t w_pe = 3 * n_bins / pe_ph, w_g = 2 * lv.n_levels / g_ph;
+      const uint32_t w_pe = 3 * n_bins / pe_ph, w_g = g_ph ? 2 * lv.n_levels / g_ph : 0u;
       DNS_LAUNCH(encode_bwd_kernel<true>, dim3(blocks128), dim3(128), (size_t)128 * ((w_pe > w_g ? w_pe : w_g) + 1) * sizeof(float), st, x,
                          make_bound(bound), bound ? 1 : 0, P, n_bins, (const float2*)table, lv, d_pe, ld_dpe, d_grid, ld_dgrid,
                          d_table_direct, d_x, (const float2*)dy_dx, pe_ph, g_ph);

@@ -920,8 +920,16 @@ def test_oneblob_alone_with_64_bins_leaves_through_the_lds_tile():
     ops = _ops()
     g = torch.Generator().manual_seed(5)
     x = torch.rand(3000, 3, generator=g)
-    y = ops.encode(x.to(DEV), None, None, None, 64, True, False)
-    assert_close(y.cpu(), tr.oneblob_forward(x, 64), rtol=1e-6, what="oneblob n=64")
+    xp = x.to(DEV).requires_grad_(True)
+    y = ops.encode(xp, None, None, None, 64, True, False)
+    assert_close(y.detach().cpu(), tr.oneblob_forward(x, 64), rtol=1e-6, what="oneblob n=64")
+    # ... and its backward (OneBlob-only gradients come in through the LDS tile too when it fits 64 KB: 16 bins; 64 bins: direct rows)
+    gy = torch.randn(3000, 192, generator=g)
+    (y * gy.to(DEV)).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    (tr.oneblob_forward(xo, 64) * gy).sum().backward()
+    d = (xp.grad.cpu() - xo.grad).abs()
+    assert float((d > 1e-4 * xo.grad.abs().max()).float().mean()) < 0.002
 
 
 def test_pair_list_scatter_of_tiny_gradients_stays_finite(monkeypatch):
