@@ -797,9 +797,10 @@ def main():
     # secondary line: the same shapes with the networks in the REFERENCE's own precision (tcnn: f16 activations / weights, loss
     # scale 128 -- models/decoder.py:58-64,94; half rows, ABI v12).  Not the headline: `value` above keeps the fp32-grade networks
     # that BASELINE's 1e-4 parity asks for.  One GPU, the default workload only; skipped with --no-render-forward.
+    skip16 = args.no_render_forward or ctx.world_size != 1 or args.workload != "cfg2" or args.stem_features or args.autograd_step
     try:
-        if args.no_render_forward or ctx.world_size != 1 or args.workload != "cfg2" or args.stem_features or args.autograd_step:
-            raise RuntimeError("skipped")
+        if skip16:
+            raise StopIteration
         wl16 = WORKLOADS["cfg2_fp16"]
         _, _, _, _, mapper16, step16 = build(wl16, device, seed=1000, dist_ctx=ctx, overlap=True, graph=False)
         for _ in range(50):
@@ -819,6 +820,8 @@ def main():
                                       "half_rows": bool(mapper16.map_step.half), "steps": n16, "final_loss": l16,
                                       "what": "cfg2's shapes, the MLPs in tcnn's own precision; eager, two streams; a secondary line"}
         del mapper16, step16
+    except StopIteration:
+        pass                                                  # (not this run's leg: more than one rank / another workload / --no-render-forward)
     except Exception as e:
         out["reference_precision"] = {"error": f"{type(e).__name__}: {e}"}
     if args.loop > 0 and ctx.world_size == 1:
