@@ -41,7 +41,7 @@ __global__ __launch_bounds__(128) void encode_fwd_kernel(const float* __restrict
                                                          uint32_t g_ph) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
+  const uint32_t pe_dim = 3 * n_bins;
   // (TILED) the tile is used pe_ph + g_ph times: OneBlob in 1 or 3 phases (all axes / one axis each), the grid in g_ph groups of
   // levels -- every phase ends in a flush, so the tile holds the widest PHASE + 1 floats per point
   const uint32_t lpp = lv.n_levels / g_ph;                // levels per grid phase (host: g_ph divides n_levels)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(128) void encode_bwd_kernel(const float* __restrict
                                                          const float2* __restrict__ dydx, uint32_t pe_ph, uint32_t g_ph) {
   extern __shared__ float tile[];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t pe_dim = 3 * n_bins, g_dim = 2 * lv.n_levels;
+  const uint32_t pe_dim = 3 * n_bins;
   const uint32_t lpp = g_ph ? lv.n_levels / g_ph : 0u;    // levels per grid phase (TILED; host: g_ph divides n_levels; 0: OneBlob columns only)
   // TILED: the workgroup's gradient rows come in through an LDS tile (coalesced row reads instead of one 320-byte-strided
   // row per lane), in TWO phases like the forward -- OneBlob columns, then grid columns -- so that the tile holds

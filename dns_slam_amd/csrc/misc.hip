@@ -89,11 +89,14 @@ __global__ __launch_bounds__(256) void group_scan_kernel(const uint32_t* __restr
                                                          uint32_t n_tiles, uint32_t* __restrict__ cursor,
                                                          int32_t* __restrict__ tile_group) {
   __shared__ uint32_t start[GROUP_MAX + 1];
+  __shared__ uint32_t cn[GROUP_MAX];                 // (the counts once, in LDS: the tile loop below looked them up in memory per tile)
+  for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) cn[g] = counts[g];
+  __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t o = 0;
     for (uint32_t g = 0; g < G; ++g) {
       start[g] = o;
-      o += (counts[g] + 127u) / 128u * 128u;
+      o += (cn[g] + 127u) / 128u * 128u;
     }
     start[G] = o;
   }
@@ -108,38 +111,78 @@ __global__ __launch_bounds__(256) void group_scan_kernel(const uint32_t* __restr
         const uint32_t mid = (lo + hi) >> 1;
         if (start[mid] <= pos) lo = mid; else hi = mid;
       }
-      if (counts[lo] >= min_count) grp = (int)lo;  // Mapper.fine_fn: a class needs more than one point (mapping.py:597)
+      if (cn[lo] >= min_count) grp = (int)lo;      // Mapper.fine_fn: a class needs more than one point (mapping.py:597)
     }
     tile_group[t] = grp;
   }
 }
 
+// K points per thread (point p = (workgroup K + k) 256 + thread: every k is one coalesced run of the slot array).  The kernel's
+// cost is its GLOBAL atomics -- one per (workgroup, group present) on the group's cursor, same-address atomics that retire at
+// ~10 ns each: a frame render's 4.2 M points per chunk took 179 us with one point per thread (16 384 workgroups) however the
+// points were ranked inside the workgroup; K = 8 makes an eighth of them.  Ranks inside the workgroup: one LDS atomic per
+// (wave, group present in it) -- the wave's first unranked lane names a group, its members rank themselves by a ballot.
+template <int K>
 __global__ __launch_bounds__(256) void group_scatter_kernel(const int64_t* __restrict__ slot, uint32_t P, uint32_t G,
                                                             uint32_t* __restrict__ cursor, int32_t* __restrict__ row_index,
                                                             uint32_t n_slots, uint32_t* __restrict__ err) {
-  // workgroup-aggregated cursors: LDS integer atomics rank the points of the workgroup inside each group, one global
-  // atomic per (workgroup, group) reserves the range
   __shared__ uint32_t cnt[GROUP_MAX];
   __shared__ uint32_t base[GROUP_MAX];
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) cnt[i] = 0;
   __syncthreads();
-  int64_t s = -1;
-  uint32_t rank = 0;
-  if (p < P) {
-    s = slot[p];
-    if (s >= 0 && s < (int64_t)G) rank = atomicAdd(&cnt[(uint32_t)s], 1u); else s = -1;
+  int s[K];
+  uint32_t rank[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t p = (blockIdx.x * K + k) * blockDim.x + threadIdx.x;
+    int64_t v = -1;
+    if (p < P) v = slot[p];
+    s[k] = (v >= 0 && v < (int64_t)G) ? (int)v : -1;
+    rank[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    bool todo = s[k] >= 0;
+    while (__any(todo)) {
+      const uint64_t act = __ballot(todo);
+      const int leader = __ffsll((long long)act) - 1;
+      const int cls = __shfl(s[k], leader);
+      const bool mine = todo && s[k] == cls;
+      const uint64_t m = __ballot(mine);
+      uint32_t first = 0;
+      if ((int)lane == leader) first = atomicAdd(&cnt[(uint32_t)cls], (uint32_t)__popcll(m));
+      first = (uint32_t)__shfl((int)first, leader);
+      if (mine) {
+        rank[k] = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo = false;
+      }
+    }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) base[i] = cnt[i] ? atomicAdd(cursor + i, cnt[i]) : 0u;
   __syncthreads();
-  if (s >= 0) {
-    // The cursors are DEVICE state (written by group_scan_kernel, advanced by atomics): a stale or corrupted one must end as
-    // an error code, not as a store past the table (round 2's memory-access fault was exactly such a consumer)
-    const uint32_t at = base[(uint32_t)s] + rank;
-    if (at < n_slots) row_index[at] = (int32_t)p;
-    else if (err) atomicOr(err, DNS_DEVERR_GROUP_CURSOR);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (s[k] >= 0) {
+      // The cursors are DEVICE state (written by group_scan_kernel, advanced by atomics): a stale or corrupted one must end as
+      // an error code, not as a store past the table (round 2's memory-access fault was exactly such a consumer)
+      const uint32_t p = (blockIdx.x * K + k) * blockDim.x + threadIdx.x;
+      const uint32_t at = base[(uint32_t)s[k]] + rank[k];
+      if (at < n_slots) row_index[at] = (int32_t)p;
+      else if (err) atomicOr(err, DNS_DEVERR_GROUP_CURSOR);
+    }
   }
+}
+
+static void launch_group_scatter(const int64_t* slot_of_point, uint32_t P, uint32_t n_groups, uint32_t* cursor, int32_t* row_index,
+                                 uint32_t n_slots, hipStream_t st) {
+  if (P >= (1u << 20))
+    DNS_LAUNCH(group_scatter_kernel<8>, dim3((P + 2047) / 2048), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index, n_slots,
+               device_error_word());
+  else
+    DNS_LAUNCH(group_scatter_kernel<1>, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index, n_slots,
+               device_error_word());
 }
 
 }  // namespace dns
@@ -194,9 +237,7 @@ extern "C" int dns_group_slots(const int64_t* slot_of_point, uint32_t P, uint32_
     DNS_LAUNCH(group_hist_kernel, dim3(hb), dim3(256), 0, st, slot_of_point, P, n_groups, counts);
   }
   DNS_LAUNCH(group_scan_kernel, dim3(1), dim3(256), 0, st, counts, n_groups, min_count, n_slots / 128u, cursor, tile_group);
-  if (P)
-    DNS_LAUNCH(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index, n_slots,
-               device_error_word());
+  if (P) launch_group_scatter(slot_of_point, P, n_groups, cursor, row_index, n_slots, st);
   return check_launch("dns_group_slots");
 }
 
@@ -207,8 +248,6 @@ extern "C" int dns_group_scatter(const int64_t* slot_of_point, uint32_t P, uint3
   hipStream_t st = (hipStream_t)stream;
   const int rc = ensure_ready(st, "dns_group_scatter");
   if (rc != DNS_OK) return rc;
-  if (P)
-    DNS_LAUNCH(group_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, slot_of_point, P, n_groups, cursor, row_index, n_slots,
-               device_error_word());
+  if (P) launch_group_scatter(slot_of_point, P, n_groups, cursor, row_index, n_slots, st);
   return check_launch("dns_group_scatter");
 }

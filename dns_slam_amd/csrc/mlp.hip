@@ -30,9 +30,16 @@ static uint32_t live_in(uint32_t flags, uint32_t n_in, uint32_t n_in1, bool two)
   return n;
 }
 
-static int check_segments(const char* who, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in) {
+// (any_row_alignment: the FORWARD reads its second segment with 16-byte loads from rows of any 4-byte alignment -- the HSA ABI runs
+//  the memory pipeline in unaligned-access mode, the fused tracker kernel reads the latent out of the coarse network's [P, 33] rows
+//  this way -- so a caller may pass a column slice of another matrix, e.g. fine[:, 1:] with ldx2 = 33, instead of a packed copy)
+static int check_segments(const char* who, const float* x2, uint32_t ldx2, uint32_t n_in1, uint32_t n_in, bool any_row_alignment = false) {
   if (!x2) return DNS_OK;
   DNS_REQUIRE(n_in1 >= 4 && n_in1 < n_in && (n_in1 % 4) == 0, "%s: first input segment must hold a multiple of 4 columns in (0, n_in)", who);
+  if (any_row_alignment) {
+    DNS_REQUIRE((((uintptr_t)x2) % 4) == 0 && ldx2 >= n_in - n_in1, "%s: x2 must be 4-byte aligned with ldx2 >= n_in - n_in1", who);
+    return DNS_OK;
+  }
   DNS_REQUIRE((ldx2 % 4) == 0 && (((uintptr_t)x2) % 16) == 0 && ldx2 >= n_in - n_in1,
               "%s: x2 must be 16-byte aligned with ldx2 %% 4 == 0 and ldx2 >= n_in - n_in1", who);
   return DNS_OK;
@@ -55,7 +62,7 @@ extern "C" int dns_mlp_fwd(const float* x, uint32_t ldx, const float* x2, uint32
   DNS_REQUIRE((ldx % 4) == 0 && (((uintptr_t)x) % 16) == 0, "dns_mlp_fwd: x must be 16-byte aligned with ldx %% 4 == 0");
   DNS_REQUIRE(ldy >= n_out, "dns_mlp_fwd: ldy < n_out");
   {
-    const int rc = check_segments("dns_mlp_fwd", x2, ldx2, n_in1, n_live);
+    const int rc = check_segments("dns_mlp_fwd", x2, ldx2, n_in1, n_live, true);
     if (rc != DNS_OK) return rc;
   }
   const int rc = ensure_ready((hipStream_t)stream, "dns_mlp_fwd");

@@ -499,7 +499,13 @@ class _RenderNetsFn(torch.autograd.Function):
         ri, tg, n_slots = group_slots(slot_of_point, n_groups or fine_pool.shape[0], min_count)
         fine = torch.zeros(P, shp_f[1], device=dev, dtype=torch.float32)
         h_f = run(buf, None, 0, fine_pool, shp_f, fine, ri, tg, n_slots, fine_pool.shape[-1])
-        feat = torch.cat((fine[:, 1:], pixel), -1)                        # [P, hidden + C]
+        if pixel.shape[1] == 0 and not torch.is_grad_enabled():
+            # forward-only, no 2-D code: the colour / logit networks read the latent straight out of the fine rows (second input
+            # segment = fine[:, 1:], row stride hidden + 1: dns_mlp_fwd takes a 4-byte aligned slice) -- no [P, hidden] copy
+            # (537 MB written and read again per 65 536-ray chunk of a frame render)
+            feat = fine[:, 1:]
+        else:
+            feat = torch.cat((fine[:, 1:], pixel), -1)                    # [P, hidden + C]
         # A code of ZERO columns (forward-only callers without a 2-D code: the reference multiplies a zero code through,
         # slams/mapping.py:553-557): the colour / logit networks run as their live (pe + hidden)-input networks, DNS_MLP_LIVE_IN
         live = 0

@@ -225,7 +225,9 @@ int dns_hashgrid_indices(const float* x, uint32_t P, const DnsGridMeta* meta, ui
  * DNS_MLP_FP16 keeps the leading part only (tcnn's own precision: fp16 operands, fp32 accumulate).
  * Two-segment input (x2 != NULL): input columns [0, n_in1) are read from x, columns [n_in1, n_in) from
  * x2[row*ldx2 + (col - n_in1)] -- the torch.cat((pe, features), -1) inputs of decoder.py:73,93,123-124 without
- * the copy.  n_in1 % 4 == 0; x2 16-byte aligned, ldx2 % 4 == 0.  x2 == NULL: one segment (ldx2, n_in1 ignored).
+ * the copy.  n_in1 % 4 == 0; x2 16-byte aligned, ldx2 % 4 == 0 -- dns_mlp_fwd alone takes an x2 of any 4-byte alignment and any
+ * ldx2 >= n_in - n_in1 (a column slice of another matrix, e.g. the latent columns fine[:, 1:] of the [P, 33] rows of the fine
+ * decoders: the forward-only frame render builds no packed copy).  x2 == NULL: one segment (ldx2, n_in1 ignored).
  * A workgroup handles 128 consecutive point SLOTS.  row_index (NULL = identity) maps slot -> row of x / x2 / y /
  * dy / d_x / d_x2, -1 = padding slot (computes on zeros, stores nothing).  tile_group (NULL = one net) gives, per
  * 128-slot tile, the weight set: params + tile_group[t]*param_stride (-1 = skip the tile) -- the per-class

@@ -58,6 +58,34 @@ def test_feature_gather_vs_oracle_large():
     assert float((code_o.abs().sum(-1) > 0).float().mean()) > 0.3          # the test does hit valid pixels
 
 
+def test_feature_gather_four_channels_per_lane_equals_one_lane_per_channel(monkeypatch):
+    """The 2-D code lookup runs 16 lanes x float4 per (reference, point) pair when C % 4 == 0 (four pairs per wave; round 5: the
+    wave-per-pair kernel issued the projection in all 64 lanes).  Same expressions per channel: bit-identical codes and masks;
+    C = 6 (not a multiple of four) still takes the one-lane-per-channel kernel and agrees with the oracle."""
+    from dns_slam_amd import ops
+    g = torch.Generator().manual_seed(4)
+    R, h, w, H, W, P = 3, 60, 80, 120, 160, 5001
+    K = torch.tensor([[100.0, 0, (W - 1) / 2], [0, 100.0, (H - 1) / 2], [0, 0, 1.0]])
+    w2c = torch.eye(4).repeat(R, 1, 1)
+    w2c[:, :3, 3] = torch.randn(R, 3, generator=g) * 0.2
+    pts = torch.randn(P, 3, generator=g) * torch.tensor([1.5, 1.0, 1.0]) + torch.tensor([0.0, 0.0, -3.0])
+    for C in (64, 128, 8):
+        feats = torch.randn(R, h, w, C, generator=g).to(DEV)
+        monkeypatch.delenv("DNS_FEATURE_GATHER_LANES", raising=False)
+        c4, m4 = ops.feature_gather(pts.to(DEV), w2c.to(DEV), K, feats, H, W)
+        monkeypatch.setenv("DNS_FEATURE_GATHER_LANES", "1")
+        c1, m1 = ops.feature_gather(pts.to(DEV), w2c.to(DEV), K, feats, H, W)
+        assert torch.equal(c4, c1) and torch.equal(m4, m1), f"C = {C}"
+        assert float(m4.float().mean()) > 0.2
+    monkeypatch.delenv("DNS_FEATURE_GATHER_LANES", raising=False)
+    from dns_slam_amd.common import feature_matching
+    feats = torch.randn(R, 6, h, w, generator=g)
+    ident = lambda p_, o_, c_: c_
+    code_o = fr.feature_matching(H, W, K, pts, w2c, feats, ident)
+    code_p = feature_matching(H, W, K, pts.to(DEV), w2c.to(DEV), feats.to(DEV), ident).cpu()
+    assert float(((code_o - code_p).abs() > 1e-5).any(-1).float().mean()) < 0.002
+
+
 def test_merge_module_matches_oracle():
     from dns_slam_amd import synthetic
     from dns_slam_amd.decoder import Decoder

@@ -913,6 +913,31 @@ def test_mlp_bwd_dx_from_skips_the_leading_columns():
     assert_close(dp1.cpu(), dp0.cpu(), rtol=1e-5, elementwise=False, what="DX_FROM: dW")
 
 
+def test_render_nets_forward_only_reads_the_latent_out_of_the_fine_rows():
+    """Forward-only callers without a 2-D code (the frame render) pass a code of ZERO columns: the colour / logit networks run as
+    their live (OneBlob + latent)-input networks and read the latent as a column slice of the fine decoders' [P, 33] rows
+    (dns_mlp_fwd: x2 of any 4-byte alignment, ldx2 = 33) -- no packed [P, 32] copy.  Same numbers as the full-width networks on
+    an explicit code of zeros (up to the live-width operand scale of W_in: fp32 rounding)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    P, G, pe_dim, hid, C, n_class, nn, nl = 5000, 3, 48, 32, 32, 8, 64, 2
+    shp_c, shp_f = (80, hid + 1, nn, nl), (80, hid + 1, nn, nl)
+    shp_col, shp_log = (pe_dim + hid + C, 3, nn, nl), (pe_dim + hid + C, n_class, nn, nl)
+    cp = tr.mlp_init(*shp_c, g).to(DEV)
+    pool = torch.stack([tr.mlp_init(*shp_f, g) for _ in range(G)]).to(DEV)
+    colp, logp = tr.mlp_init(*shp_col, g).to(DEV), tr.mlp_init(*shp_log, g).to(DEV)
+    buf = torch.randn(P, 80, generator=g).to(DEV)
+    slot = torch.randint(0, G, (P,), generator=g).to(DEV)
+    with torch.no_grad():
+        _, f0, raw0, log0 = ops.render_nets(buf, torch.empty(P, 0, device=DEV), cp, pool, colp, logp, slot, pe_dim, shp_c, shp_f,
+                                            shp_col, shp_log, need_coarse=False)
+        _, f1, raw1, log1 = ops.render_nets(buf, torch.zeros(P, C, device=DEV), cp, pool, colp, logp, slot, pe_dim, shp_c, shp_f,
+                                            shp_col, shp_log)
+    assert torch.equal(f0, f1)
+    assert_close(raw0.cpu(), raw1.cpu(), rtol=1e-6, what="raw, latent slice vs packed block of zeros")
+    assert_close(log0.cpu(), log1.cpu(), rtol=1e-6, what="logits, latent slice vs packed block of zeros")
+
+
 # ----------------------------------------------------------------------------------------- round 5 (ADVICE r4)
 def test_oneblob_alone_with_64_bins_leaves_through_the_lds_tile():
     """A OneBlob-only call takes the LDS-tiled store path; with n_bins >= 43 its tile is larger than the 64 KB a kernel gets without
