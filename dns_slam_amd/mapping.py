@@ -568,10 +568,12 @@ class Mapper:
         n_pts, n_samples, _ = pts.shape
         z_vals = samples["z_vals"]
         gt_label = samples["gt_label"]
+        slot_rays = None
         if samples.get("point_labels") is not None:
             classes = samples["point_labels"]                              # union-batch shard: the tiling of the WHOLE batch
         elif self.label_layout == "reference_tiled":
-            classes = gt_label.repeat(1, n_samples).flatten(0, 1)          # :613 -- tiles, SURVEY D1
+            classes = None if gt_label.dim() == 1 else gt_label.repeat(1, n_samples).flatten(0, 1)   # :613 -- tiles, SURVEY D1
+            slot_rays = gt_label if gt_label.dim() == 1 else None
         else:
             classes = gt_label.repeat_interleave(n_samples)
         pixel_pts = samples["features"].flatten(0, 1)
@@ -580,7 +582,12 @@ class Mapper:
         if getattr(self, "fused_nets", True) and self.pe_dim % 4 == 0 and self.pe_dim <= 64 and \
                 self.hidden_dim + pixel_pts.shape[1] <= 64 and (self.hidden_dim + pixel_pts.shape[1]) % 4 == 0:
             # the four networks as one autograd node: no cat for the colour / logit input, in-place gradient sums
-            slot = self._class_slots(classes, strict)
+            if slot_rays is not None:
+                # the class -> decoder-row lookup per RAY, then tiled like the labels (the same values as looking up the tiled
+                # labels: 1 / n_samples of the clamp / add / gather work -- a frame render's chunks hold 4.2 M points)
+                slot = self._class_slots(slot_rays, strict).repeat(n_samples)
+            else:
+                slot = self._class_slots(classes, strict)
             dec, pool = self.decoder, self.fine_decoders
             net = lambda m: (m.n_input_dims, m.n_output_dims, m.n_neurons, m.n_hidden_layers)
             coarse_latents, fine_latents, values_pts, logits_pts = ops.render_nets(
@@ -594,6 +601,8 @@ class Mapper:
                 coarse_latents = None
             # values_pts = (sigmoid colour | occupancy)
         else:
+            if classes is None:
+                classes = gt_label.repeat(1, n_samples).flatten(0, 1)
             coarse_latents = self.decoder.coarse_fn(pe, features=grid_pts) if (need_coarse or torch.is_grad_enabled()) else None
             fine_latents = self.fine_fn(pe, classes=classes, features=grid_pts, strict=strict)
             color_pts, logits_pts = self.decoder.out_fn(pe, torch.cat((fine_latents[:, 1:], pixel_pts), -1))

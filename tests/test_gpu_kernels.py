@@ -720,7 +720,13 @@ def test_empty_batches_and_argument_errors():
     p = lambda t: _lib.ptr(t)
     rc = lib.dns_mlp_fwd(p(x), 80, None, 0, 0, p(w), 80, 33, 48, 2, p(yb), 33, 256, None, None, 0, None, 0, None)
     assert rc != 0 and b"unsupported shape" in lib.dns_last_error()
-    rc = lib.dns_mlp_fwd(p(x), 80, p(x[:, 1:]), 80, 48, p(w), 80, 33, 64, 2, p(yb), 33, 256, None, None, 0, None, 0, None)
+    # (the FORWARD takes a second segment of any 4-byte alignment -- a column slice of another matrix --, but not one narrower than
+    #  the columns it must supply; the backward, whose d_x2 stores are 16 bytes wide, keeps the 16-byte rule)
+    rc = lib.dns_mlp_fwd(p(x), 80, p(x[:, 1:]), 16, 48, p(w), 80, 33, 64, 2, p(yb), 33, 256, None, None, 0, None, 0, None)
+    assert rc != 0 and b"x2 must be 4-byte aligned with ldx2 >= n_in - n_in1" in lib.dns_last_error()
+    dyb, dxb, dx2b, wsb = torch.zeros(256, 33, device=DEV), torch.empty(256, 80, device=DEV), torch.empty(256, 80, device=DEV), torch.empty(256 * 64, device=DEV)
+    rc = lib.dns_mlp_bwd(p(x), 80, p(x[:, 1:]), 80, 48, p(dyb), 33, p(w), 80, 33, 64, 2, p(dxb), 80, p(dx2b), 80, None, p(wsb), 256, None, None,
+                         0, None, 0, None)
     assert rc != 0 and b"x2 must be 16-byte aligned" in lib.dns_last_error()
     rc = lib.dns_mlp_fwd(p(x), 80, None, 0, 0, p(w), 80, 33, 64, 2, p(yb), 16, 256, None, None, 0, None, 0, None)
     assert rc != 0 and b"ldy" in lib.dns_last_error()
