@@ -361,3 +361,35 @@ def test_prefetched_draws_and_map_step_same_trajectory_without_host_syncs(worklo
         err = float(((r - runs[0]).abs() / runs[0].abs()).max())
         REPORT.append((f"{workload}: loss trajectory of 16 iterations vs the autograd step (tolerance {tol:g})", err, err / tol, tol))
         assert err <= tol, f"prefetched draws / the fixed launch sequence changed the loss trajectory: max relative difference {err:.2e}"
+
+
+@pytest.mark.parametrize("P,G,layout", [(1 << 21, 5, "tiled"), ((1 << 20) + 77, 40, "random"), (300000, 3, "tiled")])
+def test_group_slots_full_size_is_a_counting_sort(P, G, layout):
+    """dns_group_slots at a frame render's size (4.2 M points per chunk there; above 2^20 points the scatter ranks 8 points per
+    thread -- its cost was one same-address cursor atomic per workgroup and class): every point with a network appears exactly once,
+    inside its group's 128-aligned range; padding slots are -1; tiles carry their group or -1 for groups below min_count."""
+    from dns_slam_amd import ops
+    g = torch.Generator().manual_seed(P % 1000)
+    if layout == "tiled":
+        rays = torch.randint(-1, G, (P // 64 + 1,), generator=g)
+        slot = rays.repeat(64)[:P].contiguous()                    # the reference's tiled labels: long runs of one class per wave
+    else:
+        slot = torch.randint(-1, G, (P,), generator=g)
+        slot[slot == 7] = 3                                        # an empty class
+        slot[:1] = 9                                               # and (if nothing else draws it) a class with few points
+    ri, tg, n_slots = ops.group_slots(slot.to(DEV), G, 2)
+    ri, tg = ri.cpu().long(), tg.cpu().long()
+    counts = torch.bincount(slot[slot >= 0], minlength=G)
+    start = torch.cumsum(torch.cat((torch.zeros(1, dtype=torch.long), (counts + 127) // 128 * 128)), 0)
+    assert n_slots == ri.numel() and int(start[-1]) <= n_slots
+    live = ri >= 0
+    assert int(live.sum()) == int((slot >= 0).sum())
+    assert torch.equal(torch.sort(ri[live]).values, torch.nonzero(slot >= 0).reshape(-1))       # each such point exactly once
+    pos = torch.nonzero(live).reshape(-1)
+    grp_of_pos = torch.bucketize(pos, start[1:], right=True)
+    assert torch.equal(grp_of_pos, slot[ri[live]])                                               # inside its group's range
+    assert bool((pos - start[grp_of_pos] < counts[grp_of_pos]).all())                            # packed at the front of the range
+    tile_pos = torch.arange(tg.numel()) * 128
+    want = torch.bucketize(tile_pos, start[1:], right=True)
+    want = torch.where((tile_pos < start[-1]) & (counts[want.clamp(max=G - 1)] >= 2), want, torch.full_like(want, -1))
+    assert torch.equal(tg, want)

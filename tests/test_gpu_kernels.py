@@ -105,6 +105,25 @@ def test_oneblob_outside_the_unit_interval_and_small_bin_counts(n_bins):
     assert float((d > 1e-4 * xo.grad.abs().max()).float().mean()) < 0.002, f"d x mismatch on {int((d > 1e-4 * xo.grad.abs().max()).sum())} entries"
 
 
+def test_oneblob_only_backward_through_the_lds_tile_at_size():
+    """OneBlob-only gradients (Decoder.merge's relative points: 3 x P rows per cfg3 iteration) come in through the encoder's LDS
+    tile like full rows do -- coalesced runs instead of one strided row per lane (round 5: 190 -> ~55 us for 786 432 rows of a
+    [., 112] matrix; that row stride is test_merge_module_matches_oracle's).  Here: 150 001 points -- a ragged last workgroup --,
+    on and outside the unit cube."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    P, n_bins = 150001, 16
+    x = torch.rand(P, 3, generator=g) * 1.4 - 0.2
+    gy = torch.randn(P, 48, generator=g)
+    xo = x.clone().requires_grad_(True)
+    (tr.oneblob_forward(xo, n_bins) * gy).sum().backward()
+    xp = x.to(DEV).requires_grad_(True)
+    yp = ops.encode(xp, None, None, None, n_bins, True, False)
+    yp.backward(gy.to(DEV))
+    d = (xp.grad.cpu() - xo.grad).abs()
+    assert float((d > 1e-4 * xo.grad.abs().max()).float().mean()) < 0.002, f"{int((d > 1e-4 * xo.grad.abs().max()).sum())} entries differ"
+
+
 def test_encode_input_gradient_from_saved_jacobian_equals_regather(monkeypatch):
     """dL/d(points) of the hash grid, two forms: the forward keeps d(features)/dx per level (ops.SAVE_DY_DX, tcnn's dy_dx,
     SURVEY K3) and the backward is a streaming dot product, or the backward gathers the 8 corners again.  Same value up to
