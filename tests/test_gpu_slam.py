@@ -520,6 +520,12 @@ def test_eval_points_matches_oracle():
             assert float(vp[17, 3]) in (0.0, -100.0)      # single-point class: occupancy logit 0 (or outside)
         else:
             assert lp is None
+        # without a 2-D code (the marching-cubes driver's call): the colour / logit networks run on their live inputs only
+        vz, lz = mapper.eval_points(pts, pixel_pts=None, gt_label_pts=lab, stage=stage, n_pts_batch=1024)
+        voz, loz = sr.eval_points(om, pts, torch.zeros_like(pix), lab, stage)
+        assert_close(vz.cpu(), voz.detach(), what=f"eval_points values without a code ({stage})")
+        if stage == "fine":
+            assert float((lz.cpu() == loz).float().mean()) > 0.995
     lab[5] = 999
     with pytest.raises(ValueError):
         mapper.eval_points(pts, pixel_pts=pix, gt_label_pts=lab, stage="fine")
