@@ -1858,6 +1858,10 @@ extern "C" int dns_encode_fwd_split(const float* in, const double* bound, uint32
     _Float16* xh = reinterpret_cast<_Float16*>(xs_out);
     uint32_t pe_ph, g_ph;
     encode_tile_phases(n_bins, meta->n_levels, true, pe_ph, g_ph);
+    // the f16 flush writes HALF as many bytes per row and phase: the grid columns leave in ONE phase (64-byte row pieces; two phases
+    // = 32-byte pieces cost 0.46 against 0.41 ms per cfg5_fp16 iteration -- the whole step 3.54 against 3.45 --, nothing at cfg2_fp16)
+    static const bool env_phases = getenv("DNS_ENC_PHASES") != nullptr;
+    if (!env_phases) g_ph = 1u;
     const uint32_t w_pe = pe_dim / pe_ph, w_g = g_dim / g_ph;
     const size_t lds_plain = (size_t)128 * ((w_pe > w_g ? w_pe : w_g) + 1) * sizeof(float);
     DNS_LAUNCH((encode_fwd_kernel<true, true>), dim3(blocks), dim3(128), lds_plain, (hipStream_t)stream, in, make_bound(bound), bound ? 1 : 0, P,
